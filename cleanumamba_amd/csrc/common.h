@@ -1,0 +1,99 @@
+// Shared device/host helpers for libcleanumamba_hip (gfx950 only: wave64, 4 SIMDs/CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cleanumamba_hip.h"
+
+#define CUM_WAVE 64
+
+extern "C" void cum_set_error(const char *msg);
+
+#define CUM_REQUIRE(cond, msg)  \
+  do {                          \
+    if (!(cond)) {              \
+      cum_set_error(msg);       \
+      return CUM_EINVAL;        \
+    }                           \
+  } while (0)
+
+#define CUM_CHECK_LAUNCH()                      \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) {                    \
+      cum_set_error(hipGetErrorString(e__));    \
+      return CUM_ELAUNCH;                       \
+    }                                           \
+  } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+namespace cum {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each).  The libm
+// expf/log1pf expand to ~100 instructions apiece, which would cost as much per (t, d)
+// as the 64 state updates they feed.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// log1p(e) for e >= 0 with the u = 1 + e compensation: log(u) * e / (u - 1).
+__device__ __forceinline__ float fast_log1p(float e) {
+  const float u = 1.f + e;
+  const float l = __builtin_amdgcn_logf(u) * kLn2;
+  const float um1 = u - 1.f;
+  return um1 == 0.f ? e : l * (e * fast_rcp(um1));
+}
+// softplus with the upstream threshold: x <= 20 ? log1p(exp(x)) : x
+__device__ __forceinline__ float softplus20(float x) { return x <= 20.f ? fast_log1p(fast_exp(x)) : x; }
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.f + fast_exp(-x)); }
+
+// Hide a wave-uniform pointer from the optimiser so that per-step address arithmetic
+// stays inside its step instead of being precomputed (and spilled) for a whole chunk.
+template <typename T>
+__device__ __forceinline__ T *opaque(T *p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// wave-uniform value -> SGPR
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// DPP helpers (row = 16 lanes).  ctrl: quad_perm 0x00-0xFF, row_ror:n = 0x120+n.
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum `v` over the 16 lanes of each row; every lane of the row ends with the sum.
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp<0x128>(v);  // row_ror:8
+  v += dpp<0x124>(v);  // row_ror:4
+  v += dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  return v;
+}
+
+// Reduce-scatter of 16 per-lane values over the 64 lanes of a wave.
+// On return r[0..3] of every lane in row q (= lane>>4) hold the 64-lane sums of
+// v[4*q .. 4*q+3]... (see body for the exact index map: idx = 8*(q>>1) + 4*(q&1) + i).
+__device__ __forceinline__ void wave_reduce_scatter16(const float (&v)[16], float (&r)[4]) {
+  float h[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    // lanes 32-63 of a swap with lanes 0-31 of b; then a+b = pair sums: v[i] in lanes <32, v[8+i] in lanes >=32
+    auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[i]), __builtin_bit_cast(unsigned, v[8 + i]), false, false);
+    h[i] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  }
+  float q4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // odd rows of a swap with even rows of b: even rows keep h[i], odd rows keep h[4+i]
+    auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h[i]), __builtin_bit_cast(unsigned, h[4 + i]), false, false);
+    q4[i] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = row16_allsum(q4[i]);
+}
+
+}  // namespace cum

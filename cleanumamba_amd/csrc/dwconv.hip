@@ -1,0 +1,233 @@
+// Causal depthwise conv1d (+SiLU) forward / backward / streaming update for gfx950.
+//
+// Replaces causal_conv1d_cuda.{causal_conv1d_fwd,_bwd,_update} of causal-conv1d 1.1.0,
+// reached from Mamba.forward / Mamba.step (call pattern: src/network/S4/MambaS4.py:454-463;
+// torch equivalent act(conv1d(x, padding=W-1)[..., :L]) at :455).  SURVEY.md Appendix A.4.
+//
+// Pure HBM-bandwidth kernels.  lane <-> channel (channel-contiguous rows are read as
+// coalesced 256-B segments), each thread walks TC consecutive time steps with the W-1
+// halo rows in registers, so every input row is fetched 1 + (W-1)/TC times.
+#include "common.h"
+
+namespace cum {
+
+constexpr int TC = 16;    // time steps per thread
+constexpr int MAXW = 4;   // kernel width supported (reference uses d_conv = 4)
+
+struct ConvParams {
+  cum_conv_shape s;
+  const float *x, *w, *bias, *dy;
+  float *y, *dx, *ws;   // ws: [batch * nchunks][MAXW + 1][dim] partial dweight / dbias
+  int64_t dx_sb, dx_sd, dx_sl;
+  int nchunks;
+};
+
+template <int W>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ConvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 64 + lane;
+  const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  const int L = p.s.len;
+  const int t0 = chunk * TC;
+  if (d >= p.s.dim || t0 >= L) return;
+  float wk[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) wk[k] = p.w[d * W + k];
+  const float bs = p.bias ? p.bias[d] : 0.f;
+  const float *xp = p.x + b * p.s.x_sb + d * p.s.x_sd;
+  float *yp = p.y + b * p.s.y_sb + d * p.s.y_sd;
+  float xv[TC + W - 1];
+#pragma unroll
+  for (int i = 0; i < TC + W - 1; ++i) {
+    const int t = t0 - (W - 1) + i;
+    const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
+    const float v = xp[(int64_t)tc * p.s.x_sl];
+    xv[i] = (t >= 0 && t < L) ? v : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TC; ++i) {
+    const int t = t0 + i;
+    float acc = bs;
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc = fmaf(wk[k], xv[i + k], acc);
+    if (p.s.silu) acc = acc * sigmoidf_(acc);
+    if (t < L) yp[(int64_t)t * p.s.y_sl] = acc;
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ConvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 64 + lane;
+  const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  const int L = p.s.len;
+  const int t0 = chunk * TC;
+  if (d >= p.s.dim || chunk >= p.nchunks) return;
+  float wk[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) wk[k] = p.w[d * W + k];
+  const float bs = p.bias ? p.bias[d] : 0.f;
+  const float *xp = p.x + b * p.s.x_sb + d * p.s.x_sd;
+  const float *dyp = p.dy + b * p.s.y_sb + d * p.s.y_sd;
+  float *dxp = p.dx + b * p.dx_sb + d * p.dx_sd;
+  // x rows t0-(W-1) .. t0+TC+W-2, dy rows t0 .. t0+TC+W-2
+  float xv[TC + 2 * (W - 1)], g[TC + W - 1];
+#pragma unroll
+  for (int i = 0; i < TC + 2 * (W - 1); ++i) {
+    const int t = t0 - (W - 1) + i;
+    const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
+    const float v = xp[(int64_t)tc * p.s.x_sl];
+    xv[i] = (t >= 0 && t < L) ? v : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TC + W - 1; ++i) {
+    const int s = t0 + i;
+    const int sc = s < L ? s : L - 1;
+    const float v = dyp[(int64_t)sc * p.s.y_sl];
+    float gi = s < L ? v : 0.f;
+    if (p.s.silu) {
+      float pre = bs;
+#pragma unroll
+      for (int k = 0; k < W; ++k) pre = fmaf(wk[k], xv[i + k], pre);
+      const float sg = sigmoidf_(pre);
+      gi *= sg * (1.f + pre * (1.f - sg));
+    }
+    g[i] = gi;
+  }
+  float dwk[W], db = 0.f;
+#pragma unroll
+  for (int k = 0; k < W; ++k) dwk[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TC; ++i) {
+    const int t = t0 + i;
+    // dx[t] = sum_k w[k] g[t + (W-1) - k]
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc = fmaf(wk[k], g[i + (W - 1) - k], acc);
+    if (t < L) dxp[(int64_t)t * p.dx_sl] = acc;
+    // dw[k] += g[s] x[s-(W-1)+k] for s = t (each s counted by exactly one chunk)
+#pragma unroll
+    for (int k = 0; k < W; ++k) dwk[k] = fmaf(g[i], xv[i + k], dwk[k]);
+    db += g[i];
+  }
+  float *ws = p.ws + ((int64_t)(b * p.nchunks + chunk) * (MAXW + 1)) * p.s.dim + d;
+#pragma unroll
+  for (int k = 0; k < W; ++k) ws[(int64_t)k * p.s.dim] = dwk[k];
+  ws[(int64_t)MAXW * p.s.dim] = db;
+}
+
+// dweight[d][k] = sum over (batch, chunk) slabs; dbias likewise.  One thread per (k, d).
+__global__ void dwconv_bwd_finalize_kernel(const float *ws, int nslabs, int dim, int W, float *dweight, float *dbias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (MAXW + 1) * dim) return;
+  const int k = i / dim, d = i % dim;
+  if (k >= W && k != MAXW) return;
+  float s = 0.f;
+  for (int j = 0; j < nslabs; ++j) s += ws[((int64_t)j * (MAXW + 1) + k) * dim + d];
+  if (k == MAXW) {
+    if (dbias) dbias[d] = s;
+  } else {
+    dweight[d * W + k] = s;
+  }
+}
+
+__global__ void dwconv_update_kernel(int batch, int dim, int W, float *__restrict__ state, const float *__restrict__ x,
+                                     const float *__restrict__ w, const float *__restrict__ bias, int silu,
+                                     float *__restrict__ y) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)batch * dim) return;
+  const int d = i % dim;
+  float *st = state + i * W;
+  float acc = bias ? bias[d] : 0.f;
+  for (int k = 0; k < W; ++k) {
+    const float v = (k + 1 < W) ? st[k + 1] : x[i];
+    st[k] = v;
+    acc = fmaf(w[d * W + k], v, acc);
+  }
+  if (silu) acc = acc * sigmoidf_(acc);
+  y[i] = acc;
+}
+
+}  // namespace cum
+
+using namespace cum;
+
+static int conv_check(const cum_conv_shape *s) {
+  CUM_REQUIRE(s != nullptr, "conv: null shape");
+  CUM_REQUIRE(s->batch >= 0 && s->dim >= 1 && s->len >= 0, "conv: bad batch/dim/len");
+  CUM_REQUIRE(s->width >= 1 && s->width <= MAXW, "conv: width must be in [1, 4]");
+  CUM_REQUIRE(s->batch <= 65535, "conv: batch > 65535");
+  return CUM_OK;
+}
+
+extern "C" int cum_causal_conv1d_fwd(const cum_conv_shape *s, const float *x, const float *weight, const float *bias,
+                                     float *y, void *stream) {
+  if (int rc = conv_check(s)) return rc;
+  CUM_REQUIRE(x && weight && y, "conv_fwd: null tensor");
+  if (s->batch == 0 || s->len == 0) return CUM_OK;
+  ConvParams p{};
+  p.s = *s; p.x = x; p.w = weight; p.bias = bias; p.y = y;
+  p.nchunks = (s->len + TC - 1) / TC;
+  dim3 grid((s->dim + 63) / 64, (p.nchunks + 3) / 4, s->batch), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (s->width) {
+    case 1: hipLaunchKernelGGL(dwconv_fwd_kernel<1>, grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL(dwconv_fwd_kernel<2>, grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL(dwconv_fwd_kernel<3>, grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL(dwconv_fwd_kernel<4>, grid, block, 0, st, p); break;
+  }
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+extern "C" int64_t cum_conv_bwd_workspace_elems(int32_t batch, int32_t dim, int32_t len, int32_t width) {
+  (void)width;
+  const int64_t nchunks = (len + TC - 1) / TC;
+  return (int64_t)batch * nchunks * (MAXW + 1) * dim;
+}
+
+extern "C" int cum_causal_conv1d_bwd(const cum_conv_shape *s, const float *x, const float *weight, const float *bias,
+                                     const float *dy, float *dx, int64_t dx_sb, int64_t dx_sd, int64_t dx_sl,
+                                     float *dweight, float *dbias, float *workspace, void *stream) {
+  if (int rc = conv_check(s)) return rc;
+  CUM_REQUIRE(x && weight && dy && dx && dweight, "conv_bwd: null tensor");
+  hipStream_t st = (hipStream_t)stream;
+  if (s->batch == 0 || s->len == 0) {
+    (void)hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)s->dim * s->width, st);
+    if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * s->dim, st);
+    return CUM_OK;
+  }
+  CUM_REQUIRE(workspace, "conv_bwd: workspace required");
+  ConvParams p{};
+  p.s = *s; p.x = x; p.w = weight; p.bias = bias; p.dy = dy; p.dx = dx; p.ws = workspace;
+  p.dx_sb = dx_sb; p.dx_sd = dx_sd; p.dx_sl = dx_sl;
+  p.nchunks = (s->len + TC - 1) / TC;
+  dim3 grid((s->dim + 63) / 64, (p.nchunks + 3) / 4, s->batch), block(256);
+  switch (s->width) {
+    case 1: hipLaunchKernelGGL(dwconv_bwd_kernel<1>, grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL(dwconv_bwd_kernel<2>, grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL(dwconv_bwd_kernel<3>, grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL(dwconv_bwd_kernel<4>, grid, block, 0, st, p); break;
+  }
+  CUM_CHECK_LAUNCH();
+  const int total = (MAXW + 1) * s->dim;
+  hipLaunchKernelGGL(dwconv_bwd_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace,
+                     s->batch * p.nchunks, s->dim, s->width, dweight, dbias);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+extern "C" int cum_causal_conv1d_update(int32_t batch, int32_t dim, int32_t width, float *conv_state, const float *x,
+                                        const float *weight, const float *bias, int32_t silu, float *y,
+                                        void *stream) {
+  CUM_REQUIRE(batch >= 0 && dim >= 1 && width >= 1, "conv_update: bad sizes");
+  CUM_REQUIRE(conv_state && x && weight && y, "conv_update: null tensor");
+  if (batch == 0) return CUM_OK;
+  const int64_t total = (int64_t)batch * dim;
+  hipLaunchKernelGGL(dwconv_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     batch, dim, width, conv_state, x, weight, bias, silu, y);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}

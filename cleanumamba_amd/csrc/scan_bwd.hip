@@ -1,0 +1,401 @@
+// Selective scan backward for gfx950.
+//
+// Replaces selective_scan_cuda.bwd of mamba-ssm 1.2.2 (autograd of the op the reference
+// reaches through Mamba.forward, src/network/CleanUMamba.py:289-290 under
+// scaler.scale(loss).backward(), src/training/train.py:282-285).
+// Gradient formulas: SURVEY.md Appendix A.3.  Mapping: scan_common.h.
+//
+// The forward saved the state entering every 16-step chunk.  Chunks are walked in
+// reverse; inside a chunk each wave recomputes the states of one 8-step half into
+// VGPRs (8 x NS registers) and walks that half backwards:
+//     second half:  x0 -> 8 plain steps -> x8 ; 7 steps saving states ; reverse 15..8
+//     first half :  x0 -> 7 steps saving states ; reverse 7..0
+// i.e. 1.4 recomputed forward steps + 1 reverse step per time step (2.4 v_exp_f32 per
+// state element).  Sums over the channel axis (dB, dC) are reduced inside the wave with
+// v_permlane32_swap / v_permlane16_swap + DPP row adds; sums over workgroups (dB, dC)
+// and over the batch (dA, dD, dbias) go through fp32 slabs and a deterministic finalize
+// kernel -- no float atomics, bit-reproducible run to run.
+#include "scan_common.h"
+
+namespace cum {
+
+// Sum 8 per-lane values over the 64 lanes.  On return lanes of row q = lane>>4 hold in
+// r[0], r[1] the totals of v[2q], v[2q+1].
+__device__ __forceinline__ void wave_reduce_scatter8(const float (&v)[NS], float (&r)[2]) {
+  float h[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // lanes 32-63 of a swap with lanes 0-31 of b: a+b = pair sums of v[i] (lanes <32) / v[4+i] (lanes >=32)
+    auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[i]), __builtin_bit_cast(unsigned, v[4 + i]), false, false);
+    h[i] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  }
+  float q[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // odd rows of a swap with even rows of b: even rows keep h[i], odd rows keep h[2+i]
+    auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h[i]), __builtin_bit_cast(unsigned, h[2 + i]), false, false);
+    q[i] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+  }
+  // row q now holds 4-lane sums of v[4*(q>>1) + 2*(q&1) + i] = v[2q + i]
+  r[0] = row16_allsum(q[0]);
+  r[1] = row16_allsum(q[1]);
+}
+
+template <int NW, bool FAST>
+__global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
+  constexpr int K = (TB + NW - 1) / NW;
+  __shared__ float s_dt[TB][64];
+  __shared__ float s_du[TB][64];
+  __shared__ float s_dy[TB][64];
+  __shared__ float s_p1[NW][SUB][64];  // sum_n g * A'   (-> ddelta)
+  __shared__ float s_p2[NW][SUB][64];  // sum_n dx * B   (-> ddelta, du)
+  __shared__ float s_y[NW][SUB][64];   // sum_n C * x_t  (-> dz)
+
+  const int lane = threadIdx.x & 63;
+  const int w = uniform(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const int g = blockIdx.x;
+  const int d = g * 64 + lane;
+  const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
+  const bool dok = d < Dm;
+  const int dc = dok ? d : Dm - 1;
+  const int n0 = w * NS;
+  const int nvalid = (N - n0) < NS ? (N - n0) : NS;
+  const int nchunks = p.nchunks;
+
+  float Ap[NS], dAacc[NS], dxc[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int jj = j < nvalid ? j : nvalid - 1;
+    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    Ap[j] = (j < nvalid) ? a : 0.f;
+    dAacc[j] = 0.f;
+    dxc[j] = 0.f;
+  }
+  const float Dd = p.D ? p.D[dc] : 0.f;
+  const float bias = p.bias ? p.bias[dc] : 0.f;
+  const float *up = p.u + b * p.s.u_sb + dc * p.s.u_sd;
+  const float *dtp = p.delta + b * p.s.dt_sb + dc * p.s.dt_sd;
+  const bool has_z = p.z != nullptr;
+  const float *zp = has_z ? p.z + b * p.s.z_sb + dc * p.s.z_sd : up;
+  const float *dop = p.dout + b * p.s.o_sb + dc * p.s.o_sd;
+  float *dup = p.du + b * p.gs.du_sb + dc * p.gs.du_sd;
+  float *ddtp = p.ddelta + b * p.gs.dd_sb + dc * p.gs.dd_sd;
+  float *dzp = has_z ? p.dz + b * p.gs.dz_sb + dc * p.gs.dz_sd : nullptr;
+  const int du_sl = (int)p.gs.du_sl, dd_sl = (int)p.gs.dd_sl, dz_sl = (int)p.gs.dz_sl;
+  const float *Bw = p.Bm + b * p.s.B_sb + n0 * p.s.B_sn;
+  const float *Cw = p.Cm + b * p.s.C_sb + n0 * p.s.C_sn;
+  float *wsB = p.ws_dB + ((int64_t)b * p.ngroups + g) * L * N + n0;
+  float *wsC = p.ws_dC + ((int64_t)b * p.ngroups + g) * L * N + n0;
+  const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
+  const int o_sl = (int)p.s.o_sl;
+  const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
+  const int softplus = p.s.delta_softplus;
+
+  float accD = 0.f, accBias = 0.f;
+
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int t0 = c * TB;
+    const int tlast = L - 1 - t0;  // last valid local step of this chunk (>= 0)
+    float eu[K], ez[K], edo[K], edt[K], esg[K];
+    // ---- phase A: per-(t, d) quantities, once, into LDS
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int tl = w + k * NW;
+      const bool ok = dok && tl < TB && tl <= tlast;
+      const int tc = t0 + (tl <= tlast ? tl : tlast);  // clamped address, masked value
+      const float uv = up[tc * u_sl];
+      const float dv = dtp[tc * dt_sl];
+      const float zv = zp[tc * z_sl];
+      const float dov = dop[tc * o_sl];
+      const float pre = dv + bias;
+      float dtv = pre, sg = 1.f;
+      if (softplus) {
+        dtv = softplus20(pre);
+        sg = pre <= 20.f ? sigmoidf_(pre) : 1.f;
+      }
+      dtv = ok ? dtv : 0.f;
+      float dy = ok ? dov : 0.f;
+      if (has_z) dy *= zv * sigmoidf_(zv);
+      if (tl < TB) {
+        s_dt[tl][lane] = dtv;
+        s_du[tl][lane] = ok ? dtv * uv : 0.f;
+        s_dy[tl][lane] = ok ? dy : 0.f;
+      }
+      eu[k] = uv; ez[k] = zv; edo[k] = dov; edt[k] = dtv; esg[k] = sg;
+    }
+    __syncthreads();
+
+    const float *ck = p.ckpt_in + (((int64_t)b * nchunks + c) * N + n0) * Dm + dc;
+    auto load_ckpt = [&](float (&x)[NS]) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int jj = j < nvalid ? j : nvalid - 1;
+        const float v = ck[(int64_t)jj * Dm];
+        x[j] = (j < nvalid) ? v : 0.f;
+      }
+    };
+    // one recomputed forward step (state only)
+    auto fwd_step = [&](float (&x)[NS], int tl) {
+      const int tc = tl <= tlast ? tl : tlast;
+      float bv[NS];
+      load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, bv);
+      const float dt = s_dt[tl][lane];
+      const float du = s_du[tl][lane];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
+        x[j] = fmaf(a, x[j], du * bv[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // one reverse step; xp = state before step tl; slot = tl % SUB
+    auto rev_step = [&](const float (&xp)[NS], int tl, int slot) {
+      const int tc = tl <= tlast ? tl : tlast;
+      float bv[NS], cv[NS];
+      load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, bv);
+      load_bc<FAST>(opaque(Cw + (t0 + tc) * C_sl), C_sn, nvalid, cv);
+      const float dt = s_dt[tl][lane];
+      const float du = s_du[tl][lane];
+      const float dy = s_dy[tl][lane];
+      float p1 = 0.f, p2 = 0.f, yp = 0.f;
+      float dBp[NS], dCp[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
+        const float xt = fmaf(a, xp[j], du * bv[j]);
+        const float dx = fmaf(cv[j], dy, dxc[j]);
+        yp = fmaf(cv[j], xt, yp);
+        dCp[j] = dy * xt;
+        dBp[j] = dx * du;
+        const float gg = dx * xp[j] * a;
+        dAacc[j] = fmaf(gg, dt, dAacc[j]);
+        p1 = fmaf(gg, Ap[j], p1);
+        p2 = fmaf(dx, bv[j], p2);
+        dxc[j] = a * dx;
+      }
+      s_p1[w][slot][lane] = p1;
+      s_p2[w][slot][lane] = p2;
+      s_y[w][slot][lane] = yp;
+      float rB[2], rC[2];
+      wave_reduce_scatter8(dBp, rB);
+      wave_reduce_scatter8(dCp, rC);
+      if ((lane & 15) == 0 && tl <= tlast) {
+        const int q = lane >> 4;
+        const int64_t row = (int64_t)(t0 + tl) * N;
+        if (2 * q < nvalid) {
+          wsB[row + 2 * q] = rB[0];
+          wsC[row + 2 * q] = rC[0];
+        }
+        if (2 * q + 1 < nvalid) {
+          wsB[row + 2 * q + 1] = rB[1];
+          wsC[row + 2 * q + 1] = rC[1];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // phase C for one half: combine the per-wave partial sums, write du / ddelta / dz
+    auto finish_half = [&](int half) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int tl = w + k * NW;
+        const int slot = tl - half * SUB;
+        if (tl < TB && slot >= 0 && slot < SUB && tl <= tlast && dok) {
+          const int t = t0 + tl;
+          float q1 = 0.f, q2 = 0.f, y = Dd * eu[k];
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) {
+            q1 += s_p1[ww][slot][lane];
+            q2 += s_p2[ww][slot][lane];
+            y += s_y[ww][slot][lane];
+          }
+          const float zv = ez[k], dov = edo[k];
+          float dy = dov;
+          if (has_z) {
+            const float sz = sigmoidf_(zv);
+            dy = dov * zv * sz;
+            dzp[t * dz_sl] = dov * y * sz * (1.f + zv * (1.f - sz));
+          }
+          const float ddt = kLn2 * q1 + eu[k] * q2;  // d loss / d delta'
+          const float dpre = ddt * esg[k];
+          dup[t * du_sl] = fmaf(dy, Dd, edt[k] * q2);
+          ddtp[t * dd_sl] = dpre;
+          accD = fmaf(dy, eu[k], accD);
+          accBias += dpre;
+        }
+      }
+    };
+
+    float xs[SUB][NS];
+    // ---- second half (local steps 8..15), only if the chunk reaches it
+    if (tlast >= SUB) {
+      float x[NS];
+      load_ckpt(x);
+#pragma unroll
+      for (int tl = 0; tl < SUB; ++tl) fwd_step(x, tl);
+#pragma unroll
+      for (int s = 0; s < SUB; ++s) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) xs[s][j] = x[j];
+        if (s + 1 < SUB) fwd_step(x, SUB + s);
+      }
+#pragma unroll
+      for (int s = SUB - 1; s >= 0; --s) rev_step(xs[s], SUB + s, s);
+      __syncthreads();
+      finish_half(1);
+      __syncthreads();  // partial-sum buffers are reused by the first half
+    }
+    // ---- first half (local steps 0..7)
+    {
+      float x[NS];
+      load_ckpt(x);
+#pragma unroll
+      for (int s = 0; s < SUB; ++s) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) xs[s][j] = x[j];
+        if (s + 1 < SUB) fwd_step(x, s);
+      }
+#pragma unroll
+      for (int s = SUB - 1; s >= 0; --s) rev_step(xs[s], s, s);
+      __syncthreads();
+      finish_half(0);
+    }
+    // The next chunk's phase A writes only s_dt/s_du/s_dy (their readers finished before
+    // the last barrier) and its first rev_step runs after that phase's barrier, which
+    // every wave reaches only after this finish_half.
+  }
+  // ---- per-(b, d, n) dA and per-(b, d) dD / dbias slabs
+  if (dok) {
+    float *wa = p.ws_dA + ((int64_t)b * Dm + d) * N + n0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (j < nvalid) wa[j] = dAacc[j];
+  }
+  __syncthreads();
+  s_p1[w][0][lane] = accD;
+  s_p2[w][0][lane] = accBias;
+  __syncthreads();
+  if (w == 0 && dok) {
+    float a = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      a += s_p1[ww][0][lane];
+      c2 += s_p2[ww][0][lane];
+    }
+    p.ws_dD[(int64_t)b * Dm + d] = a;
+    p.ws_dbias[(int64_t)b * Dm + d] = c2;
+  }
+}
+
+// Deterministic slab reductions: dA, dD, dbias over batch; dB, dC over channel groups.
+__global__ void scan_bwd_finalize_kernel(const ScanParams p, float *dA, float *dD, float *dbias, float *dB,
+                                         float *dC) {
+  const int64_t N = p.s.dstate, L = p.s.len, Dm = p.s.dim, Bn = p.s.batch, G = p.ngroups;
+  const int64_t nA = Dm * N, nBC = Bn * L * N;
+  const int64_t total = nA + 2 * Dm + 2 * nBC;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nA) {
+      float s = 0.f;
+      for (int64_t b = 0; b < Bn; ++b) s += p.ws_dA[b * nA + i];
+      dA[i] = s;
+    } else if (i < nA + Dm) {
+      const int64_t d = i - nA;
+      float s = 0.f;
+      for (int64_t b = 0; b < Bn; ++b) s += p.ws_dD[b * Dm + d];
+      if (dD) dD[d] = s;
+    } else if (i < nA + 2 * Dm) {
+      const int64_t d = i - nA - Dm;
+      float s = 0.f;
+      for (int64_t b = 0; b < Bn; ++b) s += p.ws_dbias[b * Dm + d];
+      if (dbias) dbias[d] = s;
+    } else {
+      int64_t r = i - nA - 2 * Dm;
+      const bool isC = r >= nBC;
+      if (isC) r -= nBC;
+      const int64_t b = r / (L * N), tn = r % (L * N);
+      const float *ws = (isC ? p.ws_dC : p.ws_dB) + b * G * L * N + tn;
+      float s = 0.f;
+      for (int64_t gg = 0; gg < G; ++gg) s += ws[gg * L * N];
+      (isC ? dC : dB)[r] = s;
+    }
+  }
+}
+
+template <int NW>
+static int launch_bwd(const ScanParams &p, hipStream_t st) {
+  dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
+  const bool fast = p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW;
+  if (fast)
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, true>), grid, block, 0, st, p);
+  else
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, false>), grid, block, 0, st, p);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+}  // namespace cum
+
+using namespace cum;
+
+extern "C" int64_t cum_scan_bwd_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len) {
+  const int64_t G = (dim + 63) / 64;
+  return (int64_t)batch * dim * dstate + 2 * (int64_t)batch * dim + 2 * (int64_t)batch * G * len * dstate;
+}
+
+extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs, const float *u,
+                                      const float *delta, const float *A,
+                                      const float *Bm, const float *Cm, const float *D, const float *z,
+                                      const float *delta_bias, const float *dout, const float *ckpt, float *du,
+                                      float *ddelta, float *dA, float *dB, float *dC, float *dD, float *dz,
+                                      float *ddelta_bias, float *workspace, void *stream) {
+  if (int rc = scan_check_shape(s)) return rc;
+  CUM_REQUIRE(gs && u && delta && A && Bm && Cm && dout && du && ddelta && dA && dB && dC, "scan_bwd: null tensor");
+  {
+    const int64_t lim = 2147483647LL, Lm = s->len > 0 ? s->len - 1 : 0;
+    CUM_REQUIRE(gs->du_sl >= 0 && gs->dd_sl >= 0 && gs->dz_sl >= 0 && Lm * gs->du_sl < lim && Lm * gs->dd_sl < lim &&
+                    Lm * gs->dz_sl < lim,
+                "scan_bwd: gradient time strides must be non-negative and fit in 31 bits");
+  }
+  CUM_REQUIRE((z == nullptr) == (dz == nullptr), "scan_bwd: z and dz must be given together");
+  hipStream_t st = (hipStream_t)stream;
+  if (s->batch == 0 || s->len == 0) {
+    (void)hipMemsetAsync(dA, 0, sizeof(float) * (size_t)s->dim * s->dstate, st);
+    if (dD) (void)hipMemsetAsync(dD, 0, sizeof(float) * s->dim, st);
+    if (ddelta_bias) (void)hipMemsetAsync(ddelta_bias, 0, sizeof(float) * s->dim, st);
+    return CUM_OK;
+  }
+  CUM_REQUIRE(ckpt && workspace, "scan_bwd: ckpt and workspace are required");
+  ScanParams p{};
+  p.s = *s;
+  p.gs = *gs;
+  p.u = u; p.delta = delta; p.A = A; p.Bm = Bm; p.Cm = Cm; p.D = D; p.z = z; p.bias = delta_bias;
+  p.dout = dout; p.ckpt_in = ckpt; p.du = du; p.ddelta = ddelta; p.dz = dz;
+  p.nchunks = (s->len + TB - 1) / TB;
+  p.ngroups = (s->dim + 63) / 64;
+  const int64_t nA = (int64_t)s->batch * s->dim * s->dstate, nD = (int64_t)s->batch * s->dim;
+  const int64_t nBC = (int64_t)s->batch * p.ngroups * s->len * s->dstate;
+  p.ws_dA = workspace;
+  p.ws_dD = workspace + nA;
+  p.ws_dbias = p.ws_dD + nD;
+  p.ws_dB = p.ws_dbias + nD;
+  p.ws_dC = p.ws_dB + nBC;
+  int rc;
+  switch ((s->dstate + NS - 1) / NS) {
+    case 1: rc = launch_bwd<1>(p, st); break;
+    case 2: rc = launch_bwd<2>(p, st); break;
+    case 3: rc = launch_bwd<3>(p, st); break;
+    case 4: rc = launch_bwd<4>(p, st); break;
+    case 5: rc = launch_bwd<5>(p, st); break;
+    case 6: rc = launch_bwd<6>(p, st); break;
+    case 7: rc = launch_bwd<7>(p, st); break;
+    default: rc = launch_bwd<8>(p, st); break;
+  }
+  if (rc) return rc;
+  const int64_t total = (int64_t)s->dim * s->dstate + 2 * s->dim + 2 * (int64_t)s->batch * s->len * s->dstate;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scan_bwd_finalize_kernel, dim3(blocks), dim3(256), 0, st, p, dA, dD, ddelta_bias, dB, dC);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}

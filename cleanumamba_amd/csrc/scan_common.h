@@ -1,0 +1,55 @@
+// Shared pieces of the selective-scan kernels (scan_fwd.hip, scan_bwd.hip).
+//
+// MI355X mapping (not the upstream time-parallel BlockScan design):
+//   * lane  <-> channel d (64 channels per workgroup: coalesced 256-B rows in the
+//     channel-contiguous layout the in_proj GEMM produces),
+//   * wave  <-> slice of NS = 8 states; the NW = ceil(N/8) waves of a workgroup cover
+//     all states of its 64 channels (N = 64 -> 8 waves, 512 threads),
+//   * time is walked sequentially; x_t lives in VGPRs for the whole sequence,
+//   * B_t / C_t are wave-uniform -> read through the constant address space so they
+//     arrive by s_load into SGPRs (no LDS traffic, no VGPRs),
+//   * per 16-step chunk the workgroup computes softplus / silu once per (t, d) into
+//     LDS (phase A), scans (phase B), and sums the per-wave partial results over the
+//     state slices through LDS (phase C).
+#pragma once
+#include "common.h"
+
+namespace cum {
+
+constexpr int TB = 16;  // steps per chunk == checkpoint interval
+constexpr int SUB = 8;  // steps whose states are held in registers in backward
+constexpr int NS = 8;   // states per wave
+
+struct ScanParams {
+  cum_scan_shape s;
+  cum_scan_grad_strides gs;
+  const float *u, *delta, *A, *Bm, *Cm, *D, *z, *bias;
+  float *out, *last_state, *ckpt;
+  const float *dout, *ckpt_in;
+  float *du, *ddelta, *dz;
+  float *ws_dA, *ws_dD, *ws_dbias, *ws_dB, *ws_dC;
+  int nchunks, ngroups;
+};
+
+typedef const float __attribute__((address_space(4))) *cfp;
+
+// B_t or C_t slice of this wave (wave-uniform address -> s_load_dwordx8).
+template <bool FAST>
+__device__ __forceinline__ void load_bc(const float *base, int sn, int nvalid, float (&v)[NS]) {
+  cfp bp = (cfp)base;
+  if constexpr (FAST) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) v[j] = bp[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int jj = j < nvalid ? j : nvalid - 1;
+      const float t = bp[jj * sn];
+      v[j] = j < nvalid ? t : 0.f;
+    }
+  }
+}
+
+int scan_check_shape(const cum_scan_shape *s);
+
+}  // namespace cum

@@ -1,0 +1,275 @@
+// Selective scan forward + single-step update for gfx950.
+//
+// Replaces selective_scan_cuda.fwd of mamba-ssm 1.2.2 (reached from the reference via
+// create_block -> Mamba.forward, src/network/CleanUMamba.py:172-189, 289-290) and the
+// Triton selective_state_update used by Mamba.step (CleanUMamba.py:451-454).
+// Semantics: SURVEY.md Appendix A.2.  Mapping: scan_common.h.
+//
+// At d_state = 64 the kernel is bound by v_exp_f32 issue (one per state update), not
+// by HBM -- see DESIGN.md "scan roofline".
+#include "scan_common.h"
+
+namespace cum {
+
+template <int NW, bool FAST>
+__global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
+  constexpr int K = (TB + NW - 1) / NW;  // (t, d) rows per thread in phases A / C
+  __shared__ float s_dt[TB][64];
+  __shared__ float s_du[TB][64];
+  __shared__ float s_y[NW][TB][64];
+
+  const int lane = threadIdx.x & 63;
+  const int w = uniform(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const int d = blockIdx.x * 64 + lane;
+  const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
+  const bool dok = d < Dm;
+  const int dc = dok ? d : Dm - 1;
+  const int n0 = w * NS;
+  const int nvalid = (N - n0) < NS ? (N - n0) : NS;
+
+  float Ap[NS], x[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int jj = j < nvalid ? j : nvalid - 1;
+    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    Ap[j] = (j < nvalid) ? a : 0.f;
+    x[j] = 0.f;
+  }
+  const float Dd = p.D ? p.D[dc] : 0.f;
+  const float bias = p.bias ? p.bias[dc] : 0.f;
+  const float *up = p.u + b * p.s.u_sb + dc * p.s.u_sd;
+  const float *dtp = p.delta + b * p.s.dt_sb + dc * p.s.dt_sd;
+  const bool has_z = p.z != nullptr;
+  const float *zp = has_z ? p.z + b * p.s.z_sb + dc * p.s.z_sd : up;  // !has_z: valid dummy address
+  float *op = p.out + b * p.s.o_sb + dc * p.s.o_sd;
+  const float *Bw = p.Bm + b * p.s.B_sb + n0 * p.s.B_sn;
+  const float *Cw = p.Cm + b * p.s.C_sb + n0 * p.s.C_sn;
+  // within-batch offsets fit 32 bits (checked on the host)
+  const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
+  const int o_sl = (int)p.s.o_sl;
+  const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
+  const int softplus = p.s.delta_softplus;
+
+  float ru[K], rdt[K], rz[K];
+  auto load_rows = [&](int t0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int t = t0 + w + k * NW;
+      t = t < L ? t : L - 1;  // clamped address; the value is masked in phase A
+      ru[k] = up[t * u_sl];
+      rdt[k] = dtp[t * dt_sl];
+      rz[k] = zp[t * z_sl];
+    }
+  };
+  load_rows(0);
+
+  const int nchunks = p.nchunks;
+  for (int c = 0; c < nchunks; ++c) {
+    const int t0 = c * TB;
+    float eu[K], ez[K];
+    // ---- phase A: delta' = softplus(delta + bias), du = delta' * u  -> LDS
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int tl = w + k * NW;
+      if (tl < TB) {
+        const bool ok = dok && (t0 + tl) < L;
+        float dtv = rdt[k] + bias;
+        if (softplus) dtv = softplus20(dtv);
+        dtv = ok ? dtv : 0.f;
+        s_dt[tl][lane] = dtv;
+        s_du[tl][lane] = ok ? dtv * ru[k] : 0.f;
+      }
+      eu[k] = ru[k];
+      ez[k] = rz[k];
+    }
+    if (c + 1 < nchunks) load_rows(t0 + TB);  // prefetch the next chunk's rows
+    if (p.ckpt) {
+      float *ck = p.ckpt + (((int64_t)b * nchunks + c) * N + n0) * Dm + d;
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+        if (dok && j < nvalid) ck[(int64_t)j * Dm] = x[j];
+    }
+    __syncthreads();
+    // ---- phase B: 16 sequential steps; operands of step t+1 are fetched (s_load for
+    //      B/C, ds_read for delta'/du) while step t computes.
+    float bv[NS], cv[NS], dt, du;
+    const float *bp = Bw + t0 * B_sl, *cp = Cw + t0 * C_sl;  // t0 < L always
+    load_bc<FAST>(bp, B_sn, nvalid, bv);
+    load_bc<FAST>(cp, C_sn, nvalid, cv);
+    dt = s_dt[0][lane];
+    du = s_du[0][lane];
+#pragma unroll
+    for (int tl = 0; tl < TB; ++tl) {
+      float nb[NS], nc[NS], ndt = 0.f, ndu = 0.f;
+      if (tl + 1 < TB) {
+        const int inc = (t0 + tl + 1 < L) ? 1 : 0;  // address clamps at the last valid row
+        bp = opaque(bp + inc * B_sl);
+        cp = opaque(cp + inc * C_sl);
+        load_bc<FAST>(bp, B_sn, nvalid, nb);
+        load_bc<FAST>(cp, C_sn, nvalid, nc);
+        ndt = s_dt[tl + 1][lane];
+        ndu = s_du[tl + 1][lane];
+      }
+      float y = 0.f;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
+        x[j] = fmaf(a, x[j], du * bv[j]);
+        y = fmaf(cv[j], x[j], y);
+      }
+      s_y[w][tl][lane] = y;
+      __builtin_amdgcn_sched_barrier(0);
+      if (tl + 1 < TB) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          bv[j] = nb[j];
+          cv[j] = nc[j];
+        }
+        dt = ndt;
+        du = ndu;
+      }
+    }
+    __syncthreads();
+    // ---- phase C: sum partial y over the state slices, skip term, gate, store
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int tl = w + k * NW;
+      const int t = t0 + tl;
+      if (tl < TB && t < L && dok) {
+        float y = Dd * eu[k];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) y += s_y[ww][tl][lane];
+        if (has_z) {
+          const float zv = ez[k];
+          y *= zv * sigmoidf_(zv);
+        }
+        op[t * o_sl] = y;
+      }
+    }
+    // no third barrier: the next phase A writes s_dt/s_du (read only in phase B, which
+    // ended at the barrier above) and the next phase B writes s_y after the next
+    // phase-A barrier, which every wave reaches only after this phase C.
+  }
+  if (p.last_state && dok) {
+    float *ls = p.last_state + ((int64_t)b * Dm + d) * N + n0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (j < nvalid) ls[j] = x[j];
+  }
+}
+
+// selective_state_update: one thread per (stream b, channel d); state row of N floats.
+__global__ void state_update_kernel(int batch, int dim, int N, float *__restrict__ state, const float *__restrict__ x,
+                                    const float *__restrict__ dt, const float *__restrict__ A,
+                                    const float *__restrict__ Bv, int64_t B_sb, const float *__restrict__ Cv,
+                                    int64_t C_sb, const float *__restrict__ D, const float *__restrict__ z,
+                                    const float *__restrict__ dt_bias, int softplus, float *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)batch * dim) return;
+  const int b = i / dim, d = i % dim;
+  float dtv = dt[i] + (dt_bias ? dt_bias[d] : 0.f);
+  if (softplus) dtv = softplus20(dtv);
+  const float xv = x[i];
+  const float du = dtv * xv;
+  float *st = state + i * N;
+  const float *Ar = A + (int64_t)d * N;
+  const float *Br = Bv + b * B_sb, *Cr = Cv + b * C_sb;
+  float y = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float a = __builtin_amdgcn_exp2f(dtv * (Ar[n] * kLog2e));
+    const float s = fmaf(a, st[n], du * Br[n]);
+    st[n] = s;
+    y = fmaf(Cr[n], s, y);
+  }
+  if (D) y = fmaf(D[d], xv, y);
+  if (z) {
+    const float zv = z[i];
+    y *= zv * sigmoidf_(zv);
+  }
+  out[i] = y;
+}
+
+template <int NW>
+static int launch_fwd(const ScanParams &p, hipStream_t st) {
+  dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
+  const bool fast = p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW;
+  if (fast)
+    hipLaunchKernelGGL((scan_fwd_kernel<NW, true>), grid, block, 0, st, p);
+  else
+    hipLaunchKernelGGL((scan_fwd_kernel<NW, false>), grid, block, 0, st, p);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+int scan_check_shape(const cum_scan_shape *s) {
+  CUM_REQUIRE(s != nullptr, "scan: null shape");
+  CUM_REQUIRE(s->batch >= 0 && s->dim >= 1 && s->len >= 0, "scan: bad batch/dim/len");
+  CUM_REQUIRE(s->dstate >= 1 && s->dstate <= 64, "scan: d_state must be in [1, 64]");
+  const int64_t lim = 2147483647LL;
+  const int64_t Lm = s->len > 0 ? s->len - 1 : 0;
+  CUM_REQUIRE(s->u_sl >= 0 && s->dt_sl >= 0 && s->z_sl >= 0 && s->o_sl >= 0 && s->B_sl >= 0 && s->C_sl >= 0 &&
+                  s->B_sn >= 0 && s->C_sn >= 0,
+              "scan: negative strides are not supported");
+  CUM_REQUIRE(Lm * s->u_sl < lim && Lm * s->dt_sl < lim && Lm * s->z_sl < lim && Lm * s->o_sl < lim &&
+                  Lm * s->B_sl < lim && Lm * s->C_sl < lim && (int64_t)s->dstate * s->B_sn < lim &&
+                  (int64_t)s->dstate * s->C_sn < lim,
+              "scan: per-batch time offsets must fit in 31 bits");
+  return CUM_OK;
+}
+
+}  // namespace cum
+
+using namespace cum;
+
+extern "C" int cum_scan_chunk(void) { return TB; }
+
+extern "C" int64_t cum_scan_ckpt_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len) {
+  const int64_t nchunks = (len + TB - 1) / TB;
+  return (int64_t)batch * nchunks * dstate * dim;
+}
+
+extern "C" int cum_selective_scan_fwd(const cum_scan_shape *s, const float *u, const float *delta, const float *A,
+                                      const float *Bm, const float *Cm, const float *D, const float *z,
+                                      const float *delta_bias, float *out, float *last_state, float *ckpt,
+                                      void *stream) {
+  if (int rc = scan_check_shape(s)) return rc;
+  CUM_REQUIRE(u && delta && A && Bm && Cm && out, "scan_fwd: null tensor");
+  if (s->batch == 0) return CUM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (s->len == 0) {
+    if (last_state)
+      (void)hipMemsetAsync(last_state, 0, sizeof(float) * (size_t)s->batch * s->dim * s->dstate, st);
+    return CUM_OK;
+  }
+  ScanParams p{};
+  p.s = *s;
+  p.u = u; p.delta = delta; p.A = A; p.Bm = Bm; p.Cm = Cm; p.D = D; p.z = z; p.bias = delta_bias;
+  p.out = out; p.last_state = last_state; p.ckpt = ckpt;
+  p.nchunks = (s->len + TB - 1) / TB;
+  p.ngroups = (s->dim + 63) / 64;
+  switch ((s->dstate + NS - 1) / NS) {
+    case 1: return launch_fwd<1>(p, st);
+    case 2: return launch_fwd<2>(p, st);
+    case 3: return launch_fwd<3>(p, st);
+    case 4: return launch_fwd<4>(p, st);
+    case 5: return launch_fwd<5>(p, st);
+    case 6: return launch_fwd<6>(p, st);
+    case 7: return launch_fwd<7>(p, st);
+    default: return launch_fwd<8>(p, st);
+  }
+}
+
+extern "C" int cum_selective_state_update(int32_t batch, int32_t dim, int32_t dstate, float *state, const float *x,
+                                          const float *dt, const float *A, const float *Bv, int64_t B_sb,
+                                          const float *Cv, int64_t C_sb, const float *D, const float *z,
+                                          const float *dt_bias, int32_t dt_softplus, float *out, void *stream) {
+  CUM_REQUIRE(batch >= 0 && dim >= 1 && dstate >= 1, "state_update: bad sizes");
+  CUM_REQUIRE(state && x && dt && A && Bv && Cv && out, "state_update: null tensor");
+  if (batch == 0) return CUM_OK;
+  const int64_t total = (int64_t)batch * dim;
+  hipLaunchKernelGGL(state_update_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream, batch,
+                     dim, dstate, state, x, dt, A, Bv, B_sb, Cv, C_sb, D, z, dt_bias, dt_softplus, out);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}

@@ -1,0 +1,112 @@
+"""ctypes binding of libcleanumamba_hip.so (C ABI in include/cleanumamba_hip.h).
+
+This is the only place Python touches the native library.  There is NO fallback:
+if the library is missing, or a tensor is not on a GPU, the call raises.  The
+signatures carry plain pointers and sizes; torch is used only to own device
+memory and to name the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcleanumamba_hip.so")
+
+c_i32, c_i64, c_f32p, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
+
+
+class ScanShape(ctypes.Structure):
+    _fields_ = [("batch", c_i32), ("dim", c_i32), ("dstate", c_i32), ("len", c_i32),
+                ("u_sb", c_i64), ("u_sd", c_i64), ("u_sl", c_i64),
+                ("dt_sb", c_i64), ("dt_sd", c_i64), ("dt_sl", c_i64),
+                ("z_sb", c_i64), ("z_sd", c_i64), ("z_sl", c_i64),
+                ("o_sb", c_i64), ("o_sd", c_i64), ("o_sl", c_i64),
+                ("B_sb", c_i64), ("B_sn", c_i64), ("B_sl", c_i64),
+                ("C_sb", c_i64), ("C_sn", c_i64), ("C_sl", c_i64),
+                ("delta_softplus", c_i32)]
+
+
+class ScanGradStrides(ctypes.Structure):
+    _fields_ = [("du_sb", c_i64), ("du_sd", c_i64), ("du_sl", c_i64),
+                ("dd_sb", c_i64), ("dd_sd", c_i64), ("dd_sl", c_i64),
+                ("dz_sb", c_i64), ("dz_sd", c_i64), ("dz_sl", c_i64)]
+
+
+class ConvShape(ctypes.Structure):
+    _fields_ = [("batch", c_i32), ("dim", c_i32), ("len", c_i32), ("width", c_i32),
+                ("x_sb", c_i64), ("x_sd", c_i64), ("x_sl", c_i64),
+                ("y_sb", c_i64), ("y_sd", c_i64), ("y_sl", c_i64),
+                ("silu", c_i32)]
+
+
+# name -> (restype, argtypes); mirrors include/cleanumamba_hip.h one to one.
+_P = ctypes.c_void_p
+SIGNATURES = {
+    "cum_abi_version": (c_i32, []),
+    "cum_last_error": (ctypes.c_char_p, []),
+    "cum_scan_chunk": (c_i32, []),
+    "cum_scan_ckpt_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "cum_selective_scan_fwd": (c_i32, [ctypes.POINTER(ScanShape)] + [_P] * 12),
+    "cum_scan_bwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "cum_selective_scan_bwd": (c_i32, [ctypes.POINTER(ScanShape), ctypes.POINTER(ScanGradStrides)] + [_P] * 20),
+    "cum_selective_state_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, _P, c_i64, _P, c_i64,
+                                           _P, _P, _P, c_i32, _P, _P]),
+    "cum_causal_conv1d_fwd": (c_i32, [ctypes.POINTER(ConvShape)] + [_P] * 5),
+    "cum_conv_bwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "cum_causal_conv1d_bwd": (c_i32, [ctypes.POINTER(ConvShape)] + [_P] * 5 + [c_i64] * 3 + [_P] * 4),
+    "cum_causal_conv1d_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, c_i32, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the native library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C cleanumamba_amd/csrc`). There is no CPU or PyTorch fallback for the hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.cum_abi_version() != 1:
+            raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"cleanumamba_hip error {rc}: {lib().cum_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("cleanumamba_amd: the hot path runs only on a ROCm GPU (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError("cleanumamba_amd kernels take float32 tensors (got %s)" % t.dtype)
+        dev = t.device if dev is None else dev
+        if t.device != dev:
+            raise RuntimeError("cleanumamba_amd: tensors on different devices")
+    return dev
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def scan_chunk():
+    return lib().cum_scan_chunk()

@@ -1,0 +1,173 @@
+"""Mamba mixer and Block over the HIP kernels.
+
+Module contract of mamba-ssm 1.2.2's ``mamba_ssm.modules.mamba_simple`` as the
+reference relies on it: class name ``Mamba`` (src/network/CleanUMamba.py:540),
+sub-modules ``in_proj / x_proj / dt_proj / out_proj`` (nn.Linear), ``conv1d``
+(nn.Conv1d, groups = d_inner), parameters ``A_log``, ``D`` and the mutable ints
+``d_model, d_inner, d_state, dt_rank, d_conv, expand, layer_idx`` that the pruning
+code edits in place (src/pruning/pruninggroup.py:340-352, CleanUMamba.py:336-349,
+511-545).  Shapes are therefore always read from the tensors at call time.
+Structure mirror inside the reference: src/network/S4/MambaS4.py:367-473.
+
+Layout: activations stay channel-contiguous (B, L, C) from in_proj to out_proj --
+the layout the projection GEMMs produce and the one the scan / conv kernels
+coalesce on.  The (B, D, L) tensors of the upstream formulation appear only as
+transposed views.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops.selective_scan_interface import selective_scan_fn, selective_state_update
+
+# Module-level names that callers monkey-patch (src/examples/using_pruning_groups.py:26-27
+# sets ``causal_conv1d_fn = None`` to force the nn.Conv1d path so that hooks fire).
+from ...causal_conv1d import causal_conv1d_fn, causal_conv1d_update
+
+
+class Mamba(nn.Module):
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False,
+                 use_fast_path=True, layer_idx=None, device=None, dtype=None):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.d_model = d_model
+        self.d_state = d_state
+        self.d_conv = d_conv
+        self.expand = expand
+        self.d_inner = int(self.expand * self.d_model)
+        self.dt_rank = math.ceil(self.d_model / 16) if dt_rank == "auto" else dt_rank
+        self.use_fast_path = use_fast_path
+        self.layer_idx = layer_idx
+
+        self.in_proj = nn.Linear(self.d_model, self.d_inner * 2, bias=bias, **factory_kwargs)
+        self.conv1d = nn.Conv1d(in_channels=self.d_inner, out_channels=self.d_inner, bias=conv_bias,
+                                kernel_size=d_conv, groups=self.d_inner, padding=d_conv - 1, **factory_kwargs)
+        self.activation = "silu"
+        self.act = nn.SiLU()
+        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+
+        # dt_proj init: weight ~ U(+-dt_rank^-0.5 * dt_scale); bias = softplus^-1(dt), dt log-uniform in
+        # [dt_min, dt_max]  
+        dt_init_std = self.dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(self.dt_proj.weight, dt_init_std)
+        elif dt_init == "random":
+            nn.init.uniform_(self.dt_proj.weight, -dt_init_std, dt_init_std)
+        else:
+            raise NotImplementedError
+        dt = torch.exp(torch.rand(self.d_inner, **factory_kwargs) * (math.log(dt_max) - math.log(dt_min))
+                       + math.log(dt_min)).clamp(min=dt_init_floor)
+        inv_dt = dt + torch.log(-torch.expm1(-dt))
+        with torch.no_grad():
+            self.dt_proj.bias.copy_(inv_dt)
+        self.dt_proj.bias._no_reinit = True
+
+        A = torch.arange(1, self.d_state + 1, dtype=torch.float32, device=device)[None, :]
+        self.A_log = nn.Parameter(torch.log(A.repeat(self.d_inner, 1).contiguous()))
+        self.A_log._no_weight_decay = True
+        self.D = nn.Parameter(torch.ones(self.d_inner, device=device))
+        self.D._no_weight_decay = True
+        self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
+
+    def forward(self, hidden_states, inference_params=None):
+        """hidden_states: (B, L, d_model) -> (B, L, d_model)."""
+        batch, seqlen, _ = hidden_states.shape
+        conv_state, ssm_state = None, None
+        if inference_params is not None:
+            conv_state, ssm_state = self._get_states_from_cache(inference_params, batch)
+            if inference_params.seqlen_offset > 0:
+                out, _, _ = self.step(hidden_states, conv_state, ssm_state)
+                return out
+
+        d_inner = self.in_proj.weight.shape[0] // 2
+        dt_rank = self.dt_proj.weight.shape[1]
+        d_state = (self.x_proj.weight.shape[0] - dt_rank) // 2
+        d_conv = self.conv1d.weight.shape[-1]
+
+        xz = F.linear(hidden_states, self.in_proj.weight, self.in_proj.bias)      # (B, L, 2 d_inner)
+        x = xz[..., :d_inner].transpose(1, 2)                                     # (B, d_inner, L) views,
+        z = xz[..., d_inner:].transpose(1, 2)                                     # channel stride 1
+        A = -torch.exp(self.A_log.float())
+        if conv_state is not None:
+            conv_state.copy_(F.pad(x, (d_conv - x.shape[-1], 0)))
+        if causal_conv1d_fn is None:
+            x = self.act(self.conv1d(x)[..., :seqlen])
+            x = x.transpose(1, 2).contiguous().transpose(1, 2)
+        else:
+            x = causal_conv1d_fn(x, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
+        x_dbl = F.linear(x.transpose(1, 2), self.x_proj.weight)                   # (B, L, R + 2N)
+        dt, Bm, Cm = torch.split(x_dbl, [dt_rank, d_state, d_state], dim=-1)
+        dt = F.linear(dt, self.dt_proj.weight).transpose(1, 2)                    # (B, d_inner, L); bias goes in the scan
+        y = selective_scan_fn(x, dt, A, Bm.transpose(1, 2), Cm.transpose(1, 2), self.D.float(), z=z,
+                              delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
+                              return_last_state=ssm_state is not None)
+        if ssm_state is not None:
+            y, last_state = y
+            ssm_state.copy_(last_state)
+        return F.linear(y.transpose(1, 2), self.out_proj.weight, self.out_proj.bias)
+
+    def step(self, hidden_states, conv_state, ssm_state):
+        """One token for every stream.  hidden_states: (B, 1, d_model); states updated in place."""
+        assert hidden_states.shape[1] == 1, "step() decodes one token at a time"
+        dt_rank = self.dt_proj.weight.shape[1]
+        d_state = (self.x_proj.weight.shape[0] - dt_rank) // 2
+        xz = F.linear(hidden_states.squeeze(1), self.in_proj.weight, self.in_proj.bias)
+        x, z = xz.chunk(2, dim=-1)
+        x = causal_conv1d_update(x.float(), conv_state, self.conv1d.weight.squeeze(1).float(),
+                                 None if self.conv1d.bias is None else self.conv1d.bias.float(), self.activation)
+        x_db = F.linear(x, self.x_proj.weight)
+        dt, Bv, Cv = torch.split(x_db, [dt_rank, d_state, d_state], dim=-1)
+        dt = F.linear(dt, self.dt_proj.weight)
+        A = -torch.exp(self.A_log.float())
+        y = selective_state_update(ssm_state, x, dt.float(), A, Bv, Cv, self.D.float(), z=z.float(),
+                                   dt_bias=self.dt_proj.bias.float(), dt_softplus=True)
+        out = F.linear(y.to(hidden_states.dtype), self.out_proj.weight, self.out_proj.bias)
+        return out.unsqueeze(1), conv_state, ssm_state
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        device = self.out_proj.weight.device
+        d_inner = self.in_proj.weight.shape[0] // 2
+        conv_state = torch.zeros(batch_size, d_inner, self.conv1d.weight.shape[-1], device=device,
+                                 dtype=torch.float32)
+        ssm_state = torch.zeros(batch_size, d_inner, self.A_log.shape[1], device=device, dtype=torch.float32)
+        return conv_state, ssm_state
+
+    def _get_states_from_cache(self, inference_params, batch_size, initialize_states=False):
+        assert self.layer_idx is not None
+        if self.layer_idx not in inference_params.key_value_memory_dict:
+            inference_params.key_value_memory_dict[self.layer_idx] = self.allocate_inference_cache(batch_size, 1)
+        conv_state, ssm_state = inference_params.key_value_memory_dict[self.layer_idx]
+        if initialize_states:
+            conv_state.zero_()
+            ssm_state.zero_()
+        return conv_state, ssm_state
+
+
+class Block(nn.Module):
+    """Pre-norm residual block, non-fused path (the only one the reference executes:
+    fused_add_norm=False at src/network/CleanUMamba.py:43,156).  ``mixer`` is registered
+    before ``norm`` as in mamba-ssm 1.2.2."""
+
+    def __init__(self, dim, mixer_cls, norm_cls=nn.LayerNorm, fused_add_norm=False, residual_in_fp32=False):
+        super().__init__()
+        if fused_add_norm:
+            raise NotImplementedError("fused_add_norm=True (Triton layer norm) is not on the reference's path")
+        self.residual_in_fp32 = residual_in_fp32
+        self.fused_add_norm = fused_add_norm
+        self.mixer = mixer_cls(dim)
+        self.norm = norm_cls(dim)
+
+    def forward(self, hidden_states, residual=None, inference_params=None):
+        residual = (hidden_states + residual) if residual is not None else hidden_states
+        hidden_states = self.norm(residual.to(dtype=self.norm.weight.dtype))
+        if self.residual_in_fp32:
+            residual = residual.to(torch.float32)
+        hidden_states = self.mixer(hidden_states, inference_params=inference_params)
+        return hidden_states, residual
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)

@@ -1,0 +1,334 @@
+"""CleanUMamba module for MI355X -- drop-in for src/network/CleanUMamba.py:30-550.
+
+Same constructor keywords and defaults (:33-54), same sub-module tree and therefore
+the same state-dict keys and shapes, same public methods
+(forward, feed, flush, load_pruned_state_dict, valid_length, pad_signal,
+total_stride, frame_length, time_per_frame, reset_time_per_frame,
+allocate_inference_cache).  The arithmetic of the Mamba bottleneck runs in the HIP
+kernels of csrc/ (selective scan, causal depthwise conv, single-step update).
+
+Differences from the reference, on purpose:
+  * ``forward`` does not mutate its argument (the reference divides the caller's
+    tensor by its std in place, :262); the returned value is identical.
+  * ``feed``/``flush`` implement the intended streaming semantics (stream output ==
+    ``forward`` output with normalize_input=False).  The reference's own feed()
+    raises on every shipped model (skip order at :474) and its flush() drops the
+    decoder overlap of the tail (:364); see SURVEY.md fact 9.
+  * ablation variants (LSTM, Mamba2, MambaS4, residual_projection, rms_norm,
+    fused_add_norm) are out of scope and raise NotImplementedError.
+"""
+import copy
+import itertools
+import time
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..mamba_ssm.models.mixer_seq_simple import _init_weights, create_block
+from ..mamba_ssm.utils.generation import InferenceParams
+from ..util.util import weight_scaling_init
+from .layers import Activation
+
+
+class CleanUMamba(nn.Module):
+    """CleanUNet encoder/decoder with a Mamba bottleneck."""
+
+    def __init__(self, channels_input=1, channels_output=1, channels_H=64, max_H=768, encoder_n_layers=8,
+                 kernel_size=4, stride=2, encoder_groups=1, bypass_channels=0, glu_activation="Sigmoid",
+                 tsfm_n_layers=3, tsfm_n_head=8, tsfm_d_model=512, tsfm_d_inner=2048, fused_add_norm=False,
+                 use_fast_path=False, rms_norm=False, mamba_s4=False, LSTM=False, mamba_v2=False,
+                 residual_projection=False, norm_epsilon: float = 1e-5, normalize_input=True, device=None,
+                 dtype=None):
+        super().__init__()
+        assert glu_activation in ["Sigmoid", "ReLU", "SiLU", "GELU"], f"glu_activation={glu_activation} not supported"
+        for flag, name in ((mamba_s4, "mamba_s4"), (LSTM, "LSTM"), (mamba_v2, "mamba_v2"),
+                           (residual_projection, "residual_projection"), (rms_norm, "rms_norm"),
+                           (fused_add_norm, "fused_add_norm")):
+            if flag:
+                raise NotImplementedError(f"{name}=True is an ablation variant outside the MI355X hot path")
+        factory_kwargs = {"device": device, "dtype": dtype}
+
+        self.channels_input = channels_input
+        self.channels_output = channels_output
+        self.channels_H = channels_H
+        self.max_H = max_H
+        self.encoder_n_layers = encoder_n_layers
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.tsfm_n_layers = tsfm_n_layers
+        self.tsfm_n_head = tsfm_n_head
+        self.tsfm_d_model = tsfm_d_model
+        self.tsfm_d_inner = tsfm_d_inner
+        self.residual_projection = residual_projection
+        self.normalize_input = normalize_input
+        self.dtype = dtype
+
+        self.encoder = nn.ModuleList()
+        self.decoder = nn.ModuleList()
+        for i in range(encoder_n_layers):
+            ec_groups = encoder_groups[i] if isinstance(encoder_groups, list) else encoder_groups
+            bp_channels = bypass_channels[i] if isinstance(bypass_channels, list) else bypass_channels
+            self.encoder.append(nn.Sequential(
+                nn.Conv1d(channels_input, channels_H, kernel_size, stride, groups=ec_groups if i > 0 else 1,
+                          **factory_kwargs),
+                nn.ReLU(),
+                nn.Conv1d(channels_H, bp_channels + (channels_H - bp_channels) * 2, 1, **factory_kwargs),
+                Activation(glu_activation, bp_channels)))
+            channels_input = channels_H
+            decoder_i = nn.Sequential(
+                nn.Conv1d(channels_H, bp_channels + (channels_H - bp_channels) * 2, 1, **factory_kwargs),
+                Activation(glu_activation, bp_channels),
+                nn.ConvTranspose1d(channels_H, channels_output, kernel_size, stride, **factory_kwargs))
+            if i > 0:  # ReLU on all but the outermost decoder layer
+                decoder_i.append(nn.ReLU())
+            self.decoder.insert(0, decoder_i)
+            channels_output = channels_H
+            channels_H = min(channels_H * 2, max_H)
+
+        self.tsfm_conv1 = nn.Conv1d(channels_output, tsfm_d_model, kernel_size=1, **factory_kwargs)
+        ssm_cfg = {"d_state": tsfm_d_model // tsfm_n_head, "d_conv": 4, "expand": tsfm_d_inner // tsfm_d_model,
+                   "use_fast_path": use_fast_path}
+        self.rms_norm = rms_norm
+        self.residual_in_fp32 = True
+        self.fused_add_norm = fused_add_norm
+        self.LSTM = LSTM
+        self.tsfm_Mamba_layers = nn.ModuleList([
+            create_block(tsfm_d_model, ssm_cfg=ssm_cfg, norm_epsilon=norm_epsilon, rms_norm=rms_norm,
+                         residual_in_fp32=self.residual_in_fp32, fused_add_norm=self.fused_add_norm, layer_idx=i,
+                         **factory_kwargs)
+            for i in range(tsfm_n_layers)])
+        self.norm_f = nn.LayerNorm(tsfm_d_model, eps=norm_epsilon, **factory_kwargs)
+        self.tsfm_conv2 = nn.Conv1d(tsfm_d_model, channels_output, kernel_size=1, **factory_kwargs)
+
+        # initialisation order of the reference: weight scaling on every conv (the Mamba depthwise conv
+        # included), then mamba's _init_weights on every sub-module (:197-206)
+        for layer in self.modules():
+            if isinstance(layer, (nn.Conv1d, nn.ConvTranspose1d)):
+                weight_scaling_init(layer)
+        self.apply(partial(_init_weights, n_layer=tsfm_n_layers))
+
+        # streaming state
+        self.total_time = 0
+        self.cat_time = 0
+        self.frames = 0
+        self.input_std = 0
+        self.pending = torch.zeros(self.channels_input, 0, dtype=self.dtype, device=device)
+        self.frame_length = self.valid_length(1)
+        self.inference_params = None
+        self.encoder_decoder_state = {}
+
+    # ------------------------------------------------------------------ geometry
+    def valid_length(self, length):
+        """Smallest length >= ``length`` that survives D strided convs and their transposes exactly."""
+        D, K, S = self.encoder_n_layers, self.kernel_size, self.stride
+        for _ in range(D):
+            length = 1 if length < K else 1 + np.ceil((length - K) / S)
+        for _ in range(D):
+            length = (length - 1) * S + K
+        return int(length)
+
+    def pad_signal(self, input):
+        return F.pad(input, (0, self.valid_length(input.shape[-1]) - input.shape[-1]))
+
+    @property
+    def total_stride(self):
+        return self.stride ** self.encoder_n_layers
+
+    # ------------------------------------------------------------------- forward
+    def _bottleneck(self, x, inference_params=None):
+        """tsfm_conv1 -> Mamba blocks -> add + norm_f -> tsfm_conv2.  x: (B, C, T)."""
+        x = self.tsfm_conv1(x)
+        hidden_states = x.permute(0, 2, 1)
+        residual = None
+        for layer in self.tsfm_Mamba_layers:
+            hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
+        residual = (hidden_states + residual) if residual is not None else hidden_states
+        hidden_states = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
+        tsfm_out = hidden_states.permute(0, 2, 1)
+        return self.tsfm_conv2(tsfm_out), tsfm_out
+
+    def forward(self, noisy_audio, return_skip_connections=False):
+        if noisy_audio.dim() == 2:
+            noisy_audio = noisy_audio.unsqueeze(1)
+        B, C, L = noisy_audio.shape
+        assert C == 1
+        if self.normalize_input:
+            std = noisy_audio.std(dim=2, keepdim=True) + 1e-3
+            noisy_audio = noisy_audio / std
+        x = self.pad_signal(noisy_audio)
+
+        skip_connections = []
+        for downsampling_block in self.encoder:
+            x = downsampling_block(x)
+            skip_connections.append(x)
+        skip_connections = skip_connections[::-1]
+
+        x, tsfm_out = self._bottleneck(x)
+
+        for i, upsampling_block in enumerate(self.decoder):
+            skip_i = skip_connections[i]
+            x = x + skip_i[:, :, :x.shape[-1]]
+            x = upsampling_block(x)
+
+        if self.normalize_input:
+            x = x[:, :, :L] * std
+        if return_skip_connections:
+            skip_connections.append(tsfm_out)
+            return x, skip_connections
+        return x
+
+    # ----------------------------------------------------------------- streaming
+    def reset_time_per_frame(self):
+        self.total_time = 0
+        self.frames = 0
+
+    @property
+    def time_per_frame(self):
+        return 0 if self.frames == 0 else self.total_time / self.frames
+
+    def allocate_inference_cache_layer(self, layer, batch_size, dtype=None):
+        return layer.allocate_inference_cache(batch_size, 1, dtype=dtype)
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return {i: self.allocate_inference_cache_layer(layer.mixer, batch_size, dtype=dtype)
+                for i, layer in enumerate(self.tsfm_Mamba_layers)}
+
+    def reset_stream(self):
+        """Forget all streaming state (pending samples, conv tails, Mamba states)."""
+        dev = self.tsfm_conv1.weight.device
+        self.pending = torch.zeros(self.channels_input, 0, dtype=self.dtype, device=dev)
+        self.inference_params = None
+        self.encoder_decoder_state = {}
+        self.input_std = 0
+        self.frames = 0
+
+    @torch.no_grad()
+    def flush(self):
+        """Emit the samples still pending: pad one frame of zeros, run it through the SAME stream
+        state (so the decoder overlap of the tail is kept), then reset the stream."""
+        pending_length = self.pending.shape[1]
+        padding = torch.zeros(self.channels_input, self.frame_length, device=self.pending.device, dtype=self.dtype)
+        frames_before, time_before = self.frames, self.total_time
+        out = self.feed(padding)
+        out = out[:, :pending_length]
+        self.reset_stream()
+        self.frames, self.total_time = frames_before, time_before
+        return out
+
+    @torch.no_grad()
+    def feed(self, noisy_input):
+        """noisy_input: (1, n) samples of one stream -> (1, m) denoised samples, m a multiple of total_stride."""
+        if noisy_input.dim() != 2:
+            raise ValueError("input should be two dimensional.")
+        C, _ = noisy_input.shape
+        if C != 1:
+            raise ValueError(f"Expected 1 channel, got {C}")
+        if self.inference_params is None:
+            self.inference_params = InferenceParams(max_seqlen=1, max_batch_size=1,
+                                                    key_value_memory_dict=self.allocate_inference_cache(1, 1),
+                                                    seqlen_offset=1)
+        begin = time.time()
+        total_stride = self.total_stride
+        self.pending = torch.cat([self.pending.to(noisy_input.device), noisy_input], dim=1)
+        denoised_frames = []
+        while self.pending.shape[1] >= self.frame_length:
+            self.frames += 1
+            frame = self.pending[:, :self.frame_length]
+            if self.normalize_input:
+                # running mean of the per-frame std (src/network/CleanUMamba.py:399-401)
+                self.input_std = (frame.std(dim=1, keepdim=True) + 1e-3) / self.frames \
+                    + (1 - 1 / self.frames) * self.input_std
+                frame = frame / self.input_std
+            out = self._denoise_frame(frame)[:, :total_stride]
+            if self.normalize_input:
+                out = out * self.input_std
+            denoised_frames.append(out)
+            self.pending = self.pending[:, total_stride:]
+        self.total_time += time.time() - begin
+        if denoised_frames:
+            return torch.cat(denoised_frames, 1)
+        return torch.zeros(C, 0, device=noisy_input.device)
+
+    def _denoise_frame(self, frame):
+        """One hop: frame (1, frame_length) -> (1, >= total_stride) samples.  Encoder outputs that overlap
+        the previous frame are cached per layer; the decoder keeps the last ``stride`` samples of every
+        transposed conv for overlap-add with the next frame."""
+        x = frame.unsqueeze(1)
+        state = self.encoder_decoder_state
+        skip_connections = []
+        hop = self.total_stride
+        for i, encode in enumerate(self.encoder):
+            hop //= self.stride                      # new outputs of this layer per frame
+            prev = state.get(f"enc{i}")
+            if prev is not None:
+                length = x.shape[2]
+                n_new = (length - self.kernel_size) // self.stride + 1 - prev.shape[-1]
+                x = x[..., length - self.kernel_size - self.stride * (n_new - 1):]
+            x = encode(x)
+            if prev is not None:
+                x = torch.cat([prev, x], -1)
+            state[f"enc{i}"] = x[..., hop:]
+            skip_connections.append(x)
+
+        x, _ = self._bottleneck(x, inference_params=self.inference_params)
+
+        for i, upsampling_block in enumerate(self.decoder):
+            skip_i = skip_connections[-1 - i]        # deepest first, as in forward()
+            x = x + skip_i[..., :x.shape[-1]]
+            x = upsampling_block[2](upsampling_block[1](upsampling_block[0](x)))
+            prev = state.get(f"dec{i}")
+            state[f"dec{i}"] = x[..., -self.stride:] - upsampling_block[2].bias.view(-1, 1)
+            x = x[..., :-self.stride]
+            if prev is not None:
+                x = torch.cat([x[..., :self.stride] + prev, x[..., self.stride:]], -1)
+            if i != self.encoder_n_layers - 1:
+                x = upsampling_block[3](x)
+        return x[0]
+
+    # ------------------------------------------------------------ pruned loading
+    def load_pruned_state_dict(self, pruned_state_dict):
+        """Adopt the (smaller, odd) shapes of a pruned checkpoint, then load it strictly.
+        Interface of src/network/CleanUMamba.py:492-550."""
+
+        def adopt_shapes(module, local_sd, prefix=""):
+            persistent = {k: v for k, v in module._buffers.items() if k not in module._non_persistent_buffers_set}
+            for name, param in itertools.chain(module._parameters.items(), persistent.items()):
+                if param is None:
+                    continue
+                key = prefix + name
+                if key not in local_sd:
+                    print(f"Error cant find {key} in {module}")
+                    continue
+                param.data = copy.deepcopy(local_sd[key].data).to(device=param.device)
+                if isinstance(module, (nn.LayerNorm, nn.Conv1d, nn.ConvTranspose1d, nn.Linear)):
+                    weight = module.weight
+                    if isinstance(module, nn.LayerNorm):
+                        module.normalized_shape = tuple(weight.shape)
+                    if isinstance(module, nn.Conv1d):
+                        module.in_channels = weight.shape[1]
+                        module.out_channels = weight.shape[0]
+                        if module.groups > 1:
+                            module.groups = weight.shape[0]
+                    if isinstance(module, nn.ConvTranspose1d):
+                        module.in_channels = weight.shape[0]
+                        module.out_channels = weight.shape[1]
+                    if isinstance(module, nn.Linear):
+                        module.in_features = weight.shape[1]
+                        module.out_features = weight.shape[0]
+            for name, child in module._modules.items():
+                if child is not None:
+                    child_prefix = prefix + name + "."
+                    adopt_shapes(child, {k: v for k, v in local_sd.items() if k.startswith(child_prefix)},
+                                 child_prefix)
+            if module.__class__.__name__ == "Mamba":
+                module.dt_rank = module.dt_proj.in_features
+                module.d_state = (module.x_proj.out_features - module.dt_rank) // 2
+                module.d_inner = module.x_proj.in_features
+                module.d_model = module.in_proj.in_features
+                module.expand = module.d_inner / module.d_model
+
+        adopt_shapes(self, pruned_state_dict)
+        self.load_state_dict(pruned_state_dict, strict=True)

@@ -1,0 +1,143 @@
+/*
+ * cleanumamba_hip.h -- C ABI of libcleanumamba_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the CleanUMamba forward+backward hot path.  Each entry
+ * point replaces one native op the reference reaches through third-party wheels
+ * (mamba-ssm 1.2.2, causal-conv1d 1.1.0; pinned at /root/reference
+ * environment.yml:29-30) or through cuDNN/cuBLAS via torch.nn:
+ *
+ *   cum_selective_scan_fwd/bwd    <- selective_scan_cuda.fwd/bwd, reached from
+ *                                    Mamba.forward via create_block
+ *                                    (src/network/CleanUMamba.py:172-189, 289-290)
+ *   cum_causal_conv1d_fwd/bwd     <- causal_conv1d_cuda.causal_conv1d_fwd/bwd
+ *                                    (call pattern src/network/S4/MambaS4.py:454-463)
+ *   cum_causal_conv1d_update      <- causal_conv1d_cuda.causal_conv1d_update   (Mamba.step,
+ *   cum_selective_state_update    <- selective_state_update                     CleanUMamba.py:451-454)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the
+ *     caller (PyTorch caching allocator).  Kernels never allocate or free.
+ *   - strides are in ELEMENTS.  "len" is the time axis, "dim" the channel axis.
+ *     The kernels are tuned for channel-contiguous (stride_dim == 1) tensors and
+ *     remain correct for any stride.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     the call returns immediately (no synchronisation, graph-capturable).
+ *   - return value: CUM_OK (0) or a negative CUM_E* code; nothing throws.
+ *     cum_last_error() returns a static description of the last failure on the
+ *     calling thread.
+ *   - re-entrant: no global mutable state besides the thread-local error string.
+ */
+#ifndef CLEANUMAMBA_HIP_H
+#define CLEANUMAMBA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUM_OK 0
+#define CUM_EINVAL (-1)      /* bad argument / unsupported shape */
+#define CUM_ELAUNCH (-2)     /* hipLaunch failed */
+#define CUM_EWORKSPACE (-3)  /* workspace too small */
+
+#define CUM_ABI_VERSION 1
+
+int cum_abi_version(void);
+const char *cum_last_error(void);
+
+/* Time steps between saved scan states (fixed by the kernels). */
+int cum_scan_chunk(void);
+
+/* ------------------------------------------------------------ selective scan
+ * Logical shapes: u, delta, z, out: (batch, dim, len); A: (dim, dstate) row-major
+ * contiguous fp32; Bm, Cm: (batch, dstate, len); D, delta_bias: (dim) or NULL;
+ * z may be NULL (no gate).  x_{t} = exp(delta_t A) x_{t-1} + delta_t B_t u_t,
+ * y_t = <C_t, x_t> + D u_t, out = y * silu(z).   
+ *
+ * ckpt: NULL (inference) or fp32 buffer of cum_scan_ckpt_elems() elements that
+ * receives the state entering every chunk of cum_scan_chunk() steps; the
+ * backward consumes it.  last_state: NULL or (batch, dim, dstate) contiguous.
+ */
+typedef struct {
+  int32_t batch, dim, dstate, len;
+  int64_t u_sb, u_sd, u_sl;          /* u strides: batch, dim, len */
+  int64_t dt_sb, dt_sd, dt_sl;       /* delta */
+  int64_t z_sb, z_sd, z_sl;          /* z (ignored if z == NULL) */
+  int64_t o_sb, o_sd, o_sl;          /* out */
+  int64_t B_sb, B_sn, B_sl;          /* Bm */
+  int64_t C_sb, C_sn, C_sl;          /* Cm */
+  int32_t delta_softplus;            /* apply softplus (threshold 20) to delta + bias */
+} cum_scan_shape;
+
+int64_t cum_scan_ckpt_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len);
+
+int cum_selective_scan_fwd(const cum_scan_shape *s, const float *u, const float *delta,
+                           const float *A, const float *Bm, const float *Cm, const float *D,
+                           const float *z, const float *delta_bias, float *out,
+                           float *last_state, float *ckpt, void *stream);
+
+/* Strides (batch, dim, len) of the three per-element gradient outputs. */
+typedef struct {
+  int64_t du_sb, du_sd, du_sl;
+  int64_t dd_sb, dd_sd, dd_sl;       /* ddelta */
+  int64_t dz_sb, dz_sd, dz_sl;       /* dz (ignored if z == NULL) */
+} cum_scan_grad_strides;
+
+/* Backward.  dout strides = the o_* strides of the shape; du/ddelta/dz use `gs`.
+ * dB, dC: (batch, len, dstate) CONTIGUOUS fp32 outputs.
+ * dA: (dim, dstate), dD, ddelta_bias: (dim) -- fully overwritten (not accumulated).
+ * workspace: fp32, cum_scan_bwd_workspace_elems() elements.
+ * out_y: optional; if z != NULL the kernel needs y (pre-gate) and recomputes it. */
+int64_t cum_scan_bwd_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len);
+
+int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs,
+                           const float *u, const float *delta,
+                           const float *A, const float *Bm, const float *Cm, const float *D,
+                           const float *z, const float *delta_bias, const float *dout,
+                           const float *ckpt, float *du, float *ddelta, float *dA, float *dB,
+                           float *dC, float *dD, float *dz, float *ddelta_bias,
+                           float *workspace, void *stream);
+
+/* One time step for `batch` concurrent streams (Mamba.step).  state (batch, dim,
+ * dstate) contiguous, updated in place.  x, dt, z, out: (batch, dim) contiguous;
+ * Bv, Cv: (batch, dstate) with element stride 1 and row strides B_sb / C_sb. */
+int cum_selective_state_update(int32_t batch, int32_t dim, int32_t dstate, float *state,
+                               const float *x, const float *dt, const float *A,
+                               const float *Bv, int64_t B_sb, const float *Cv, int64_t C_sb,
+                               const float *D, const float *z, const float *dt_bias,
+                               int32_t dt_softplus, float *out, void *stream);
+
+/* ------------------------------------------------------- causal depthwise conv
+ * y[b,d,t] = act(bias_d + sum_k w[d,k] x[b,d,t-(W-1)+k]), zero left pad, W <= 4.
+ * (SURVEY.md Appendix A.4).  weight (dim, width) contiguous, bias (dim) or NULL.
+ * silu: 1 -> SiLU activation, 0 -> identity. */
+typedef struct {
+  int32_t batch, dim, len, width;
+  int64_t x_sb, x_sd, x_sl;
+  int64_t y_sb, y_sd, y_sl;
+  int32_t silu;
+} cum_conv_shape;
+
+int cum_causal_conv1d_fwd(const cum_conv_shape *s, const float *x, const float *weight,
+                          const float *bias, float *y, void *stream);
+
+/* dy has y's strides; dx has strides (dx_sb, dx_sd, dx_sl).  dweight (dim, width),
+ * dbias (dim): overwritten.  workspace: cum_conv_bwd_workspace_elems() fp32 elements. */
+int64_t cum_conv_bwd_workspace_elems(int32_t batch, int32_t dim, int32_t len, int32_t width);
+
+int cum_causal_conv1d_bwd(const cum_conv_shape *s, const float *x, const float *weight,
+                          const float *bias, const float *dy, float *dx, int64_t dx_sb,
+                          int64_t dx_sd, int64_t dx_sl, float *dweight, float *dbias,
+                          float *workspace, void *stream);
+
+/* Streaming step: conv_state (batch, dim, width) contiguous is shifted left by one
+ * and x (batch, dim) appended; y (batch, dim) = act(bias + <state, w>). */
+int cum_causal_conv1d_update(int32_t batch, int32_t dim, int32_t width, float *conv_state,
+                             const float *x, const float *weight, const float *bias,
+                             int32_t silu, float *y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLEANUMAMBA_HIP_H */

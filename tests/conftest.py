@@ -1,0 +1,44 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
+def golden_json(arr):
+    return json.loads(bytes(arr).decode())
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def load_ckpt(name):
+    """(state_dict fp32, network_config) from a tests/golden/ckpt_*.npz fixture."""
+    g = load_golden("ckpt_" + name)
+    cfg = golden_json(g.pop("__network_config__"))
+    return {k: torch.from_numpy(v.astype(np.float32)) for k, v in g.items()}, cfg
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,69 @@
+"""Gradient exchange (bucketed all-reduce, grads as views of flat buckets) on 2 CPU ranks over gloo."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    from cleanumamba_amd.training.train_distributed import (apply_gradient_allreduce, init_distributed,
+                                                          reduce_tensor)
+    torch.set_num_threads(1)
+    init_distributed(rank, world, None, "gloo", f"tcp://127.0.0.1:{port}")
+    torch.manual_seed(100 + rank)                       # different init per rank: broadcast must fix it
+    net = nn.Sequential(nn.Conv1d(1, 8, 4, 2), nn.ReLU(), nn.Conv1d(8, 16, 1), nn.Conv1d(16, 1, 3), nn.Linear(7, 3))
+    unused = nn.Linear(3, 3)                            # never receives a gradient
+    net.add_module("unused", unused)
+    net = apply_gradient_allreduce(net, bucket_bytes=256)   # tiny buckets -> several collectives
+    assert len(net.grad_buckets.buckets) > 2
+    ref = [p.detach().clone() for p in net.parameters()]
+    gathered = [torch.zeros_like(ref[0]) for _ in range(world)]
+    dist.all_gather(gathered, ref[0])
+    assert torch.equal(gathered[0], gathered[1]), "parameters were not broadcast from rank 0"
+
+    for step in range(2):
+        net.grad_buckets.zero_grad()
+        g = torch.Generator().manual_seed(7 + 10 * step + rank)
+        x = torch.randn(4, 1, 20, generator=g)
+        y = net[4](net[3](net[2](net[1](net[0](x)))))
+        local = torch.autograd.grad(y.square().mean(), [p for p in net.parameters() if p is not unused.weight
+                                                       and p is not unused.bias], retain_graph=True)
+        y.square().mean().backward()
+        params = [p for p in net.parameters() if p is not unused.weight and p is not unused.bias]
+        for p, lg in zip(params, local):
+            both = [torch.zeros_like(lg) for _ in range(world)]
+            dist.all_gather(both, lg.contiguous())
+            want = (both[0] + both[1]) / world
+            assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7), "averaged gradient mismatch"
+            idx, view = net.grad_buckets.where[id(p)]
+            assert p.grad.data_ptr() == view.data_ptr(), "grad is not a view of its bucket"
+        assert torch.all(unused.weight.grad == 0)
+    loss = torch.tensor([float(rank + 1)])
+    assert reduce_tensor(loss, world).item() == 1.5
+    out.put((rank, "ok"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]

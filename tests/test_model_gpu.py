@@ -1,0 +1,116 @@
+"""End-to-end CleanUMamba on the GPU vs golden vectors produced by the reference class (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_json, load_ckpt, load_golden, rel_l2
+from oracle import cleanumamba_ref as R
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+E2E_TOL = 1e-4            # north_star: denoised output within 1e-4 relative L2 of the reference
+
+
+def _net(name, cuda, pruned=False):
+    from cleanumamba_amd.network import CleanUMamba
+    sd, cfg = load_ckpt(name)
+    net = CleanUMamba(**cfg)
+    if pruned:
+        net.load_pruned_state_dict(sd)
+    else:
+        net.load_state_dict(sd, strict=True)
+    return net.to(cuda).float().eval()
+
+
+@pytest.mark.parametrize("name,pruned", [("442k", False), ("pruned500k", True)])
+def test_forward_matches_reference_class_output(cuda, name, pruned):
+    net = _net(name, cuda, pruned)
+    g = load_golden("e2e_" + name)
+    x = T(g["input"]).to(cuda)
+    keep = x.clone()
+    with torch.no_grad():
+        y = net(x)
+        assert torch.equal(x, keep), "forward must not mutate its input"
+        assert rel_l2(y, g["out_norm"]) < E2E_TOL
+        assert rel_l2(y, g["out64_norm"]) < E2E_TOL
+        net.normalize_input = False
+        y, skips = net(x, return_skip_connections=True)
+        assert rel_l2(y, g["out_raw"]) < E2E_TOL
+        assert rel_l2(skips[0], g["tsfm_in_raw"]) < E2E_TOL
+        assert rel_l2(skips[-1], g["tsfm_out_raw"]) < E2E_TOL
+        assert rel_l2(skips[-2][:, :, :64], g["skip_first_raw_head"]) < E2E_TOL
+        assert net(x[:, 0]).shape == (2, 1, 16000)      # (B, L) input form
+
+
+@pytest.mark.parametrize("name", ["e8_synth", "e6_synth"])
+def test_full_width_model_forward_and_gradients(cuda, name):
+    """E8 / E6 dimensions (d_state 64, 768 channels) with synthetic weights: output and sampled gradients
+    against the reference class run in the build container."""
+    from cleanumamba_amd.network import CleanUMamba
+    g = load_golden("e2e_" + name)
+    meta = golden_json(g["meta"])
+    net = CleanUMamba(**meta["cfg"])
+    sd = synth.fill_state_dict(dict(zip(meta["keys"], meta["shapes"])), seed=meta["seed"])
+    net.load_state_dict(sd, strict=True)
+    net = net.to(cuda).train()
+    clean, noisy = synth.waveform(2, meta["L"], seed=meta["wave_seed"])
+    y = net(noisy.to(cuda))
+    assert rel_l2(y, g["out"]) < E2E_TOL
+    assert rel_l2(y, g["out64"]) < E2E_TOL
+    (y * clean.to(cuda)).sum().backward()
+    named = dict(net.named_parameters())
+    for k in g:
+        if k.startswith("grad:"):
+            p = named[k[5:]]
+            gn = float(g["gradnorm:" + k[5:]])
+            err = (p.grad.flatten()[:4096].double().cpu() - T(g[k]).double()).norm().item()
+            assert err < 5e-4 * gn, (k, err, gn)
+            assert abs(p.grad.double().norm().item() - gn) < 5e-4 * gn
+    tot = sum((p.grad.double() ** 2).sum().item() for p in net.parameters())
+    assert abs(tot - float(g["grad_sq_total"])) < 1e-3 * float(g["grad_sq_total"])
+
+
+@pytest.mark.parametrize("name,pruned", [("442k", False), ("pruned500k", True)])
+def test_streaming_equals_parallel_forward(cuda, name, pruned):
+    """The reference's one numeric property (src/network/CleanUMamba.py:568-582), on the intended semantics."""
+    net = _net(name, cuda, pruned)
+    net.normalize_input = False
+    g = load_golden("e2e_" + name)
+    x = T(g["input"]).to(cuda)[0]                       # (1, 16000)
+    with torch.no_grad():
+        par = net(x.unsqueeze(0))[0]
+        outs = [net.feed(x[:, i:i + 1000]) for i in range(0, 16000, 1000)]
+        outs.append(net.flush())
+        seq = torch.cat(outs, 1)
+    assert seq.shape == par.shape
+    assert rel_l2(seq, par) < 1e-4
+    assert rel_l2(seq, T(g["out_raw"])[0]) < 1e-4
+    assert net.frames > 0 and net.time_per_frame > 0
+    with torch.no_grad():                               # the stream state was reset by flush()
+        again = torch.cat([net.feed(x), net.flush()], 1)
+    assert rel_l2(again, par) < 1e-4
+
+
+def test_loss_and_train_step_on_gpu(cuda):
+    from cleanumamba_amd.training.train_step import TrainStep
+    from cleanumamba_amd.util.stft_loss import MultiResolutionSTFTLoss
+    from cleanumamba_amd.util.util import loss_fn
+    g = load_golden("loss")
+    cfg = golden_json(g["cfg"])
+    den = T(g["denoised"]).to(cuda).requires_grad_(True)
+    mr = MultiResolutionSTFTLoss(**cfg["stft_config"]).to(cuda)
+    kw = {k: v for k, v in cfg.items() if k != "stft_config"}
+    loss, dic = loss_fn(lambda x: den, (T(g["clean"]).to(cuda), T(g["clean"]).to(cuda)), mrstftloss=mr, **kw)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert rel_l2(den.grad, g["grad"]) < 1e-3
+    # two optimisation steps on the 442K model: the loss is finite and parameters move
+    net = _net("442k", cuda).train()
+    step = TrainStep(net, optimization={"n_iters": 100})
+    clean, noisy = synth.waveform(2, 8000, seed=5)
+    before = net.tsfm_Mamba_layers[0].mixer.A_log.detach().clone()
+    l0, gn = step(clean.to(cuda), noisy.to(cuda))
+    l1, _ = step(clean.to(cuda), noisy.to(cuda))
+    assert torch.isfinite(l0) and torch.isfinite(l1) and torch.isfinite(gn)
+    assert not torch.equal(before, net.tsfm_Mamba_layers[0].mixer.A_log.detach())

@@ -1,0 +1,88 @@
+"""Pins the oracle: restatement vs golden vectors (made from the reference class in the build
+container) and vs HF transformers' independent Mamba.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_json, load_ckpt, load_golden, rel_l2
+from oracle import cleanumamba_ref as R
+from oracle import mamba_ref as M
+from oracle import synth
+
+T = torch.from_numpy
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_scan_ref_reproduces_golden(idx):
+    g = load_golden(f"scan_{idx}")
+    kw = dict(D=T(g["D"]) if "D" in g else None, z=T(g["z"]) if "z" in g else None,
+              delta_bias=T(g["delta_bias"]) if "delta_bias" in g else None)
+    y, last = M.selective_scan_ref(T(g["u"]), T(g["delta"]), T(g["A"]), T(g["B"]), T(g["C"]),
+                                   delta_softplus=True, return_last_state=True, **kw)
+    assert rel_l2(y, g["out32"]) < 1e-6
+    assert rel_l2(y, g["out64"]) < 2e-6
+    assert rel_l2(last, g["last64"]) < 2e-6
+
+
+@pytest.mark.parametrize("idx", [0, 2, 4])
+def test_scan_ref_matches_hf_transformers(idx):
+    hf = pytest.importorskip("transformers.models.mamba.modeling_mamba")
+    g = load_golden(f"scan_{idx}")
+    kw = dict(D=T(g["D"]) if "D" in g else None, z=T(g["z"]) if "z" in g else None,
+              delta_bias=T(g["delta_bias"]) if "delta_bias" in g else None)
+    y = hf.mamba_selective_scan(T(g["u"]), T(g["delta"]), T(g["A"]), T(g["B"]), T(g["C"]), delta_softplus=True, **kw)
+    assert rel_l2(y, g["out64"]) < 5e-6
+
+
+def test_dwconv_and_step_ref_reproduce_golden():
+    for i in range(4):
+        g = load_golden(f"dwconv_{i}")
+        y = M.causal_conv1d_ref(T(g["x"]), T(g["w"]), T(g["b"]), "silu")
+        assert rel_l2(y, g["y64"]) < 1e-6
+    g = load_golden("step")
+    cs = torch.zeros(3, 48, 4)
+    ss = torch.zeros(3, 48, 13)
+    for s in range(g["xs"].shape[0]):
+        xc = M.causal_conv1d_update_ref(T(g["xs"][s]), cs, T(g["w"]), T(g["conv_bias"]), "silu")
+        y = M.selective_state_update_ref(ss, xc, T(g["dts"][s]), T(g["A"]), T(g["Bs"][s]), T(g["Cs"][s]),
+                                         T(g["D"]), z=T(g["zs"][s]), dt_bias=T(g["dt_bias"]), dt_softplus=True)
+        assert rel_l2(y, g["y64"][s]) < 1e-5
+    assert rel_l2(ss, g["ssm_state64"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["442k", "pruned500k"])
+def test_full_model_restatement_vs_reference_class(name):
+    """oracle/cleanumamba_ref.py against outputs of the reference's own CleanUMamba class."""
+    sd, _ = load_ckpt(name)
+    g = load_golden("e2e_" + name)
+    x = T(g["input"])
+    with torch.no_grad():
+        y_raw, skips, inter = R.forward_ref(sd, x, normalize_input=False, return_intermediates=True)
+        y_norm = R.forward_ref(sd, x, normalize_input=True)
+    assert rel_l2(y_raw, g["out_raw"]) < 1e-6
+    assert rel_l2(y_norm, g["out_norm"]) < 1e-6
+    assert rel_l2(y_norm, g["out64_norm"]) < 1e-5
+    assert rel_l2(inter["tsfm_out"], g["tsfm_out_raw"]) < 1e-6
+    assert rel_l2(skips[0], g["tsfm_in_raw"]) < 1e-6
+    assert R.valid_length(16000, 8) == int(g["valid_length"]) == 16126
+
+
+def test_synth_e6_restatement_vs_reference_class():
+    g = load_golden("e2e_e6_synth")
+    meta = golden_json(g["meta"])
+    sd = synth.fill_state_dict(dict(zip(meta["keys"], meta["shapes"])), seed=meta["seed"])
+    _, noisy = synth.waveform(2, meta["L"], seed=meta["wave_seed"])
+    with torch.no_grad():
+        y = R.forward_ref(sd, noisy)
+    assert rel_l2(y, g["out"]) < 1e-5      # 768-channel fp32 convs: summation order varies with threading
+
+
+def test_loss_restatement_vs_reference_loss_fn():
+    g = load_golden("loss")
+    cfg = golden_json(g["cfg"])
+    den = T(g["denoised"]).requires_grad_(True)
+    loss = R.loss_ref(den, T(g["clean"]), ell_p=cfg["ell_p"], ell_p_lambda=cfg["ell_p_lambda"],
+                      stft_lambda=cfg["stft_lambda"], stft_config=cfg["stft_config"])
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 * abs(float(g["loss"])) + 1e-7
+    assert rel_l2(den.grad, g["grad"]) < 1e-5

@@ -74,26 +74,18 @@ __device__ __forceinline__ float row16_allsum(float v) {
   return v;
 }
 
-// Reduce-scatter of 16 per-lane values over the 64 lanes of a wave.
-// On return r[0..3] of every lane in row q (= lane>>4) hold the 64-lane sums of
-// v[4*q .. 4*q+3]... (see body for the exact index map: idx = 8*(q>>1) + 4*(q&1) + i).
-__device__ __forceinline__ void wave_reduce_scatter16(const float (&v)[16], float (&r)[4]) {
-  float h[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    // lanes 32-63 of a swap with lanes 0-31 of b; then a+b = pair sums: v[i] in lanes <32, v[8+i] in lanes >=32
-    auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[i]), __builtin_bit_cast(unsigned, v[8 + i]), false, false);
-    h[i] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
-  }
-  float q4[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    // odd rows of a swap with even rows of b: even rows keep h[i], odd rows keep h[4+i]
-    auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h[i]), __builtin_bit_cast(unsigned, h[4 + i]), false, false);
-    q4[i] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = row16_allsum(q4[i]);
+// Half / row exchanges.  hipcc (ROCm 7.2) miscompiles the two-result builtins
+// __builtin_amdgcn_permlane{32,16}_swap when both results feed one expression (it reuses
+// result 0 for result 1: `v_permlane32_swap v3, v7; v_add_f32 v3, v3, v3`), so the
+// instruction is emitted directly.  The two v_nop cover the "VALU write -> permlane
+// swap read" hazard (2 wait states), which hipcc does not pad inside asm.
+//   swap32(a, b): lanes 32-63 of a  <->  lanes 0-31 of b
+//   swap16(a, b): odd 16-lane rows of a  <->  even rows of b
+__device__ __forceinline__ void swap32(float &a, float &b) {
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(float &a, float &b) {
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
 }  // namespace cum

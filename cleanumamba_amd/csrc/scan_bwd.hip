@@ -25,16 +25,18 @@ __device__ __forceinline__ void wave_reduce_scatter8(const float (&v)[NS], float
   float h[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    // lanes 32-63 of a swap with lanes 0-31 of b: a+b = pair sums of v[i] (lanes <32) / v[4+i] (lanes >=32)
-    auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[i]), __builtin_bit_cast(unsigned, v[4 + i]), false, false);
-    h[i] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+    // after the exchange a + b = pair sums of v[i] (lanes < 32) / of v[4+i] (lanes >= 32)
+    float a = v[i], b = v[4 + i];
+    swap32(a, b);
+    h[i] = a + b;
   }
   float q[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    // odd rows of a swap with even rows of b: even rows keep h[i], odd rows keep h[2+i]
-    auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, h[i]), __builtin_bit_cast(unsigned, h[2 + i]), false, false);
-    q[i] = __builtin_bit_cast(float, s[0]) + __builtin_bit_cast(float, s[1]);
+    // even rows keep the sums of h[i], odd rows those of h[2+i]
+    float a = h[i], b = h[2 + i];
+    swap16(a, b);
+    q[i] = a + b;
   }
   // row q now holds 4-lane sums of v[4*(q>>1) + 2*(q&1) + i] = v[2q + i]
   r[0] = row16_allsum(q[0]);
@@ -350,7 +352,7 @@ extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_gr
                                       float *ddelta, float *dA, float *dB, float *dC, float *dD, float *dz,
                                       float *ddelta_bias, float *workspace, void *stream) {
   if (int rc = scan_check_shape(s)) return rc;
-  CUM_REQUIRE(gs && u && delta && A && Bm && Cm && dout && du && ddelta && dA && dB && dC, "scan_bwd: null tensor");
+  CUM_REQUIRE(gs && dA, "scan_bwd: null tensor");
   {
     const int64_t lim = 2147483647LL, Lm = s->len > 0 ? s->len - 1 : 0;
     CUM_REQUIRE(gs->du_sl >= 0 && gs->dd_sl >= 0 && gs->dz_sl >= 0 && Lm * gs->du_sl < lim && Lm * gs->dd_sl < lim &&
@@ -365,6 +367,7 @@ extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_gr
     if (ddelta_bias) (void)hipMemsetAsync(ddelta_bias, 0, sizeof(float) * s->dim, st);
     return CUM_OK;
   }
+  CUM_REQUIRE(u && delta && A && Bm && Cm && dout && du && ddelta && dB && dC, "scan_bwd: null tensor");
   CUM_REQUIRE(ckpt && workspace, "scan_bwd: ckpt and workspace are required");
   ScanParams p{};
   p.s = *s;

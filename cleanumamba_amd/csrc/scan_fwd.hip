@@ -234,14 +234,14 @@ extern "C" int cum_selective_scan_fwd(const cum_scan_shape *s, const float *u, c
                                       const float *delta_bias, float *out, float *last_state, float *ckpt,
                                       void *stream) {
   if (int rc = scan_check_shape(s)) return rc;
-  CUM_REQUIRE(u && delta && A && Bm && Cm && out, "scan_fwd: null tensor");
   if (s->batch == 0) return CUM_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (s->len == 0) {
+  if (s->len == 0) {  // empty sequences carry null data pointers
     if (last_state)
       (void)hipMemsetAsync(last_state, 0, sizeof(float) * (size_t)s->batch * s->dim * s->dstate, st);
     return CUM_OK;
   }
+  CUM_REQUIRE(u && delta && A && Bm && Cm && out, "scan_fwd: null tensor");
   ScanParams p{};
   p.s = *s;
   p.u = u; p.delta = delta; p.A = A; p.Bm = Bm; p.Cm = Cm; p.D = D; p.z = z; p.bias = delta_bias;

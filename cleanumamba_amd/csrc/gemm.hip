@@ -1,0 +1,421 @@
+// Fused "convolution as GEMM" kernels for the encoder / decoder stack on gfx950.
+//
+// Replaces cuDNN/cuBLAS behind nn.Conv1d / nn.ConvTranspose1d + ReLU / GLU / skip-add in
+// the reference's encoder and decoder layers (src/network/CleanUMamba.py:108-113, 121-130,
+// 313-316; GLU src/network/layers.py:26-33).
+//
+// Layout idea (DESIGN.md "conv stack"): activations are channels-last [B, T+2, Cpad] with
+// two zero rows closing every clip.  Then
+//   * Conv1d(k=4, s=2) output row t reads input rows 2t..2t+3 = 4*C CONTIGUOUS elements
+//     starting at row 2t: a GEMM whose A rows overlap (row stride 2*C < K = 4*C);
+//   * ConvTranspose1d(k=4, s=2) output rows (2t, 2t+1) read input rows t-1, t = 2*C
+//     contiguous elements: again an overlapping-row GEMM, N = 2*Cout;
+//   * 1x1 convs are plain GEMMs;
+// and every backward-data pass is one of the same forms with re-packed weights.  One NT
+// GEMM kernel, out[m][n] = epi(sum_k A[m*lda + k] * W[n*ldw + k]), therefore covers every
+// fused layer: epilogues bias / ReLU / GLU (+ residual add, + row masking that keeps the
+// closing rows zero), pre-activation side output for the backward.
+//
+// MFMA mapping: 128x128 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16
+// (bf16 in, f32 acc) or v_mfma_f32_16x16x4_f32 (exact f32 for the parity path).  The
+// weight tile is the MFMA "A" operand and the activation tile the "B" operand, so a lane
+// ends up with 4 CONSECUTIVE output channels of one row: 8-/16-byte stores, and the GLU
+// pair (a_j, b_j) sits in the same lane of two adjacent 16-column tiles (weights are packed
+// [16 a-rows | 16 b-rows] per 32 rows).  LDS tiles are [128 rows][8 x 16 B] with the 16-B
+// chunk index XOR-swizzled by (row & 7); global->register->LDS staging is double-buffered
+// (loads of tile k+1 are in flight while tile k is multiplied; one barrier per K step).
+#include "common.h"
+
+namespace cum {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_GLU = 2 };
+
+struct GemmParams {
+  const void *A, *W;
+  const float *bias;       // [N] (padded), may be null
+  const void *res;         // residual [M][ldr], may be null; added AFTER the activation
+  void *out;               // [M][ldc]
+  void *aux;               // GLU: pre-activation [M][ldz] (N columns); else activation before the residual add
+  int64_t lda, ldw, ldc, ldr, ldz;
+  int M, N, K;             // N multiple of 16 (32 for GLU), K multiple of the K tile
+  int pitch, valid;        // row m is real iff (m % pitch) < valid; other rows are stored as zeros
+  int n_store;             // number of output columns to store (<= N, or N/2 for GLU); multiple of 4
+};
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <>
+struct Elem<__bf16> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+  static __device__ __forceinline__ __bf16 from_f(float v) { return (__bf16)v; }
+};
+
+template <typename T>
+__device__ __forceinline__ void store4(T *p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(float *p, const float (&v)[4]) {
+  *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<__bf16>(__bf16 *p, const float (&v)[4]) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  *reinterpret_cast<bf16x4 *>(p) = o;
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T *p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float *p, float (&v)[4]) {
+  const float4 t = *reinterpret_cast<const float4 *>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void load4<__bf16>(const __bf16 *p, float (&v)[4]) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const bf16x4 t = *reinterpret_cast<const bf16x4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
+}
+
+constexpr int BM = 128, BN = 128;
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BK = 8 * EPC;  // 64 bf16 / 32 f32: LDS rows are 128 B either way
+  __shared__ uint4 lds[2][2][BM * 8];  // [stage][0: activations, 1: weights][row * 8 + chunk]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, r = lane & 15;
+  const int n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const T *A = static_cast<const T *>(p.A);
+  const T *W = static_cast<const T *>(p.W);
+
+  // ---- global -> register staging: thread handles linear LDS positions it*256 + tid
+  const T *ga[4], *gw[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int pos = it * 256 + tid;
+    const int row = pos >> 3, cphys = pos & 7;
+    const int clog = cphys ^ (row & 7);
+    int am = m0 + row;
+    am = am < p.M ? am : p.M - 1;
+    int wr = n0 + row;
+    wr = wr < p.N ? wr : p.N - 1;
+    ga[it] = A + (int64_t)am * p.lda + clog * EPC;
+    gw[it] = W + (int64_t)wr * p.ldw + clog * EPC;
+  }
+  uint4 ra[4], rw[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      ra[it] = *reinterpret_cast<const uint4 *>(ga[it] + k0);
+      rw[it] = *reinterpret_cast<const uint4 *>(gw[it] + k0);
+    }
+  };
+  auto lstore = [&](int stage) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      lds[stage][0][it * 256 + tid] = ra[it];
+      lds[stage][1][it * 256 + tid] = rw[it];
+    }
+  };
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 wf[4], af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int wrow = wn * 64 + i * 16 + r;
+          const int arow = wm * 64 + i * 16 + r;
+          const int cl = ks * 4 + g;
+          wf[i] = __builtin_bit_cast(bf16x8, lds[st][1][wrow * 8 + (cl ^ (wrow & 7))]);
+          af[i] = __builtin_bit_cast(bf16x8, lds[st][0][arow * 8 + (cl ^ (arow & 7))]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+      }
+    } else {
+      // f32: lane reads k = 8g .. 8g+7 (two chunks) of its row; MFMA k-slot g at sub-step s is k = 8g + s
+      // for BOTH operands, so the dot product is a permutation of the same 32 products.
+      float wf[4][8], af[4][8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int wrow = wn * 64 + i * 16 + r;
+        const int arow = wm * 64 + i * 16 + r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int cl = 2 * g + h;
+          const uint4 wv = lds[st][1][wrow * 8 + (cl ^ (wrow & 7))];
+          const uint4 av = lds[st][0][arow * 8 + (cl ^ (arow & 7))];
+          wf[i][4 * h + 0] = __builtin_bit_cast(float, wv.x); wf[i][4 * h + 1] = __builtin_bit_cast(float, wv.y);
+          wf[i][4 * h + 2] = __builtin_bit_cast(float, wv.z); wf[i][4 * h + 3] = __builtin_bit_cast(float, wv.w);
+          af[i][4 * h + 0] = __builtin_bit_cast(float, av.x); af[i][4 * h + 1] = __builtin_bit_cast(float, av.y);
+          af[i][4 * h + 2] = __builtin_bit_cast(float, av.z); af[i][4 * h + 3] = __builtin_bit_cast(float, av.w);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][s], af[mi][s], acc[ni][mi], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(st ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds D[n = nb + 4g + j][m = mb + r], j = 0..3 -> 4 consecutive channels of row m
+  T *out = static_cast<T *>(p.out);
+  T *aux = static_cast<T *>(p.aux);
+  const T *res = static_cast<const T *>(p.res);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + r;
+    if (m >= p.M) continue;
+    const bool real = (m % p.pitch) < p.valid;
+    if constexpr (EPI == EPI_GLU) {
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {  // tile pair (2*pi, 2*pi+1) = (a, b)
+        const int na = n0 + wn * 64 + (2 * pi) * 16 + 4 * g;
+        const int nb = na + 16;
+        if (na >= p.N) continue;
+        float a[4], b[4], o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[j] = acc[2 * pi][mi][j] + (p.bias ? p.bias[na + j] : 0.f);
+          b[j] = acc[2 * pi + 1][mi][j] + (p.bias ? p.bias[nb + j] : 0.f);
+          o[j] = real ? a[j] * sigmoidf_(b[j]) : 0.f;
+        }
+        if (aux) {
+          store4<T>(aux + (int64_t)m * p.ldz + na, a);
+          store4<T>(aux + (int64_t)m * p.ldz + nb, b);
+        }
+        const int oc = (n0 + wn * 64) / 2 + pi * 16 + 4 * g;
+        if (oc < p.n_store) {
+          if (res) {
+            float rr[4];
+            load4<T>(res + (int64_t)m * p.ldr + oc, rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
+          }
+          store4<T>(out + (int64_t)m * p.ldc + oc, o);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+        if (n >= p.n_store) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[ni][mi][j] + (p.bias ? p.bias[n + j] : 0.f);
+          if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
+          v[j] = real ? v[j] : 0.f;
+        }
+        if (aux) store4<T>(aux + (int64_t)m * p.ldz + n, v);
+        if (res) {
+          float rr[4];
+          load4<T>(res + (int64_t)m * p.ldr + n, rr);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = real ? v[j] + rr[j] : 0.f;
+        }
+        store4<T>(out + (int64_t)m * p.ldc + n, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- elementwise backward
+// GLU backward on the packed pre-activation: Z [M][ldz] holds per 32 columns 16 a then 16 b;
+// dOut [M][ldo] holds the 16 matching output channels per group.  dZ has Z's layout.
+template <typename T>
+__global__ void glu_bwd_kernel(const T *__restrict__ Z, const T *__restrict__ dO, T *__restrict__ dZ, int64_t M,
+                               int ngroups, int64_t ldz, int64_t ldo, int n_out) {
+  const int64_t total = M * ngroups * 4;  // one thread per (row, group, quad of 4 channels)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = i & 3;
+    const int64_t t = i >> 2;
+    const int grp = t % ngroups;
+    const int64_t m = t / ngroups;
+    const int oc = grp * 16 + q * 4;
+    float a[4], b[4], d[4] = {0.f, 0.f, 0.f, 0.f}, da[4], db[4];
+    load4<T>(Z + m * ldz + grp * 32 + q * 4, a);
+    load4<T>(Z + m * ldz + grp * 32 + 16 + q * 4, b);
+    if (oc < n_out) load4<T>(dO + m * ldo + oc, d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float s = sigmoidf_(b[j]);
+      da[j] = d[j] * s;
+      db[j] = d[j] * a[j] * s * (1.f - s);
+    }
+    store4<T>(dZ + m * ldz + grp * 32 + q * 4, da);
+    store4<T>(dZ + m * ldz + grp * 32 + 16 + q * 4, db);
+  }
+}
+
+// dZ = dOut * (Y > 0)   (Y = ReLU output before any residual add); 4 elements per thread
+template <typename T>
+__global__ void relu_bwd_kernel(const T *__restrict__ Y, const T *__restrict__ dO, T *__restrict__ dZ, int64_t M,
+                                int ncol4, int64_t ldy, int64_t ldo, int64_t ldz) {
+  const int64_t total = M * ncol4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (i % ncol4) * 4;
+    const int64_t m = i / ncol4;
+    float y[4], d[4];
+    load4<T>(Y + m * ldy + c, y);
+    load4<T>(dO + m * ldo + c, d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = y[j] > 0.f ? d[j] : 0.f;
+    store4<T>(dZ + m * ldz + c, d);
+  }
+}
+
+// Column sums of X [M][ld] (first n columns) -> out[n] (f32), two deterministic stages.
+template <typename T>
+__global__ void colsum_stage1(const T *__restrict__ X, int64_t M, int n, int64_t ld, int rows_per_block,
+                              float *__restrict__ part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  r1 = r1 < M ? r1 : M;
+  float s = 0.f;
+  for (int64_t m = r0; m < r1; ++m) s += Elem<T>::to_f(X[m * ld + c]);
+  part[(int64_t)blockIdx.y * n + c] = s;
+}
+__global__ void colsum_stage2(const float *__restrict__ part, int nparts, int n, float *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int i = 0; i < nparts; ++i) s += part[(int64_t)i * n + c];
+  out[c] = s;
+}
+
+template <typename T>
+static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), block(256);
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, st, p); break;
+    case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU>), grid, block, 0, st, p); break;
+  }
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+}  // namespace cum
+
+using namespace cum;
+
+extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias, const void *res,
+                           void *out, void *aux, void *stream) {
+  CUM_REQUIRE(d && A && W && out, "gemm: null argument");
+  CUM_REQUIRE(d->dtype == CUM_F32 || d->dtype == CUM_BF16, "gemm: dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2, "gemm: bad epilogue");
+  const int bk = d->dtype == CUM_BF16 ? 64 : 32;
+  const int epc = d->dtype == CUM_BF16 ? 8 : 4;
+  CUM_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0 && d->K % bk == 0, "gemm: K must be a positive multiple of the K tile");
+  CUM_REQUIRE(d->N % (d->epilogue == 2 ? 32 : 16) == 0, "gemm: N must be a multiple of 16 (32 for GLU)");
+  CUM_REQUIRE(d->lda % epc == 0 && d->ldw % epc == 0, "gemm: lda/ldw must keep rows 16-byte aligned");
+  CUM_REQUIRE(d->ldc % 4 == 0 && d->ldr % 4 == 0 && d->ldz % 4 == 0 && d->n_store % 4 == 0, "gemm: ldc/ldr/ldz/n_store must be multiples of 4");
+  CUM_REQUIRE(d->pitch > 0 && d->valid >= 0, "gemm: bad pitch/valid");
+  CUM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A and W must be 16-byte aligned");
+  if (d->M == 0) return CUM_OK;
+  GemmParams p{};
+  p.A = A; p.W = W; p.bias = bias; p.res = res; p.out = out; p.aux = aux;
+  p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr; p.ldz = d->ldz;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;
+  if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);
+  return launch_gemm<float>(p, d->epilogue, (hipStream_t)stream);
+}
+
+extern "C" int cum_glu_bwd(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Z, int64_t ldz,
+                           const void *dOut, int64_t ldo, void *dZ, void *stream) {
+  CUM_REQUIRE(Z && dOut && dZ && n_groups > 0 && M >= 0, "glu_bwd: bad argument");
+  CUM_REQUIRE(ldz % 4 == 0 && ldo % 4 == 0, "glu_bwd: strides must be multiples of 4");
+  if (M == 0) return CUM_OK;
+  const int64_t total = M * n_groups * 4;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == CUM_BF16)
+    hipLaunchKernelGGL(glu_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Z,
+                       (const __bf16 *)dOut, (__bf16 *)dZ, M, n_groups, ldz, ldo, n_out);
+  else
+    hipLaunchKernelGGL(glu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)Z,
+                       (const float *)dOut, (float *)dZ, M, n_groups, ldz, ldo, n_out);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+extern "C" int cum_relu_bwd(int32_t dtype, int64_t M, int32_t n_cols, const void *Y, int64_t ldy, const void *dOut,
+                            int64_t ldo, void *dZ, int64_t ldz, void *stream) {
+  CUM_REQUIRE(Y && dOut && dZ && n_cols > 0 && n_cols % 4 == 0 && M >= 0, "relu_bwd: bad argument");
+  CUM_REQUIRE(ldy % 4 == 0 && ldo % 4 == 0 && ldz % 4 == 0, "relu_bwd: strides must be multiples of 4");
+  if (M == 0) return CUM_OK;
+  const int64_t total = M * (n_cols / 4);
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == CUM_BF16)
+    hipLaunchKernelGGL(relu_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Y,
+                       (const __bf16 *)dOut, (__bf16 *)dZ, M, n_cols / 4, ldy, ldo, ldz);
+  else
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)Y,
+                       (const float *)dOut, (float *)dZ, M, n_cols / 4, ldy, ldo, ldz);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+extern "C" int64_t cum_colsum_workspace_elems(int64_t M, int32_t n_cols) {
+  const int64_t parts = (M + 1023) / 1024;
+  return parts * n_cols;
+}
+
+extern "C" int cum_colsum(int32_t dtype, int64_t M, int32_t n_cols, const void *X, int64_t ld, float *out,
+                          float *workspace, void *stream) {
+  CUM_REQUIRE(X && out && workspace && n_cols > 0 && M >= 0, "colsum: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    (void)hipMemsetAsync(out, 0, sizeof(float) * n_cols, st);
+    return CUM_OK;
+  }
+  const int parts = (int)((M + 1023) / 1024);
+  dim3 grid((n_cols + 63) / 64, parts), block(64);
+  if (dtype == CUM_BF16)
+    hipLaunchKernelGGL(colsum_stage1<__bf16>, grid, block, 0, st, (const __bf16 *)X, M, n_cols, ld, 1024, workspace);
+  else
+    hipLaunchKernelGGL(colsum_stage1<float>, grid, block, 0, st, (const float *)X, M, n_cols, ld, 1024, workspace);
+  CUM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_stage2, dim3((n_cols + 63) / 64), dim3(64), 0, st, workspace, parts, n_cols, out);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}

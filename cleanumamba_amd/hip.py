@@ -40,6 +40,15 @@ class ConvShape(ctypes.Structure):
                 ("silu", c_i32)]
 
 
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("lda", c_i64), ("ldw", c_i64), ("ldc", c_i64), ("ldr", c_i64), ("ldz", c_i64),
+                ("pitch", c_i32), ("valid", c_i32), ("n_store", c_i32)]
+
+
+CUM_F32, CUM_BF16 = 0, 1
+EPI_BIAS, EPI_RELU, EPI_GLU = 0, 1, 2
+
 # name -> (restype, argtypes); mirrors include/cleanumamba_hip.h one to one.
 _P = ctypes.c_void_p
 SIGNATURES = {
@@ -56,6 +65,11 @@ SIGNATURES = {
     "cum_conv_bwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "cum_causal_conv1d_bwd": (c_i32, [ctypes.POINTER(ConvShape)] + [_P] * 5 + [c_i64] * 3 + [_P] * 4),
     "cum_causal_conv1d_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, c_i32, _P, _P]),
+    "cum_gemm_nt": (c_i32, [ctypes.POINTER(GemmDesc)] + [_P] * 7),
+    "cum_glu_bwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, _P]),
+    "cum_relu_bwd": (c_i32, [c_i32, c_i64, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P]),
+    "cum_colsum_workspace_elems": (c_i64, [c_i64, c_i32]),
+    "cum_colsum": (c_i32, [c_i32, c_i64, c_i32, _P, c_i64, _P, _P, _P]),
 }
 
 _lib = None
@@ -88,7 +102,15 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def require_gpu(*tensors):
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return CUM_F32
+    if dtype == torch.bfloat16:
+        return CUM_BF16
+    raise RuntimeError(f"cleanumamba_amd GEMM kernels take float32 or bfloat16 (got {dtype})")
+
+
+def require_gpu(*tensors, any_dtype=False):
     dev = None
     for t in tensors:
         if t is None:
@@ -96,7 +118,7 @@ def require_gpu(*tensors):
         if not t.is_cuda:
             raise RuntimeError("cleanumamba_amd: the hot path runs only on a ROCm GPU (got a %s tensor); "
                                "there is no CPU fallback" % t.device)
-        if t.dtype != torch.float32:
+        if not any_dtype and t.dtype != torch.float32:
             raise RuntimeError("cleanumamba_amd kernels take float32 tensors (got %s)" % t.dtype)
         dev = t.device if dev is None else dev
         if t.device != dev:

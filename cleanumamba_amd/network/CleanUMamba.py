@@ -30,6 +30,7 @@ import torch.nn.functional as F
 from ..mamba_ssm.models.mixer_seq_simple import _init_weights, create_block
 from ..mamba_ssm.utils.generation import InferenceParams
 from ..util.util import weight_scaling_init
+from . import convstack as cs
 from .layers import Activation
 
 
@@ -110,6 +111,11 @@ class CleanUMamba(nn.Module):
                 weight_scaling_init(layer)
         self.apply(partial(_init_weights, n_layer=tsfm_n_layers))
 
+        # True: encoder/decoder run on the fused HIP GEMM kernels (network/convstack.py).  False: the layers
+        # are called as torch modules (needed only when forward hooks on the conv modules must fire, as the
+        # reference's pruning tools expect); the Mamba bottleneck uses the HIP kernels either way.
+        self.use_fused_convs = True
+
         # streaming state
         self.total_time = 0
         self.cat_time = 0
@@ -160,18 +166,22 @@ class CleanUMamba(nn.Module):
             noisy_audio = noisy_audio / std
         x = self.pad_signal(noisy_audio)
 
-        skip_connections = []
-        for downsampling_block in self.encoder:
-            x = downsampling_block(x)
-            skip_connections.append(x)
-        skip_connections = skip_connections[::-1]
-
-        x, tsfm_out = self._bottleneck(x)
-
-        for i, upsampling_block in enumerate(self.decoder):
-            skip_i = skip_connections[i]
-            x = x + skip_i[:, :, :x.shape[-1]]
-            x = upsampling_block(x)
+        if getattr(self, "use_fused_convs", True) and x.is_cuda:
+            if not cs.supported(self):
+                raise NotImplementedError("fused conv stack covers kernel 4 / stride 2 / ungrouped / sigmoid-GLU "
+                                          "layers; set model.use_fused_convs = False for other variants")
+            x, skip_connections, tsfm_out = self._forward_fused(x)
+        else:
+            skip_connections = []
+            for downsampling_block in self.encoder:
+                x = downsampling_block(x)
+                skip_connections.append(x)
+            skip_connections = skip_connections[::-1]
+            x, tsfm_out = self._bottleneck(x)
+            for i, upsampling_block in enumerate(self.decoder):
+                skip_i = skip_connections[i]
+                x = x + skip_i[:, :, :x.shape[-1]]
+                x = upsampling_block(x)
 
         if self.normalize_input:
             x = x[:, :, :L] * std
@@ -179,6 +189,57 @@ class CleanUMamba(nn.Module):
             skip_connections.append(tsfm_out)
             return x, skip_connections
         return x
+
+    def _forward_fused(self, x):
+        """Encoder, bottleneck and decoder on channels-last row buffers (network/convstack.py).
+        x: (B, 1, valid_length) float32.  Returns (out (B, 1, T) float32, skips deepest first, tsfm_out)."""
+        B, _, T0 = x.shape
+        E = self.encoder_n_layers
+        dt = torch.float32
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.bfloat16            # fp16 autocast also maps to bf16 MFMA (f32 accumulate)
+        save = torch.is_grad_enabled()
+        geo = cs.Geo(B, T0, 1)
+        buf = cs.to_rows(x, geo, dt)
+        skips = []
+        for enc in self.encoder:
+            T1 = (geo.T - self.kernel_size) // self.stride + 1
+            g_mid = cs.Geo(B, T1, enc[0].weight.shape[0])
+            if geo.P != 2 * g_mid.P:
+                raise RuntimeError("fused conv stack needs an input of valid_length()")
+            y1 = cs.ConvK4S2ReLU.apply(buf, enc[0].weight, enc[0].bias, geo, g_mid)
+            g_out = cs.Geo(B, T1, enc[2].weight.shape[0] // 2)
+            buf = cs.PointwiseGLU.apply(y1, enc[2].weight, enc[2].bias, g_mid, g_out, save)
+            skips.append((buf, g_out))
+            geo = g_out
+        skips = skips[::-1]
+
+        g_t = cs.Geo(B, geo.T, self.tsfm_conv1.weight.shape[0])
+        hbuf = cs.Pointwise.apply(buf, self.tsfm_conv1.weight, self.tsfm_conv1.bias, None, geo, g_t)
+        hidden_states = g_t.rows(hbuf)[:, :g_t.T, :g_t.C]
+        residual = None
+        for layer in self.tsfm_Mamba_layers:
+            hidden_states, residual = layer(hidden_states, residual, inference_params=None)
+        residual = hidden_states + residual
+        hidden_states = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
+        tsfm_out = hidden_states.permute(0, 2, 1)
+        tbuf = cs.to_rows(tsfm_out, g_t, dt)
+        # tsfm_conv2 with the deepest skip added in its epilogue
+        buf = cs.Pointwise.apply(tbuf, self.tsfm_conv2.weight, self.tsfm_conv2.bias, skips[0][0], g_t, geo)
+
+        for j, dec in enumerate(self.decoder):
+            g_glu = cs.Geo(B, geo.T, dec[0].weight.shape[0] // 2)
+            gbuf = cs.PointwiseGLU.apply(buf, dec[0].weight, dec[0].bias, geo, g_glu, save)
+            last = j == E - 1
+            g_out = cs.Geo(B, 2 * geo.T + 2, dec[2].weight.shape[1])
+            skip = None
+            if not last:
+                skip, g_skip = skips[j + 1]
+                assert g_skip.T == g_out.T and g_skip.C == g_out.C
+            buf = cs.ConvT4S2.apply(gbuf, dec[2].weight, dec[2].bias, skip, g_glu, g_out, not last)
+            geo = g_out
+        out = cs.from_rows(buf, geo).float()
+        return out, [cs.from_rows(b, g) for b, g in skips], tsfm_out
 
     # ----------------------------------------------------------------- streaming
     def reset_time_per_frame(self):

@@ -1,0 +1,343 @@
+"""Encoder / decoder layers on the fused GEMM kernels (csrc/gemm.hip).
+
+Host side of the "convolution as GEMM" design (DESIGN.md "conv stack").  It reads the
+SAME parameters as the reference's modules -- encoder[i][0] Conv1d(k4,s2), encoder[i][2]
+Conv1d(1x1), decoder[j][0] Conv1d(1x1), decoder[j][2] ConvTranspose1d(k4,s2)
+(src/network/CleanUMamba.py:108-113, 121-130) -- re-packs them into GEMM operands and runs
+every layer forward and backward through ``cum_gemm_nt``; the weight-gradient products
+(plain transposed GEMMs with no fusion) go to the BLAS library via torch.matmul.
+
+Activation layout ("rows"): a 2-D tensor [1 + B*(T+2) + slack, Cp]; Cp = channels rounded
+up to 8; row 0 is a zero row, then per clip T real rows followed by 2 zero rows; the slack
+rows are zero.  For inputs of ``valid_length`` the pitch T+2 halves exactly with every
+encoder layer (T_in + 2 == 2 * (T_out + 2)), which is what makes the strided conv and the
+transposed conv single GEMMs over the flat buffer:
+  conv k4 s2 : A row m = 4*Cp contiguous elements at element offset (1 + 2m) * Cp
+  convT k4 s2: A row m = 2*Cp contiguous elements at element offset m * Cp  (rows m-1, m)
+"""
+import ctypes
+
+import torch
+
+from .. import hip
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Geo:
+    """Geometry of one activation buffer."""
+
+    def __init__(self, B, T, C):
+        self.B, self.T, self.C = B, T, C
+        self.P = T + 2
+        self.Cp = rup(C, 8)
+        self.M = B * self.P                      # flat rows that carry clips
+        self.slack = 2 + (128 + self.Cp - 1) // self.Cp
+        self.R = 1 + self.M + self.slack
+
+    def new(self, dtype, device, zero=False):
+        if zero:
+            return torch.zeros(self.R, self.Cp, dtype=dtype, device=device)
+        buf = torch.empty(self.R, self.Cp, dtype=dtype, device=device)
+        buf[0].zero_()
+        buf[1 + self.M:].zero_()
+        return buf
+
+    def rows(self, buf):
+        """[B, P, Cp] view of the clip rows."""
+        return buf[1:1 + self.M].view(self.B, self.P, self.Cp)
+
+
+def bk_of(dtype):
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def _pad2(w, rows, cols):
+    out = torch.zeros(rows, cols, dtype=w.dtype, device=w.device)
+    out[:w.shape[0], :w.shape[1]] = w
+    return out
+
+
+def _padv(b, n):
+    out = torch.zeros(n, dtype=torch.float32, device=b.device)
+    out[:b.shape[0]] = b.float()
+    return out
+
+
+# ------------------------------------------------------------------ GEMM launcher
+def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_store, res=None, r_off=0, ldr=0,
+         aux=None, x_off=0, ldz=0):
+    """A, out, res, aux: flat tensors; *_off element offsets of row 0; Wp [N, K] packed weights."""
+    hip.require_gpu(A, Wp, out, res, aux, any_dtype=True)
+    dt = A.dtype
+    if Wp.dtype != dt or out.dtype != dt:
+        raise RuntimeError("gemm: A, W and out must share one dtype")
+    esz = A.element_size()
+    d = hip.GemmDesc()
+    d.dtype, d.epilogue = hip.dtype_code(dt), epilogue
+    d.M, d.N, d.K = M, Wp.shape[0], Wp.shape[1]
+    d.lda, d.ldw, d.ldc, d.ldr, d.ldz = lda, Wp.stride(0), ldc, ldr if res is not None else 4, ldz if aux is not None else 4
+    d.pitch, d.valid, d.n_store = pitch, valid, n_store
+    P = lambda t, off: None if t is None else ctypes.c_void_p(t.data_ptr() + off * esz)
+    with torch.cuda.device(A.device):
+        hip.check(hip.lib().cum_gemm_nt(ctypes.byref(d), P(A, a_off), P(Wp, 0), hip.ptr(bias), P(res, r_off),
+                                        P(out, o_off), P(aux, x_off), hip.stream_ptr()))
+
+
+def colsum(X, x_off, ld, M, n):
+    lib = hip.lib()
+    out = torch.empty(n, dtype=torch.float32, device=X.device)
+    ws = torch.empty(max(lib.cum_colsum_workspace_elems(M, n), 1), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        hip.check(lib.cum_colsum(hip.dtype_code(X.dtype), M, n, ctypes.c_void_p(X.data_ptr() + x_off * X.element_size()),
+                                 ld, hip.ptr(out), hip.ptr(ws), hip.stream_ptr()))
+    return out
+
+
+# ------------------------------------------------------------------ weight packing
+def glu_perm(H, device):
+    """Row order of the GLU-packed weight: per 32 rows, 16 a-rows (channels 16g..16g+15) then their b-rows.
+    Returns (index into the 2H rows or -1 for padding, number of groups)."""
+    G = (H + 15) // 16
+    idx = torch.full((G * 32,), -1, dtype=torch.long, device=device)
+    ch = torch.arange(H, device=device)
+    g, c = ch // 16, ch % 16
+    idx[g * 32 + c] = ch
+    idx[g * 32 + 16 + c] = H + ch
+    return idx, G
+
+
+def pack_rows(w2d, idx, Kp, dtype):
+    """out[i] = w2d[idx[i]] (zero where idx < 0), K padded to Kp."""
+    out = torch.zeros(idx.shape[0], Kp, dtype=dtype, device=w2d.device)
+    ok = idx >= 0
+    out[ok, :w2d.shape[1]] = w2d[idx[ok]].to(dtype)
+    return out
+
+
+def unpack_rows(gp, idx, n_rows, n_cols):
+    out = torch.zeros(n_rows, n_cols, dtype=torch.float32, device=gp.device)
+    ok = idx >= 0
+    out[idx[ok]] = gp[ok, :n_cols].float()
+    return out
+
+
+# ===================================================================== fused layers
+class ConvK4S2ReLU(torch.autograd.Function):
+    """y = relu(conv1d(x, w, b, stride=2)) on row buffers.  w: (H, Cin, 4)."""
+
+    @staticmethod
+    def forward(ctx, xbuf, w, b, gi, go):
+        dt, dev = xbuf.dtype, xbuf.device
+        H, Cin, Kw = w.shape
+        assert Kw == 4 and gi.P == 2 * go.P and gi.C == Cin and go.C == H
+        K = 4 * gi.Cp
+        wp = torch.zeros(rup(H, 16), rup(K, bk_of(dt)), dtype=dt, device=dev)
+        wp[:H, :K].view(H, 4, gi.Cp)[:, :, :Cin] = w.permute(0, 2, 1).to(dt)
+        bp = _padv(b, wp.shape[0])
+        ybuf = go.new(dt, dev)
+        gemm(xbuf, gi.Cp, 2 * gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_RELU, go.Cp)
+        ctx.gi, ctx.go = gi, go
+        ctx.save_for_backward(xbuf, w, ybuf)
+        return ybuf
+
+    @staticmethod
+    def backward(ctx, dy):
+        xbuf, w, ybuf = ctx.saved_tensors
+        gi, go = ctx.gi, ctx.go
+        dt, dev = xbuf.dtype, xbuf.device
+        H, Cin, _ = w.shape
+        dy = dy.contiguous()
+        # dz = dy * (y > 0), same row layout (closing rows stay zero because dy's are zero there)
+        dz = go.new(dt, dev)
+        with torch.cuda.device(dev):
+            hip.check(hip.lib().cum_relu_bwd(hip.dtype_code(dt), go.M, go.Cp, hip.ptr(ybuf[1:]), go.Cp,
+                                             hip.ptr(dy[1:]), go.Cp, hip.ptr(dz[1:]), go.Cp, hip.stream_ptr()))
+        db = colsum(dz, go.Cp, go.Cp, go.M, H)
+        # weight gradient: dW'[:, half] = dz^T @ pair rows of x (plain GEMMs -> BLAS)
+        x2 = xbuf.view(-1)[gi.Cp:gi.Cp + (go.M + 1) * 2 * gi.Cp].view(go.M + 1, 2 * gi.Cp)
+        dzr = dz[1:1 + go.M]
+        dwp = torch.cat([dzr.t() @ x2[:go.M], dzr.t() @ x2[1:go.M + 1]], dim=1)       # [Hp, 4*Cp]
+        dw = dwp[:H].float().view(H, 4, gi.Cp)[:, :, :Cin].permute(0, 2, 1).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # data gradient = transposed conv: pair row t' of dx reads dz rows t'-1, t'
+            K = 2 * go.Cp
+            wd = torch.zeros(rup(2 * gi.Cp, 16), rup(K, bk_of(dt)), dtype=dt, device=dev)
+            wv = wd[:2 * gi.Cp, :K].view(2, gi.Cp, 2, go.Cp)           # [j][c][half][h]
+            wt = w.to(dt).permute(2, 1, 0)                              # [kk][c][h]
+            wv[0, :Cin, 0, :H], wv[0, :Cin, 1, :H] = wt[2], wt[0]
+            wv[1, :Cin, 0, :H], wv[1, :Cin, 1, :H] = wt[3], wt[1]
+            dx = gi.new(dt, dev)
+            gemm(dz, 0, go.Cp, wd, None, dx, gi.Cp, 2 * gi.Cp, go.M, go.P, go.T + 1, hip.EPI_BIAS, 2 * gi.Cp)
+        return dx, dw.to(w.dtype), db.to(w.dtype), None, None
+
+
+class PointwiseGLU(torch.autograd.Function):
+    """y = glu(conv1x1(x, w, b)) (+ nothing); w: (2H, Cin, 1).  Rows in, rows out (same geometry T)."""
+
+    @staticmethod
+    def forward(ctx, xbuf, w, b, gi, go, save_z):
+        dt, dev = xbuf.dtype, xbuf.device
+        H2, Cin, _ = w.shape
+        H = H2 // 2
+        assert gi.T == go.T and go.C == H and gi.C == Cin
+        idx, G = glu_perm(H, dev)
+        wp = pack_rows(w[:, :, 0], idx, rup(gi.Cp, bk_of(dt)), dt)
+        bp = torch.zeros(G * 32, dtype=torch.float32, device=dev)
+        bp[idx >= 0] = b.float()[idx[idx >= 0]]
+        ybuf = go.new(dt, dev)
+        z = torch.empty(go.M, G * 32, dtype=dt, device=dev) if save_z else None
+        gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_GLU, go.Cp,
+             aux=z, x_off=0, ldz=G * 32)
+        ctx.gi, ctx.go, ctx.G = gi, go, G
+        ctx.save_for_backward(xbuf, w, z, idx)
+        return ybuf
+
+    @staticmethod
+    def backward(ctx, dy):
+        xbuf, w, z, idx = ctx.saved_tensors
+        if z is None:
+            raise RuntimeError("PointwiseGLU was run without save_z; backward is unavailable")
+        gi, go, G = ctx.gi, ctx.go, ctx.G
+        dt, dev = xbuf.dtype, xbuf.device
+        H2, Cin, _ = w.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        with torch.cuda.device(dev):
+            hip.check(hip.lib().cum_glu_bwd(hip.dtype_code(dt), go.M, G, go.Cp, hip.ptr(z), G * 32, hip.ptr(dy[1:]),
+                                            go.Cp, hip.ptr(dz), hip.stream_ptr()))
+        dbp = colsum(dz, 0, G * 32, go.M, G * 32)
+        ok = idx >= 0
+        db = torch.zeros(H2, dtype=torch.float32, device=dev)
+        db[idx[ok]] = dbp[ok]
+        xr = xbuf[1:1 + gi.M]
+        dwp = dz.t() @ xr                                                   # [G*32, Cp_in]
+        dw = unpack_rows(dwp, idx, H2, Cin).unsqueeze(-1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.zeros(rup(gi.Cp, 16), rup(G * 32, bk_of(dt)), dtype=dt, device=dev)
+            wt[:Cin, :G * 32][:, ok] = w[:, :, 0].to(dt)[idx[ok]].t()
+            dx = gi.new(dt, dev)
+            gemm(dz, 0, G * 32, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
+        return dx, dw.to(w.dtype), db.to(w.dtype), None, None, None
+
+
+class ConvT4S2(torch.autograd.Function):
+    """y = [relu](conv_transpose1d(x, w, b, stride=2)) [+ skip]; w: (Cin, Cout, 4).  go.P == 2 * gi.P."""
+
+    @staticmethod
+    def forward(ctx, xbuf, w, b, skip, gi, go, relu):
+        dt, dev = xbuf.dtype, xbuf.device
+        Cin, Cout, Kw = w.shape
+        assert Kw == 4 and go.P == 2 * gi.P and gi.C == Cin and go.C == Cout
+        K = 2 * gi.Cp
+        N = 2 * go.Cp
+        wp = torch.zeros(rup(N, 16), rup(K, bk_of(dt)), dtype=dt, device=dev)
+        wv = wp[:N, :K].view(2, go.Cp, 2, gi.Cp)                       # [j][co][half][c]
+        wt = w.to(dt).permute(2, 1, 0)                                  # [kk][co][c]
+        wv[0, :Cout, 0, :Cin], wv[0, :Cout, 1, :Cin] = wt[2], wt[0]
+        wv[1, :Cout, 0, :Cin], wv[1, :Cout, 1, :Cin] = wt[3], wt[1]
+        bp = torch.zeros(wp.shape[0], dtype=torch.float32, device=dev)
+        bp[:N].view(2, go.Cp)[:, :Cout] = b.float()
+        ybuf = go.new(dt, dev)
+        keep = relu and skip is not None            # the ReLU mask is not recoverable from y + skip
+        act = go.new(dt, dev) if keep else None
+        gemm(xbuf, 0, gi.Cp, wp, bp, ybuf, go.Cp, N, gi.M, gi.P, gi.T + 1, hip.EPI_RELU if relu else hip.EPI_BIAS, N,
+             res=skip, r_off=go.Cp, ldr=N, aux=act, x_off=go.Cp, ldz=N)
+        ctx.gi, ctx.go, ctx.relu, ctx.has_skip = gi, go, relu, skip is not None
+        ctx.save_for_backward(xbuf, w, act if keep else (ybuf if relu else None))
+        return ybuf
+
+    @staticmethod
+    def backward(ctx, dy):
+        xbuf, w, act = ctx.saved_tensors
+        gi, go = ctx.gi, ctx.go
+        dt, dev = xbuf.dtype, xbuf.device
+        Cin, Cout, _ = w.shape
+        dy = dy.contiguous()
+        dskip = dy if ctx.has_skip else None
+        if ctx.relu:
+            dz = go.new(dt, dev)
+            with torch.cuda.device(dev):
+                hip.check(hip.lib().cum_relu_bwd(hip.dtype_code(dt), go.M, go.Cp, hip.ptr(act[1:]), go.Cp,
+                                                 hip.ptr(dy[1:]), go.Cp, hip.ptr(dz[1:]), go.Cp, hip.stream_ptr()))
+        else:
+            dz = dy
+        db = colsum(dz, go.Cp, go.Cp, go.M, Cout)
+        # weight gradient: pair rows of dz against rows (m-1, m) of x
+        dz2 = dz.view(-1)[go.Cp:go.Cp + gi.M * 2 * go.Cp].view(gi.M, 2 * go.Cp)
+        dwp = torch.cat([dz2.t() @ xbuf[0:gi.M], dz2.t() @ xbuf[1:gi.M + 1]], dim=1)   # [2*Cop, 2*Cip]
+        dv = dwp.float().view(2, go.Cp, 2, gi.Cp)[:, :Cout, :, :Cin]                    # [j][co][half][c]
+        dw = torch.stack([dv[0, :, 1], dv[1, :, 1], dv[0, :, 0], dv[1, :, 0]], dim=0).permute(2, 1, 0).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # data gradient = strided conv of dz: row t reads dz rows 2t..2t+3
+            K = 4 * go.Cp
+            wc = torch.zeros(rup(gi.Cp, 16), rup(K, bk_of(dt)), dtype=dt, device=dev)
+            wc[:Cin, :K].view(Cin, 4, go.Cp)[:, :, :Cout] = w.to(dt).permute(0, 2, 1)
+            dx = gi.new(dt, dev)
+            gemm(dz, go.Cp, 2 * go.Cp, wc, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
+        return dx, dw.to(w.dtype), db.to(w.dtype), dskip, None, None, None
+
+
+class Pointwise(torch.autograd.Function):
+    """y = conv1x1(x, w, b) [+ skip]; w: (Cout, Cin, 1)."""
+
+    @staticmethod
+    def forward(ctx, xbuf, w, b, skip, gi, go):
+        dt, dev = xbuf.dtype, xbuf.device
+        Cout, Cin, _ = w.shape
+        assert gi.T == go.T and gi.C == Cin and go.C == Cout
+        wp = _pad2(w[:, :, 0].to(dt), rup(Cout, 16), rup(gi.Cp, bk_of(dt)))
+        bp = _padv(b, wp.shape[0])
+        ybuf = go.new(dt, dev)
+        gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_BIAS, go.Cp,
+             res=skip, r_off=go.Cp, ldr=go.Cp)
+        ctx.gi, ctx.go, ctx.has_skip = gi, go, skip is not None
+        ctx.save_for_backward(xbuf, w)
+        return ybuf
+
+    @staticmethod
+    def backward(ctx, dy):
+        xbuf, w = ctx.saved_tensors
+        gi, go = ctx.gi, ctx.go
+        dt, dev = xbuf.dtype, xbuf.device
+        Cout, Cin, _ = w.shape
+        dy = dy.contiguous()
+        db = colsum(dy, go.Cp, go.Cp, go.M, Cout)
+        dw = (dy[1:1 + go.M].t() @ xbuf[1:1 + gi.M])[:Cout, :Cin].float().unsqueeze(-1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = _pad2(w[:, :, 0].to(dt).t(), rup(gi.Cp, 16), rup(go.Cp, bk_of(dt)))
+            dx = gi.new(dt, dev)
+            gemm(dy, go.Cp, go.Cp, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
+        return dx, dw.to(w.dtype), db.to(w.dtype), (dy if ctx.has_skip else None), None, None
+
+
+# ===================================================================== row <-> tensor glue
+def to_rows(x, geo, dtype):
+    """(B, C, T) tensor -> row buffer (differentiable)."""
+    buf = torch.zeros(geo.R, geo.Cp, dtype=dtype, device=x.device)
+    geo.rows(buf)[:, :geo.T, :geo.C] = x.transpose(1, 2).to(dtype)
+    return buf
+
+
+def from_rows(buf, geo):
+    """row buffer -> (B, C, T) view (channel stride 1)."""
+    return geo.rows(buf)[:, :geo.T, :geo.C].transpose(1, 2)
+
+
+def supported(model):
+    """The fused path covers the shipped configuration: kernel 4, stride 2, ungrouped convs, sigmoid GLU,
+    no bypass channels."""
+    if model.kernel_size != 4 or model.stride != 2:
+        return False
+    for enc, dec in zip(model.encoder, model.decoder):
+        if enc[0].groups != 1 or enc[3].bypass_channels != 0 or dec[1].bypass_channels != 0:
+            return False
+        if not isinstance(enc[3].activation, torch.nn.Sigmoid) or not isinstance(dec[1].activation, torch.nn.Sigmoid):
+            return False
+    return True

@@ -137,6 +137,52 @@ int cum_causal_conv1d_update(int32_t batch, int32_t dim, int32_t width, float *c
                              const float *x, const float *weight, const float *bias,
                              int32_t silu, float *y, void *stream);
 
+/* ------------------------------------------- encoder / decoder layers as fused GEMMs
+ * Replaces cuDNN/cuBLAS behind nn.Conv1d / nn.ConvTranspose1d (+ ReLU / GLU / skip add)
+ * of the encoder and decoder layers (src/network/CleanUMamba.py:108-113, 121-130,
+ * 313-316; GLU src/network/layers.py:26-33).
+ *
+ *   out[m][n] = epilogue( sum_k A[m*lda + k] * W[n*ldw + k] + bias[n] )   (+ res[m][n])
+ *
+ * A rows may overlap (lda < K): with channels-last activations [B, T+2, C] a Conv1d
+ * (k=4, s=2) output row reads 4*C contiguous elements at row stride 2*C, and a
+ * ConvTranspose1d (k=4, s=2) output row pair reads 2*C contiguous elements at row
+ * stride C, so both are this GEMM with re-packed weights (DESIGN.md "conv stack").
+ * W is [N][ldw] with the K axis contiguous and zero-padded to K; bias is f32[N].
+ * epilogue: 0 bias, 1 bias+ReLU, 2 bias+GLU (weights packed 16 a-rows then 16 b-rows per
+ * 32 rows; the output has N/2 columns).  Rows with (m % pitch) >= valid are written as
+ * zeros.  aux (optional): GLU -> the pre-activation [M][ldz] (N columns);
+ * otherwise -> the activation before the residual add.  res is added after the activation.
+ * dtype: element type of A, W, res, out, aux; accumulation is always f32. */
+#define CUM_F32 0
+#define CUM_BF16 1
+
+typedef struct {
+  int32_t dtype, epilogue;
+  int32_t M, N, K;           /* N multiple of 16 (32 for GLU); K multiple of 64 (bf16) / 32 (f32) */
+  int64_t lda, ldw, ldc, ldr, ldz;
+  int32_t pitch, valid;
+  int32_t n_store;           /* output columns written (multiple of 4) */
+} cum_gemm_desc;
+
+int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias,
+                const void *res, void *out, void *aux, void *stream);
+
+/* GLU backward on the packed pre-activation Z [M][ldz] (n_groups x (16 a | 16 b));
+ * dOut [M][ldo] has 16 channels per group (n_out valid columns); dZ has Z's layout. */
+int cum_glu_bwd(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Z,
+                int64_t ldz, const void *dOut, int64_t ldo, void *dZ, void *stream);
+
+/* dZ = dOut * (Y > 0) over M rows x n_cols columns (n_cols multiple of 4). */
+int cum_relu_bwd(int32_t dtype, int64_t M, int32_t n_cols, const void *Y, int64_t ldy,
+                 const void *dOut, int64_t ldo, void *dZ, int64_t ldz, void *stream);
+
+/* out[c] = sum_m X[m*ld + c] in f32 (bias gradients); deterministic two-stage reduction.
+ * workspace: cum_colsum_workspace_elems() f32 elements. */
+int64_t cum_colsum_workspace_elems(int64_t M, int32_t n_cols);
+int cum_colsum(int32_t dtype, int64_t M, int32_t n_cols, const void *X, int64_t ld, float *out,
+               float *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,104 @@
+"""Fused encoder / decoder layers (csrc/gemm.hip via network/convstack.py) vs the oracle's
+F.conv1d / F.conv_transpose1d restatement, forward and backward, fp32 and bf16 (GPU)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import cleanumamba_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer_params(cin, h, cout, seed):
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    return {"encoder.0.0.weight": rn(h, cin, 4) / (4 * cin) ** 0.5, "encoder.0.0.bias": 0.1 * rn(h),
+            "encoder.0.2.weight": rn(2 * h, h, 1) / h ** 0.5, "encoder.0.2.bias": 0.1 * rn(2 * h),
+            "decoder.0.0.weight": rn(2 * h, h, 1) / h ** 0.5, "decoder.0.0.bias": 0.1 * rn(2 * h),
+            "decoder.0.2.weight": rn(h, cout, 4) / (2 * h) ** 0.5, "decoder.0.2.bias": 0.1 * rn(cout)}
+
+
+@pytest.mark.parametrize("cin,h,tin", [(1, 64, 62), (53, 74, 30), (128, 256, 126), (768, 768, 14)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_encoder_layer_fwd_bwd(cuda, cin, h, tin, dtype, tol):
+    from cleanumamba_amd.network import convstack as cs
+    B = 3
+    sd = _layer_params(cin, h, h, seed=cin + h)
+    x = torch.randn(B, cin, tin, generator=torch.Generator().manual_seed(1))
+    tout = (tin - 4) // 2 + 1
+    dout = torch.randn(B, h, tout, generator=torch.Generator().manual_seed(2))
+    ref = {k: v.double().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder")}
+    xr = x.double().requires_grad_(True)
+    yr = R.encoder_layer(ref, 0, xr)
+    (yr * dout.double()).sum().backward()
+
+    dev = {k: v.to(cuda).requires_grad_(True) for k, v in sd.items() if k.startswith("encoder")}
+    xd = x.to(cuda).requires_grad_(True)
+    gi, gm, go = cs.Geo(B, tin, cin), cs.Geo(B, tout, h), cs.Geo(B, tout, h)
+    buf = cs.to_rows(xd, gi, dtype)
+    y1 = cs.ConvK4S2ReLU.apply(buf, dev["encoder.0.0.weight"], dev["encoder.0.0.bias"], gi, gm)
+    ybuf = cs.PointwiseGLU.apply(y1, dev["encoder.0.2.weight"], dev["encoder.0.2.bias"], gm, go, True)
+    y = cs.from_rows(ybuf, go).float()
+    assert rel_l2(y, yr) < tol
+    # closing rows / padded channels stay zero
+    rows = go.rows(ybuf)
+    assert float(rows[:, go.T:].abs().max()) == 0 and float(rows[:, :, go.C:].abs().max() if go.Cp > go.C else 0) == 0
+    (y * dout.to(cuda)).sum().backward()
+    assert rel_l2(xd.grad, xr.grad) < 5 * tol
+    for k in dev:
+        assert rel_l2(dev[k].grad, ref[k].grad) < 5 * tol, k
+
+
+@pytest.mark.parametrize("h,cout,t,relu,with_skip", [(64, 1, 30, False, False), (74, 53, 14, True, True),
+                                                     (256, 128, 62, True, True), (768, 768, 6, True, True)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_decoder_layer_fwd_bwd(cuda, h, cout, t, relu, with_skip, dtype, tol):
+    from cleanumamba_amd.network import convstack as cs
+    B = 2
+    sd = _layer_params(h, h, cout, seed=h + cout)
+    x = torch.randn(B, h, t, generator=torch.Generator().manual_seed(3))
+    skip = torch.randn(B, cout, 2 * t + 2, generator=torch.Generator().manual_seed(4))
+    dout = torch.randn(B, cout, 2 * t + 2, generator=torch.Generator().manual_seed(5))
+    ref = {k: v.double().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder")}
+    xr, sr = x.double().requires_grad_(True), skip.double().requires_grad_(True)
+    yr = R.decoder_layer(ref, 0, xr, last=not relu)
+    if with_skip:
+        yr = yr + sr
+    (yr * dout.double()).sum().backward()
+
+    dev = {k: v.to(cuda).requires_grad_(True) for k, v in sd.items() if k.startswith("decoder")}
+    xd, sk = x.to(cuda).requires_grad_(True), skip.to(cuda).requires_grad_(True)
+    gi, gg, go = cs.Geo(B, t, h), cs.Geo(B, t, h), cs.Geo(B, 2 * t + 2, cout)
+    buf = cs.to_rows(xd, gi, dtype)
+    sbuf = cs.to_rows(sk, go, dtype) if with_skip else None
+    g = cs.PointwiseGLU.apply(buf, dev["decoder.0.0.weight"], dev["decoder.0.0.bias"], gi, gg, True)
+    ybuf = cs.ConvT4S2.apply(g, dev["decoder.0.2.weight"], dev["decoder.0.2.bias"], sbuf, gg, go, relu)
+    y = cs.from_rows(ybuf, go).float()
+    assert rel_l2(y, yr) < tol
+    assert float(go.rows(ybuf)[:, go.T:].abs().max()) == 0
+    (y * dout.to(cuda)).sum().backward()
+    assert rel_l2(xd.grad, xr.grad) < 5 * tol
+    if with_skip:
+        assert rel_l2(sk.grad, sr.grad) < 5 * tol
+    for k in dev:
+        assert rel_l2(dev[k].grad, ref[k].grad) < 5 * tol, k
+
+
+def test_pointwise_with_residual(cuda):
+    from cleanumamba_amd.network import convstack as cs
+    B, cin, cout, t = 2, 512, 768, 10
+    g = torch.Generator().manual_seed(9)
+    w, b = torch.randn(cout, cin, 1, generator=g) / cin ** 0.5, torch.randn(cout, generator=g)
+    x, s = torch.randn(B, cin, t, generator=g), torch.randn(B, cout, t, generator=g)
+    yr = torch.nn.functional.conv1d(x.double(), w.double(), b.double()) + s.double()
+    gi, go = cs.Geo(B, t, cin), cs.Geo(B, t, cout)
+    wd, bd = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    xd = x.to(cuda).requires_grad_(True)
+    ybuf = cs.Pointwise.apply(cs.to_rows(xd, gi, torch.float32), wd, bd, cs.to_rows(s.to(cuda), go, torch.float32),
+                              gi, go)
+    y = cs.from_rows(ybuf, go)
+    assert rel_l2(y, yr) < 2e-5
+    y.square().sum().backward()
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (torch.nn.functional.conv1d(xr, wr, b.double()) + s.double()).square().sum().backward()
+    assert rel_l2(xd.grad, xr.grad) < 1e-4 and rel_l2(wd.grad, wr.grad) < 1e-4

@@ -55,7 +55,7 @@ def test_full_width_model_forward_and_gradients(cuda, name):
     disagree on the sign of a ~1e-5 fraction of pre-activations, which moves upstream gradients by
     sqrt(fraction) ~ 0.3-1.5 % in rel-L2 (measured; the last decoder layer, behind no ReLU, agrees to
     1e-6).  The tight backward checks are the per-op ones in test_scan_gpu.py; here the bound is 3 %
-    per sampled tensor and 0.5 % on norms."""
+    per sampled tensor and 2 % on norms."""
     from cleanumamba_amd.network import CleanUMamba
     g = load_golden("e2e_" + name)
     meta = golden_json(g["meta"])
@@ -77,7 +77,7 @@ def test_full_width_model_forward_and_gradients(cuda, name):
             ref_head = T(g[k]).double().norm().item()
             tol = 1e-5 if k.endswith(f"decoder.{meta['cfg']['encoder_n_layers'] - 1}.2.weight") else 3e-2
             assert err < tol * ref_head, (k, err, ref_head)
-            assert abs(p.grad.double().norm().item() - gn) < 5e-3 * gn
+            assert abs(p.grad.double().norm().item() - gn) < 2e-2 * gn
     tot = sum((p.grad.double() ** 2).sum().item() for p in net.parameters())
     assert abs(tot - float(g["grad_sq_total"])) < 1e-3 * float(g["grad_sq_total"])
 

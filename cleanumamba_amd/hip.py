@@ -70,6 +70,8 @@ SIGNATURES = {
     "cum_relu_bwd": (c_i32, [c_i32, c_i64, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P]),
     "cum_colsum_workspace_elems": (c_i64, [c_i64, c_i32]),
     "cum_colsum": (c_i32, [c_i32, c_i64, c_i32, _P, c_i64, _P, _P, _P]),
+    "cum_gemm_tn_workspace_elems": (c_i64, [c_i32, c_i64, c_i32, c_i32]),
+    "cum_gemm_tn": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P, _P, _P]),
 }
 
 _lib = None

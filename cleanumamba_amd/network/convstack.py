@@ -86,6 +86,22 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
                                         P(out, o_off), P(aux, x_off), hip.stream_ptr()))
 
 
+def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True):
+    """dW [N, K] f32 = dZ^T X (X rows may overlap), db [N] f32 = column sums of dZ.  csrc/gemm_tn.hip."""
+    lib = hip.lib()
+    dc = hip.dtype_code(dZ.dtype)
+    dev = dZ.device
+    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    ws = torch.empty(max(lib.cum_gemm_tn_workspace_elems(dc, M, N, K), 1), dtype=torch.float32, device=dev)
+    esz = dZ.element_size()
+    with torch.cuda.device(dev):
+        hip.check(lib.cum_gemm_tn(dc, M, N, K, ctypes.c_void_p(dZ.data_ptr() + z_off * esz), ldz,
+                                  ctypes.c_void_p(X.data_ptr() + x_off * esz), ldx, hip.ptr(dW), K, hip.ptr(db),
+                                  hip.ptr(ws), hip.stream_ptr()))
+    return dW, db
+
+
 def colsum(X, x_off, ld, M, n):
     lib = hip.lib()
     out = torch.empty(n, dtype=torch.float32, device=X.device)
@@ -155,12 +171,10 @@ class ConvK4S2ReLU(torch.autograd.Function):
         with torch.cuda.device(dev):
             hip.check(hip.lib().cum_relu_bwd(hip.dtype_code(dt), go.M, go.Cp, hip.ptr(ybuf[1:]), go.Cp,
                                              hip.ptr(dy[1:]), go.Cp, hip.ptr(dz[1:]), go.Cp, hip.stream_ptr()))
-        db = colsum(dz, go.Cp, go.Cp, go.M, H)
-        # weight gradient: dW'[:, half] = dz^T @ pair rows of x (plain GEMMs -> BLAS)
-        x2 = xbuf.view(-1)[gi.Cp:gi.Cp + (go.M + 1) * 2 * gi.Cp].view(go.M + 1, 2 * gi.Cp)
-        dzr = dz[1:1 + go.M]
-        dwp = torch.cat([dzr.t() @ x2[:go.M], dzr.t() @ x2[1:go.M + 1]], dim=1)       # [Hp, 4*Cp]
-        dw = dwp[:H].float().view(H, 4, gi.Cp)[:, :, :Cin].permute(0, 2, 1).contiguous()
+        # weight + bias gradient in one launch: X row m = the 4*Cp contiguous inputs of output row m
+        dwp, dbp = wgrad(dz, go.Cp, go.Cp, go.Cp, xbuf, gi.Cp, 2 * gi.Cp, 4 * gi.Cp, go.M)
+        db = dbp[:H]
+        dw = dwp[:H].view(H, 4, gi.Cp)[:, :, :Cin].permute(0, 2, 1).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
             # data gradient = transposed conv: pair row t' of dx reads dz rows t'-1, t'
@@ -209,12 +223,10 @@ class PointwiseGLU(torch.autograd.Function):
         with torch.cuda.device(dev):
             hip.check(hip.lib().cum_glu_bwd(hip.dtype_code(dt), go.M, G, go.Cp, hip.ptr(z), G * 32, hip.ptr(dy[1:]),
                                             go.Cp, hip.ptr(dz), hip.stream_ptr()))
-        dbp = colsum(dz, 0, G * 32, go.M, G * 32)
+        dwp, dbp = wgrad(dz, 0, G * 32, G * 32, xbuf, gi.Cp, gi.Cp, gi.Cp, go.M)
         ok = idx >= 0
         db = torch.zeros(H2, dtype=torch.float32, device=dev)
         db[idx[ok]] = dbp[ok]
-        xr = xbuf[1:1 + gi.M]
-        dwp = dz.t() @ xr                                                   # [G*32, Cp_in]
         dw = unpack_rows(dwp, idx, H2, Cin).unsqueeze(-1)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -266,11 +278,10 @@ class ConvT4S2(torch.autograd.Function):
                                                  hip.ptr(dy[1:]), go.Cp, hip.ptr(dz[1:]), go.Cp, hip.stream_ptr()))
         else:
             dz = dy
-        db = colsum(dz, go.Cp, go.Cp, go.M, Cout)
-        # weight gradient: pair rows of dz against rows (m-1, m) of x
-        dz2 = dz.view(-1)[go.Cp:go.Cp + gi.M * 2 * go.Cp].view(gi.M, 2 * go.Cp)
-        dwp = torch.cat([dz2.t() @ xbuf[0:gi.M], dz2.t() @ xbuf[1:gi.M + 1]], dim=1)   # [2*Cop, 2*Cip]
-        dv = dwp.float().view(2, go.Cp, 2, gi.Cp)[:, :Cout, :, :Cin]                    # [j][co][half][c]
+        # weight + bias gradient: pair rows of dz against the 2*Cp contiguous inputs (rows m-1, m) of x
+        dwp, dbp = wgrad(dz, go.Cp, 2 * go.Cp, 2 * go.Cp, xbuf, 0, gi.Cp, 2 * gi.Cp, gi.M)
+        db = (dbp[:go.Cp] + dbp[go.Cp:])[:Cout]
+        dv = dwp.view(2, go.Cp, 2, gi.Cp)[:, :Cout, :, :Cin]                            # [j][co][half][c]
         dw = torch.stack([dv[0, :, 1], dv[1, :, 1], dv[0, :, 0], dv[1, :, 0]], dim=0).permute(2, 1, 0).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
@@ -307,8 +318,9 @@ class Pointwise(torch.autograd.Function):
         dt, dev = xbuf.dtype, xbuf.device
         Cout, Cin, _ = w.shape
         dy = dy.contiguous()
-        db = colsum(dy, go.Cp, go.Cp, go.M, Cout)
-        dw = (dy[1:1 + go.M].t() @ xbuf[1:1 + gi.M])[:Cout, :Cin].float().unsqueeze(-1)
+        dwp, dbp = wgrad(dy, go.Cp, go.Cp, go.Cp, xbuf, gi.Cp, gi.Cp, gi.Cp, go.M)
+        db = dbp[:Cout]
+        dw = dwp[:Cout, :Cin].unsqueeze(-1)
         dx = None
         if ctx.needs_input_grad[0]:
             wt = _pad2(w[:, :, 0].to(dt).t(), rup(gi.Cp, 16), rup(go.Cp, bk_of(dt)))

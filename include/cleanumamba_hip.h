@@ -183,6 +183,16 @@ int64_t cum_colsum_workspace_elems(int64_t M, int32_t n_cols);
 int cum_colsum(int32_t dtype, int64_t M, int32_t n_cols, const void *X, int64_t ld, float *out,
                float *workspace, void *stream);
 
+/* Weight gradient of any of the layers above, with the bias gradient fused:
+ *   dW[n*ldw + k] = sum_m dZ[m*ldz + n] * X[m*ldx + k]   (n < N, k < K),   db[n] = sum_m dZ[m*ldz + n]
+ * X rows may overlap (ldx < K) as in cum_gemm_nt.  dW, db are f32 and fully overwritten; db may
+ * be NULL.  The m axis is split over workgroups and combined deterministically.
+ * workspace: cum_gemm_tn_workspace_elems() f32 elements. */
+int64_t cum_gemm_tn_workspace_elems(int32_t dtype, int64_t M, int32_t N, int32_t K);
+int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz,
+                const void *X, int64_t ldx, float *dW, int64_t ldw, float *db, float *workspace,
+                void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,8 +22,11 @@
 // ends up with 4 CONSECUTIVE output channels of one row: 8-/16-byte stores, and the GLU
 // pair (a_j, b_j) sits in the same lane of two adjacent 16-column tiles (weights are packed
 // [16 a-rows | 16 b-rows] per 32 rows).  LDS tiles are [128 rows][8 x 16 B] with the 16-B
-// chunk index XOR-swizzled by (row & 7); global->register->LDS staging is double-buffered
-// (loads of tile k+1 are in flight while tile k is multiplied; one barrier per K step).
+// chunk index XOR-swizzled by (row & 7).  Tiles go HBM -> LDS directly (global_load_lds_dwordx4,
+// no staging VGPRs; the swizzle is applied to the per-lane SOURCE address because the LDS side of
+// the DMA is linear), single-buffered: 32 KB of LDS and ~110 VGPRs per workgroup let 4 workgroups
+// share a CU, and their interleaving hides the load latency (CDNA guide: the 128x128 "step-3"
+// structure).
 #include "common.h"
 
 namespace cum {
@@ -90,16 +93,24 @@ __device__ __forceinline__ void load4<__bf16>(const __bf16 *p, float (&v)[4]) {
 constexpr int BM = 128, BN = 128;
 
 template <typename T, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_kernel(const GemmParams p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;  // 64 bf16 / 32 f32: LDS rows are 128 B either way
-  __shared__ uint4 lds[2][2][BM * 8];  // [stage][0: activations, 1: weights][row * 8 + chunk]
+  __shared__ uint4 lds[2][BM * 8];  // [0: activations, 1: weights][row * 8 + chunk]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
+  // ids b and b+8 share an L2.  All n-tiles of one m-tile get ids that are 8 apart: they run back to back on
+  // ONE XCD and the activation panel (128 x K) is fetched from HBM once instead of once per n-tile; the small
+  // weight matrix is served from the Infinity Cache.  Placement affects speed only.
+  const int NB = (p.N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int m_tile = (local / NB) * 8 + xcd;
+  const int n0 = (local % NB) * BN;
+  const int m0 = m_tile * BM;
+  if (m0 >= p.M) return;
   const T *A = static_cast<const T *>(p.A);
   const T *W = static_cast<const T *>(p.W);
 
@@ -117,21 +128,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
     ga[it] = A + (int64_t)am * p.lda + clog * EPC;
     gw[it] = W + (int64_t)wr * p.ldw + clog * EPC;
   }
-  uint4 ra[4], rw[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      ra[it] = *reinterpret_cast<const uint4 *>(ga[it] + k0);
-      rw[it] = *reinterpret_cast<const uint4 *>(gw[it] + k0);
-    }
-  };
-  auto lstore = [&](int stage) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      lds[stage][0][it * 256 + tid] = ra[it];
-      lds[stage][1][it * 256 + tid] = rw[it];
-    }
-  };
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+  const int wave_u = uniform(wave);
+  // one wave-instruction fills 1 KiB = 8 LDS rows; lane L writes chunk position it*256 + wave*64 + L
+#define CUM_GLDS(k0)                                                                                              \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                             \
+    __builtin_amdgcn_global_load_lds((glb_ptr)(ga[it] + (k0)), (lds_ptr)(&lds[0][it * 256 + wave_u * 64]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((glb_ptr)(gw[it] + (k0)), (lds_ptr)(&lds[1][it * 256 + wave_u * 64]), 16, 0, 0); \
+  }
 
   f32x4 acc[4][4];  // [ni][mi]
 #pragma unroll
@@ -140,12 +145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int st = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    CUM_GLDS(kt * BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
           const int wrow = wn * 64 + i * 16 + r;
           const int arow = wm * 64 + i * 16 + r;
           const int cl = ks * 4 + g;
-          wf[i] = __builtin_bit_cast(bf16x8, lds[st][1][wrow * 8 + (cl ^ (wrow & 7))]);
-          af[i] = __builtin_bit_cast(bf16x8, lds[st][0][arow * 8 + (cl ^ (arow & 7))]);
+          wf[i] = __builtin_bit_cast(bf16x8, lds[1][wrow * 8 + (cl ^ (wrow & 7))]);
+          af[i] = __builtin_bit_cast(bf16x8, lds[0][arow * 8 + (cl ^ (arow & 7))]);
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int cl = 2 * g + h;
-          const uint4 wv = lds[st][1][wrow * 8 + (cl ^ (wrow & 7))];
-          const uint4 av = lds[st][0][arow * 8 + (cl ^ (arow & 7))];
+          const uint4 wv = lds[1][wrow * 8 + (cl ^ (wrow & 7))];
+          const uint4 av = lds[0][arow * 8 + (cl ^ (arow & 7))];
           wf[i][4 * h + 0] = __builtin_bit_cast(float, wv.x); wf[i][4 * h + 1] = __builtin_bit_cast(float, wv.y);
           wf[i][4 * h + 2] = __builtin_bit_cast(float, wv.z); wf[i][4 * h + 3] = __builtin_bit_cast(float, wv.w);
           af[i][4 * h + 0] = __builtin_bit_cast(float, av.x); af[i][4 * h + 1] = __builtin_bit_cast(float, av.y);
@@ -191,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
           for (int mi = 0; mi < 4; ++mi)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][s], af[mi][s], acc[ni][mi], 0, 0, 0);
     }
-    if (kt + 1 < nk) lstore(st ^ 1);
-    __syncthreads();
+    __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
   }
+#undef CUM_GLDS
 
   // ---- epilogue: lane holds D[n = nb + 4g + j][m = mb + r], j = 0..3 -> 4 consecutive channels of row m
   T *out = static_cast<T *>(p.out);
@@ -325,7 +328,8 @@ __global__ void colsum_stage2(const float *__restrict__ part, int nparts, int n,
 
 template <typename T>
 static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), block(256);
+  const int NB = (p.N + BN - 1) / BN, MB = (p.M + BM - 1) / BM;
+  dim3 grid(8 * NB * ((MB + 7) / 8)), block(256);
   switch (epi) {
     case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, st, p); break;
     case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU>), grid, block, 0, st, p); break;

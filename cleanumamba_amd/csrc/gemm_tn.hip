@@ -50,7 +50,7 @@ struct TnCfg<float> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_kernel(const TnParams p) {
   constexpr int EPC = TnCfg<T>::EPC, BMK = TnCfg<T>::BMK;
   constexpr int CPR = TN_T / EPC;          // 16-byte chunks per tile row: 16 (bf16) / 32 (f32)
   constexpr int NCH = BMK * CPR / 256;     // chunks per thread per operand: 2 (bf16: 512) / 2 (f32: 512)

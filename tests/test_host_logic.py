@@ -105,3 +105,33 @@ def test_lr_schedule_matches_reference_formula():
     assert abs(lrs[49] - 1e-4) < 1e-12
     assert abs(lrs[-1] - 4e-10) < 1e-12
     assert lrs[500] < lrs[100]
+
+
+def test_integration_recipe_aliases_reference_import_paths():
+    """The sys.modules recipe of INTEGRATION.md makes the reference's own import lines resolve to this package."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, cleanumamba_amd.network, cleanumamba_amd.network.network, cleanumamba_amd.network.CleanUMamba
+import cleanumamba_amd.network.layers, cleanumamba_amd.mamba_ssm as _m, cleanumamba_amd.causal_conv1d as _c
+import cleanumamba_amd.mamba_ssm.models.mixer_seq_simple, cleanumamba_amd.mamba_ssm.utils.generation
+import cleanumamba_amd.mamba_ssm.modules.mamba_simple, cleanumamba_amd.mamba_ssm.ops.selective_scan_interface
+for name in ("network", "network.network", "network.CleanUMamba", "network.layers"):
+    sys.modules["src." + name] = sys.modules["cleanumamba_amd." + name]
+for name, mod in list(sys.modules.items()):
+    if name.startswith("cleanumamba_amd.mamba_ssm"):
+        sys.modules[name.replace("cleanumamba_amd.", "", 1)] = mod
+sys.modules["causal_conv1d"] = _c
+from src.network.network import Net
+from src.network.layers import Activation
+from mamba_ssm.models.mixer_seq_simple import create_block, _init_weights
+from mamba_ssm.utils.generation import InferenceParams
+from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+from causal_conv1d import causal_conv1d_fn, causal_conv1d_update
+net = Net("CleanUMamba", dict(channels_H=8, max_H=16, encoder_n_layers=3, tsfm_d_model=16, tsfm_d_inner=32, tsfm_n_head=2))
+assert type(net.tsfm_Mamba_layers[0].mixer).__name__ == "Mamba"
+print("ok")
+'''
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

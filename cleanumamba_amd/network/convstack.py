@@ -4,8 +4,8 @@ Host side of the "convolution as GEMM" design (DESIGN.md "conv stack").  It read
 SAME parameters as the reference's modules -- encoder[i][0] Conv1d(k4,s2), encoder[i][2]
 Conv1d(1x1), decoder[j][0] Conv1d(1x1), decoder[j][2] ConvTranspose1d(k4,s2)
 (src/network/CleanUMamba.py:108-113, 121-130) -- re-packs them into GEMM operands and runs
-every layer forward and backward through ``cum_gemm_nt``; the weight-gradient products
-(plain transposed GEMMs with no fusion) go to the BLAS library via torch.matmul.
+every layer forward and backward-data through ``cum_gemm_nt`` and every weight/bias gradient
+through ``cum_gemm_tn``.
 
 Activation layout ("rows"): a 2-D tensor [1 + B*(T+2) + slack, Cp]; Cp = channels rounded
 up to 8; row 0 is a zero row, then per clip T real rows followed by 2 zero rows; the slack
@@ -113,30 +113,135 @@ def colsum(X, x_off, ld, M, n):
 
 
 # ------------------------------------------------------------------ weight packing
-def glu_perm(H, device):
-    """Row order of the GLU-packed weight: per 32 rows, 16 a-rows (channels 16g..16g+15) then their b-rows.
-    Returns (index into the 2H rows or -1 for padding, number of groups)."""
+# Every packed operand is "gather from [flattened parameter, 0]".  The gather index depends only on shapes,
+# so it is built once on the host (by running the layout code below on element ids) and cached; at run time
+# a pack is one pad/cast kernel + one index_select, with no host synchronisation.
+_INDEX_CACHE = {}
+
+
+def _ids(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return torch.arange(1, n + 1, dtype=torch.int64).view(shape)      # 0 is reserved for "zero padding"
+
+
+def take(src, key, build, dtype=None):
+    """out = [src.flatten(), 0][index].view(shape); ``build()`` returns the id layout (0 = padding)."""
+    ent = _INDEX_CACHE.get((key, src.device))
+    if ent is None:
+        ids = build()
+        idx = ids.reshape(-1) - 1
+        idx[idx < 0] = src.numel()
+        ent = (idx.to(src.device), tuple(ids.shape))
+        _INDEX_CACHE[(key, src.device)] = ent
+    idx, shape = ent
+    flat = src.reshape(-1)
+    if dtype is not None and flat.dtype != dtype:
+        flat = flat.to(dtype)
+    return torch.nn.functional.pad(flat, (0, 1)).index_select(0, idx).view(shape)
+
+
+def _invert(packed_ids, param_shape):
+    """packed_ids: id layout of a packed tensor (values = 1-based parameter element ids, 0 = padding).
+    Returns the id layout that gathers the parameter back out of the packed tensor."""
+    flat = packed_ids.reshape(-1)
+    n = 1
+    for d in param_shape:
+        n *= d
+    out = torch.zeros(n, dtype=torch.int64)
+    pos = torch.arange(1, flat.numel() + 1, dtype=torch.int64)
+    m = flat > 0
+    out[flat[m] - 1] = pos[m]
+    return out.view(param_shape)
+
+
+def _zeros(rows, cols):
+    return torch.zeros(rows, cols, dtype=torch.int64)
+
+
+def lay_conv_fwd(wshape, cp_in, rows, cols):
+    """Conv1d(k4,s2) weight (H, Cin, 4) -> [rows][cols], element (h, kk*cp_in + c)."""
+    H, Cin, _ = wshape
+    out = _zeros(rows, cols)
+    out[:H, :4 * cp_in].view(H, 4, cp_in)[:, :, :Cin] = _ids(wshape).permute(0, 2, 1)
+    return out
+
+
+def lay_conv_dgrad(wshape, cp_in, cp_out, rows, cols):
+    """Conv1d(k4,s2) weight -> transposed-conv form [(j, c)][(half, h)]: half 0 <-> tap j+2, half 1 <-> tap j."""
+    H, Cin, _ = wshape
+    out = _zeros(rows, cols)
+    wv = out[:2 * cp_in, :2 * cp_out].view(2, cp_in, 2, cp_out)
+    wt = _ids(wshape).permute(2, 1, 0)                                   # [kk][c][h]
+    wv[0, :Cin, 0, :H], wv[0, :Cin, 1, :H] = wt[2], wt[0]
+    wv[1, :Cin, 0, :H], wv[1, :Cin, 1, :H] = wt[3], wt[1]
+    return out
+
+
+def lay_convt_fwd(wshape, cp_in, cp_out, rows, cols):
+    """ConvTranspose1d(k4,s2) weight (Cin, Cout, 4) -> [(j, co)][(half, c)]."""
+    Cin, Cout, _ = wshape
+    out = _zeros(rows, cols)
+    wv = out[:2 * cp_out, :2 * cp_in].view(2, cp_out, 2, cp_in)
+    wt = _ids(wshape).permute(2, 1, 0)                                   # [kk][co][c]
+    wv[0, :Cout, 0, :Cin], wv[0, :Cout, 1, :Cin] = wt[2], wt[0]
+    wv[1, :Cout, 0, :Cin], wv[1, :Cout, 1, :Cin] = wt[3], wt[1]
+    return out
+
+
+def lay_convt_dgrad(wshape, cp_out, rows, cols):
+    """ConvTranspose1d weight -> strided-conv form [c][kk*cp_out + co]."""
+    Cin, Cout, _ = wshape
+    out = _zeros(rows, cols)
+    out[:Cin, :4 * cp_out].view(Cin, 4, cp_out)[:, :, :Cout] = _ids(wshape).permute(0, 2, 1)
+    return out
+
+
+def glu_rows(H):
+    """Row order of a GLU-packed matrix: per 32 rows, 16 a-rows (channels 16g..16g+15) then their 16 b-rows.
+    Returns (row -> source row in the (2H, .) weight or -1, number of groups)."""
     G = (H + 15) // 16
-    idx = torch.full((G * 32,), -1, dtype=torch.long, device=device)
-    ch = torch.arange(H, device=device)
+    idx = torch.full((G * 32,), -1, dtype=torch.long)
+    ch = torch.arange(H)
     g, c = ch // 16, ch % 16
     idx[g * 32 + c] = ch
     idx[g * 32 + 16 + c] = H + ch
     return idx, G
 
 
-def pack_rows(w2d, idx, Kp, dtype):
-    """out[i] = w2d[idx[i]] (zero where idx < 0), K padded to Kp."""
-    out = torch.zeros(idx.shape[0], Kp, dtype=dtype, device=w2d.device)
+def lay_glu_fwd(wshape, rows, cols):
+    """1x1 GLU weight (2H, Cin, 1) -> [G*32 packed rows][cols]."""
+    H2, Cin, _ = wshape
+    idx, _ = glu_rows(H2 // 2)
+    out = _zeros(rows, cols)
     ok = idx >= 0
-    out[ok, :w2d.shape[1]] = w2d[idx[ok]].to(dtype)
+    out[:idx.numel()][ok, :Cin] = _ids((H2, Cin))[idx[ok]]
     return out
 
 
-def unpack_rows(gp, idx, n_rows, n_cols):
-    out = torch.zeros(n_rows, n_cols, dtype=torch.float32, device=gp.device)
+def lay_glu_vec(H2):
+    idx, G = glu_rows(H2 // 2)
+    out = torch.zeros(G * 32, dtype=torch.int64)
     ok = idx >= 0
-    out[idx[ok]] = gp[ok, :n_cols].float()
+    out[ok] = _ids((H2,))[idx[ok]]
+    return out
+
+
+def lay_plain(wshape, rows, cols, transpose=False):
+    Cout, Cin, _ = wshape
+    out = _zeros(rows, cols)
+    ids = _ids((Cout, Cin))
+    if transpose:
+        out[:Cin, :Cout] = ids.t()
+    else:
+        out[:Cout, :Cin] = ids
+    return out
+
+
+def lay_vec(n, rows):
+    out = torch.zeros(rows, dtype=torch.int64)
+    out[:n] = _ids((n,))
     return out
 
 
@@ -149,10 +254,10 @@ class ConvK4S2ReLU(torch.autograd.Function):
         dt, dev = xbuf.dtype, xbuf.device
         H, Cin, Kw = w.shape
         assert Kw == 4 and gi.P == 2 * go.P and gi.C == Cin and go.C == H
-        K = 4 * gi.Cp
-        wp = torch.zeros(rup(H, 16), rup(K, bk_of(dt)), dtype=dt, device=dev)
-        wp[:H, :K].view(H, 4, gi.Cp)[:, :, :Cin] = w.permute(0, 2, 1).to(dt)
-        bp = _padv(b, wp.shape[0])
+        Np, Kp = rup(H, 16), rup(4 * gi.Cp, bk_of(dt))
+        sh = tuple(w.shape)
+        wp = take(w, ("conv_fwd", sh, gi.Cp, Np, Kp), lambda: lay_conv_fwd(sh, gi.Cp, Np, Kp), dt)
+        bp = take(b, ("vec", H, Np), lambda: lay_vec(H, Np), torch.float32)
         ybuf = go.new(dt, dev)
         gemm(xbuf, gi.Cp, 2 * gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_RELU, go.Cp)
         ctx.gi, ctx.go = gi, go
@@ -174,16 +279,14 @@ class ConvK4S2ReLU(torch.autograd.Function):
         # weight + bias gradient in one launch: X row m = the 4*Cp contiguous inputs of output row m
         dwp, dbp = wgrad(dz, go.Cp, go.Cp, go.Cp, xbuf, gi.Cp, 2 * gi.Cp, 4 * gi.Cp, go.M)
         db = dbp[:H]
-        dw = dwp[:H].view(H, 4, gi.Cp)[:, :, :Cin].permute(0, 2, 1).contiguous()
+        sh = tuple(w.shape)
+        dw = take(dwp, ("conv_unpack", sh, gi.Cp, go.Cp),
+                  lambda: _invert(lay_conv_fwd(sh, gi.Cp, go.Cp, 4 * gi.Cp), sh))
         dx = None
         if ctx.needs_input_grad[0]:
             # data gradient = transposed conv: pair row t' of dx reads dz rows t'-1, t'
-            K = 2 * go.Cp
-            wd = torch.zeros(rup(2 * gi.Cp, 16), rup(K, bk_of(dt)), dtype=dt, device=dev)
-            wv = wd[:2 * gi.Cp, :K].view(2, gi.Cp, 2, go.Cp)           # [j][c][half][h]
-            wt = w.to(dt).permute(2, 1, 0)                              # [kk][c][h]
-            wv[0, :Cin, 0, :H], wv[0, :Cin, 1, :H] = wt[2], wt[0]
-            wv[1, :Cin, 0, :H], wv[1, :Cin, 1, :H] = wt[3], wt[1]
+            Nd, Kd = rup(2 * gi.Cp, 16), rup(2 * go.Cp, bk_of(dt))
+            wd = take(w, ("conv_dgrad", sh, gi.Cp, go.Cp, Nd, Kd), lambda: lay_conv_dgrad(sh, gi.Cp, go.Cp, Nd, Kd), dt)
             dx = gi.new(dt, dev)
             gemm(dz, 0, go.Cp, wd, None, dx, gi.Cp, 2 * gi.Cp, go.M, go.P, go.T + 1, hip.EPI_BIAS, 2 * gi.Cp)
         return dx, dw.to(w.dtype), db.to(w.dtype), None, None
@@ -198,21 +301,22 @@ class PointwiseGLU(torch.autograd.Function):
         H2, Cin, _ = w.shape
         H = H2 // 2
         assert gi.T == go.T and go.C == H and gi.C == Cin
-        idx, G = glu_perm(H, dev)
-        wp = pack_rows(w[:, :, 0], idx, rup(gi.Cp, bk_of(dt)), dt)
-        bp = torch.zeros(G * 32, dtype=torch.float32, device=dev)
-        bp[idx >= 0] = b.float()[idx[idx >= 0]]
+        G = (H + 15) // 16
+        Kp = rup(gi.Cp, bk_of(dt))
+        sh = tuple(w.shape)
+        wp = take(w, ("glu_fwd", sh, G * 32, Kp), lambda: lay_glu_fwd(sh, G * 32, Kp), dt)
+        bp = take(b, ("glu_vec", H2), lambda: lay_glu_vec(H2), torch.float32)
         ybuf = go.new(dt, dev)
         z = torch.empty(go.M, G * 32, dtype=dt, device=dev) if save_z else None
         gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_GLU, go.Cp,
              aux=z, x_off=0, ldz=G * 32)
         ctx.gi, ctx.go, ctx.G = gi, go, G
-        ctx.save_for_backward(xbuf, w, z, idx)
+        ctx.save_for_backward(xbuf, w, z)
         return ybuf
 
     @staticmethod
     def backward(ctx, dy):
-        xbuf, w, z, idx = ctx.saved_tensors
+        xbuf, w, z = ctx.saved_tensors
         if z is None:
             raise RuntimeError("PointwiseGLU was run without save_z; backward is unavailable")
         gi, go, G = ctx.gi, ctx.go, ctx.G
@@ -224,14 +328,14 @@ class PointwiseGLU(torch.autograd.Function):
             hip.check(hip.lib().cum_glu_bwd(hip.dtype_code(dt), go.M, G, go.Cp, hip.ptr(z), G * 32, hip.ptr(dy[1:]),
                                             go.Cp, hip.ptr(dz), hip.stream_ptr()))
         dwp, dbp = wgrad(dz, 0, G * 32, G * 32, xbuf, gi.Cp, gi.Cp, gi.Cp, go.M)
-        ok = idx >= 0
-        db = torch.zeros(H2, dtype=torch.float32, device=dev)
-        db[idx[ok]] = dbp[ok]
-        dw = unpack_rows(dwp, idx, H2, Cin).unsqueeze(-1)
+        sh = tuple(w.shape)
+        db = take(dbp, ("glu_vec_unpack", H2), lambda: _invert(lay_glu_vec(H2), (H2,)))
+        dw = take(dwp, ("glu_unpack", sh, G * 32, gi.Cp), lambda: _invert(lay_glu_fwd(sh, G * 32, gi.Cp), sh))
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = torch.zeros(rup(gi.Cp, 16), rup(G * 32, bk_of(dt)), dtype=dt, device=dev)
-            wt[:Cin, :G * 32][:, ok] = w[:, :, 0].to(dt)[idx[ok]].t()
+            Nd, Kd = rup(gi.Cp, 16), rup(G * 32, bk_of(dt))
+            wt = take(w, ("glu_dgrad", sh, Nd, Kd),
+                      lambda: torch.nn.functional.pad(lay_glu_fwd(sh, G * 32, Nd).t(), (0, Kd - G * 32)), dt)
             dx = gi.new(dt, dev)
             gemm(dz, 0, G * 32, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
         return dx, dw.to(w.dtype), db.to(w.dtype), None, None, None
@@ -245,15 +349,16 @@ class ConvT4S2(torch.autograd.Function):
         dt, dev = xbuf.dtype, xbuf.device
         Cin, Cout, Kw = w.shape
         assert Kw == 4 and go.P == 2 * gi.P and gi.C == Cin and go.C == Cout
-        K = 2 * gi.Cp
         N = 2 * go.Cp
-        wp = torch.zeros(rup(N, 16), rup(K, bk_of(dt)), dtype=dt, device=dev)
-        wv = wp[:N, :K].view(2, go.Cp, 2, gi.Cp)                       # [j][co][half][c]
-        wt = w.to(dt).permute(2, 1, 0)                                  # [kk][co][c]
-        wv[0, :Cout, 0, :Cin], wv[0, :Cout, 1, :Cin] = wt[2], wt[0]
-        wv[1, :Cout, 0, :Cin], wv[1, :Cout, 1, :Cin] = wt[3], wt[1]
-        bp = torch.zeros(wp.shape[0], dtype=torch.float32, device=dev)
-        bp[:N].view(2, go.Cp)[:, :Cout] = b.float()
+        Np, Kp = rup(N, 16), rup(2 * gi.Cp, bk_of(dt))
+        sh = tuple(w.shape)
+        wp = take(w, ("convt_fwd", sh, gi.Cp, go.Cp, Np, Kp), lambda: lay_convt_fwd(sh, gi.Cp, go.Cp, Np, Kp), dt)
+
+        def bias_layout():
+            out = torch.zeros(Np, dtype=torch.int64)
+            out[:N].view(2, go.Cp)[:, :Cout] = _ids((Cout,))
+            return out
+        bp = take(b, ("convt_vec", Cout, go.Cp, Np), bias_layout, torch.float32)
         ybuf = go.new(dt, dev)
         keep = relu and skip is not None            # the ReLU mask is not recoverable from y + skip
         act = go.new(dt, dev) if keep else None
@@ -281,14 +386,14 @@ class ConvT4S2(torch.autograd.Function):
         # weight + bias gradient: pair rows of dz against the 2*Cp contiguous inputs (rows m-1, m) of x
         dwp, dbp = wgrad(dz, go.Cp, 2 * go.Cp, 2 * go.Cp, xbuf, 0, gi.Cp, 2 * gi.Cp, gi.M)
         db = (dbp[:go.Cp] + dbp[go.Cp:])[:Cout]
-        dv = dwp.view(2, go.Cp, 2, gi.Cp)[:, :Cout, :, :Cin]                            # [j][co][half][c]
-        dw = torch.stack([dv[0, :, 1], dv[1, :, 1], dv[0, :, 0], dv[1, :, 0]], dim=0).permute(2, 1, 0).contiguous()
+        sh = tuple(w.shape)
+        dw = take(dwp, ("convt_unpack", sh, gi.Cp, go.Cp),
+                  lambda: _invert(lay_convt_fwd(sh, gi.Cp, go.Cp, 2 * go.Cp, 2 * gi.Cp), sh))
         dx = None
         if ctx.needs_input_grad[0]:
             # data gradient = strided conv of dz: row t reads dz rows 2t..2t+3
-            K = 4 * go.Cp
-            wc = torch.zeros(rup(gi.Cp, 16), rup(K, bk_of(dt)), dtype=dt, device=dev)
-            wc[:Cin, :K].view(Cin, 4, go.Cp)[:, :, :Cout] = w.to(dt).permute(0, 2, 1)
+            Nd, Kd = rup(gi.Cp, 16), rup(4 * go.Cp, bk_of(dt))
+            wc = take(w, ("convt_dgrad", sh, go.Cp, Nd, Kd), lambda: lay_convt_dgrad(sh, go.Cp, Nd, Kd), dt)
             dx = gi.new(dt, dev)
             gemm(dz, go.Cp, 2 * go.Cp, wc, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
         return dx, dw.to(w.dtype), db.to(w.dtype), dskip, None, None, None
@@ -302,8 +407,10 @@ class Pointwise(torch.autograd.Function):
         dt, dev = xbuf.dtype, xbuf.device
         Cout, Cin, _ = w.shape
         assert gi.T == go.T and gi.C == Cin and go.C == Cout
-        wp = _pad2(w[:, :, 0].to(dt), rup(Cout, 16), rup(gi.Cp, bk_of(dt)))
-        bp = _padv(b, wp.shape[0])
+        Np, Kp = rup(Cout, 16), rup(gi.Cp, bk_of(dt))
+        sh = tuple(w.shape)
+        wp = take(w, ("plain_fwd", sh, Np, Kp), lambda: lay_plain(sh, Np, Kp), dt)
+        bp = take(b, ("vec", Cout, Np), lambda: lay_vec(Cout, Np), torch.float32)
         ybuf = go.new(dt, dev)
         gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_BIAS, go.Cp,
              res=skip, r_off=go.Cp, ldr=go.Cp)
@@ -323,7 +430,9 @@ class Pointwise(torch.autograd.Function):
         dw = dwp[:Cout, :Cin].unsqueeze(-1)
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = _pad2(w[:, :, 0].to(dt).t(), rup(gi.Cp, 16), rup(go.Cp, bk_of(dt)))
+            Nd, Kd = rup(gi.Cp, 16), rup(go.Cp, bk_of(dt))
+            sh = tuple(w.shape)
+            wt = take(w, ("plain_dgrad", sh, Nd, Kd), lambda: lay_plain(sh, Nd, Kd, transpose=True), dt)
             dx = gi.new(dt, dev)
             gemm(dy, go.Cp, go.Cp, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
         return dx, dw.to(w.dtype), db.to(w.dtype), (dy if ctx.has_skip else None), None, None

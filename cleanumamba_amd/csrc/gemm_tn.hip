@@ -33,7 +33,7 @@ struct TnParams {
   int64_t M;
   int N, K;          // valid columns of dZ / of an X row (multiples of 4)
   int Np, Kp;        // slab dims (multiples of 128)
-  int rows_per_split;
+  int rows_per_split, nsplit;
 };
 
 constexpr int TN_T = 128;  // output tile (n and k)
@@ -42,78 +42,63 @@ template <typename T>
 struct TnCfg;
 template <>
 struct TnCfg<__bf16> {
-  static constexpr int EPC = 8, BMK = 32;
+  static constexpr int EPC = 8, BMK = 64;   // 64 rows per step = two 32-deep MFMA reductions
+  // 16-byte chunk swizzle (in chunks): consecutive rows, and rows 8 apart, land in different 32-byte slots so the
+  // 4-row x 32-byte blocks fetched by ds_read_b64_tr_b16 do not collide; XOR with an even number keeps each
+  // 32-byte block (two chunks) together.
+  static __device__ __forceinline__ int swz(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 };
 template <>
 struct TnCfg<float> {
-  static constexpr int EPC = 4, BMK = 16;
+  static constexpr int EPC = 4, BMK = 32;
+  static __device__ __forceinline__ int swz(int row) { return 4 * (row & 7); }  // 64-byte shifts
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_kernel(const TnParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_tn_kernel(const TnParams p) {
   constexpr int EPC = TnCfg<T>::EPC, BMK = TnCfg<T>::BMK;
   constexpr int CPR = TN_T / EPC;          // 16-byte chunks per tile row: 16 (bf16) / 32 (f32)
-  constexpr int NCH = BMK * CPR / 256;     // chunks per thread per operand: 2 (bf16: 512) / 2 (f32: 512)
-  constexpr int RS = TN_T * sizeof(T) + 16;  // LDS row stride in bytes (+16 B pad breaks the power-of-two stride)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BMK * RS];  // [stage][0: dZ, 1: X]
+  constexpr int NCH = BMK * CPR / 256;     // chunks per thread per operand: 4
+  __shared__ uint4 lds[2][BMK * CPR];      // [0: dZ, 1: X][row * CPR + physical chunk]; 32 KB, single-buffered
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = uniform(wave);
   const int wk = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * TN_T, k0 = blockIdx.y * TN_T, sp = blockIdx.z;
+  // XCD-aware order (ids b and b+8 share an XCD / L2): all (n, k) tiles of one row split run back to back on one
+  // XCD, so its dZ and X rows come from HBM once and are re-read from that L2 by the other tiles.
+  const int ntn = p.Np / TN_T, ntk = p.Kp / TN_T, tiles = ntn * ntk;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int sp = (local / tiles) * 8 + xcd;
+  if (sp >= p.nsplit) return;
+  const int tile = local % tiles;
+  const int n0 = (tile % ntn) * TN_T, k0 = (tile / ntn) * TN_T;
   const int64_t m_begin = (int64_t)sp * p.rows_per_split;
   int64_t m_end = m_begin + p.rows_per_split;
   m_end = m_end < p.M ? m_end : p.M;
   const T *dZ = static_cast<const T *>(p.dZ);
   const T *X = static_cast<const T *>(p.X);
-  const bool do_bias = p.bslab != nullptr && blockIdx.y == 0;
+  const bool do_bias = p.bslab != nullptr && k0 == 0;
 
-  // staging: chunk c = tid + 256*i -> row c / CPR, column chunk c % CPR (the same for every i)
-  const int cc = tid % CPR;
-  int zcol = n0 + cc * EPC, xcol = k0 + cc * EPC;
-  const bool zok = zcol < p.N, xok = xcol < p.K;
-  zcol = zok ? zcol : 0;
-  xcol = xok ? xcol : 0;
-  uint4 rz[NCH], rx[NCH];
+  // HBM -> LDS directly: the thread's i-th DMA lands at linear chunk position i*256 + tid = (row, physical chunk);
+  // it fetches the LOGICAL chunk (physical ^ swz(row)) so that reads can use the swizzled address.
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+  int lrow[NCH], zoff[NCH], xoff[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int pos = i * 256 + tid;
+    lrow[i] = pos / CPR;
+    const int clog = (pos % CPR) ^ TnCfg<T>::swz(lrow[i]);
+    const int zc = n0 + clog * EPC, xc = k0 + clog * EPC;
+    zoff[i] = zc < p.N ? zc : 0;   // columns past the edge fetch valid memory; their products land in slab
+    xoff[i] = xc < p.K ? xc : 0;   // columns that are never read
+  }
+  // column sums for the bias gradient: this thread owns logical chunk (tid % CPR) of rows tid / CPR + 256/CPR * i
+  const int bc = tid % CPR;
   float bsum[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) bsum[e] = 0.f;
-
-  auto gload = [&](int64_t mb) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int row = (tid + 256 * i) / CPR;
-      const int64_t m = mb + row;
-      const bool ok = m < m_end;
-      const int64_t mc = ok ? m : m_end - 1;
-      uint4 vz = *reinterpret_cast<const uint4 *>(dZ + mc * p.ldz + zcol);
-      uint4 vx = *reinterpret_cast<const uint4 *>(X + mc * p.ldx + xcol);
-      if (!(ok && zok)) vz = make_uint4(0, 0, 0, 0);
-      if (!(ok && xok)) vx = make_uint4(0, 0, 0, 0);
-      rz[i] = vz;
-      rx[i] = vx;
-    }
-  };
-  auto lstore = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int row = (tid + 256 * i) / CPR;
-      *reinterpret_cast<uint4 *>(&lds[st][0][row * RS + cc * 16]) = rz[i];
-      *reinterpret_cast<uint4 *>(&lds[st][1][row * RS + cc * 16]) = rx[i];
-      if (do_bias) {
-        if constexpr (sizeof(T) == 2) {
-          const bf16x8 v = __builtin_bit_cast(bf16x8, rz[i]);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
-        } else {
-          bsum[0] += __builtin_bit_cast(float, rz[i].x);
-          bsum[1] += __builtin_bit_cast(float, rz[i].y);
-          bsum[2] += __builtin_bit_cast(float, rz[i].z);
-          bsum[3] += __builtin_bit_cast(float, rz[i].w);
-        }
-      }
-    }
-  };
 
   f32x4 acc[4][4];  // [ki][ni]: D[i = k][j = n]
 #pragma unroll
@@ -122,45 +107,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int64_t nsteps = (m_end - m_begin + BMK - 1) / BMK;
-  if (nsteps > 0) {
-    gload(m_begin);
-    lstore(0);
-  }
-  __syncthreads();
   for (int64_t s = 0; s < nsteps; ++s) {
-    const int st = s & 1;
-    if (s + 1 < nsteps) gload(m_begin + (s + 1) * BMK);
-    if constexpr (sizeof(T) == 2) {
-      // transposing reads: the 16 lanes of group g fetch a [4 rows][16 cols] block; lane (q, p) = (r>>2, r&3)
-      // addresses row q, cols 4p..4p+3 and receives column r of the 4 rows
-      const int q = r >> 2, pp = r & 3;
-      bf16x8 xf[4], zf[4];
+    const int64_t mb = m_begin + s * BMK;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int xc = wk * 64 + i * 16 + 4 * pp, zc = wn * 64 + i * 16 + 4 * pp;
-        bf16x4 lo, hi;
-        typedef __attribute__((address_space(3))) bf16x4 *lp;
-        lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(&lds[st][1][(8 * g + q) * RS + xc * 2]));
-        hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(&lds[st][1][(8 * g + 4 + q) * RS + xc * 2]));
-        xf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(&lds[st][0][(8 * g + q) * RS + zc * 2]));
-        hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(&lds[st][0][(8 * g + 4 + q) * RS + zc * 2]));
-        zf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    for (int i = 0; i < NCH; ++i) {
+      int64_t m = mb + lrow[i];
+      m = m < m_end ? m : m_end - 1;
+      __builtin_amdgcn_global_load_lds((glb_ptr)(dZ + m * p.ldz + zoff[i]), (lds_ptr)(&lds[0][i * 256 + wave_u * 64]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(X + m * p.ldx + xoff[i]), (lds_ptr)(&lds[1][i * 256 + wave_u * 64]), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (mb + BMK > m_end) {  // ragged last step: rows past the end must contribute nothing
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (mb + lrow[i] >= m_end) {
+          lds[0][i * 256 + tid] = make_uint4(0, 0, 0, 0);
+          lds[1][i * 256 + tid] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int row = tid / CPR + (256 / CPR) * i;
+        const uint4 v = lds[0][row * CPR + (bc ^ TnCfg<T>::swz(row))];
+        if constexpr (sizeof(T) == 2) {
+          const bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[e] += (float)h[e];
+        } else {
+          bsum[0] += __builtin_bit_cast(float, v.x);
+          bsum[1] += __builtin_bit_cast(float, v.y);
+          bsum[2] += __builtin_bit_cast(float, v.z);
+          bsum[3] += __builtin_bit_cast(float, v.w);
+        }
       }
+    }
+    const unsigned char *lz = reinterpret_cast<const unsigned char *>(&lds[0][0]);
+    const unsigned char *lx = reinterpret_cast<const unsigned char *>(&lds[1][0]);
+    if constexpr (sizeof(T) == 2) {
+      // transposing reads: the 16 lanes of group g fetch a [4 rows][16 cols] block; lane (q, pp) = (r>>2, r&3)
+      // addresses row q, cols 4pp..4pp+3 and receives column r of the 4 rows
+      const int q = r >> 2, pp = r & 3;
+      typedef __attribute__((address_space(3))) bf16x4 *lp;
 #pragma unroll
-      for (int ki = 0; ki < 4; ++ki)
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 xf[4], zf[4];
+        const int r0 = 32 * kk + 8 * g + q, r1 = r0 + 4;
+        const int s0 = TnCfg<T>::swz(r0), s1 = TnCfg<T>::swz(r1);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ki], zf[ni], acc[ki][ni], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          const int xch = (wk * 64 + i * 16) / 8, zch = (wn * 64 + i * 16) / 8;   // even chunk index of the 16-col block
+          bf16x4 lo, hi;
+          lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lx + (r0 * CPR + (xch ^ s0)) * 16 + pp * 8));
+          hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lx + (r1 * CPR + (xch ^ s1)) * 16 + pp * 8));
+          xf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lz + (r0 * CPR + (zch ^ s0)) * 16 + pp * 8));
+          hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lz + (r1 * CPR + (zch ^ s1)) * 16 + pp * 8));
+          zf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ki], zf[ni], acc[ki][ni], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int ss = 0; ss < BMK / 4; ++ss) {
         float xf[4], zf[4];
         const int row = 4 * ss + g;
+        const int sw = TnCfg<T>::swz(row);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          xf[i] = *reinterpret_cast<const float *>(&lds[st][1][row * RS + (wk * 64 + i * 16 + r) * 4]);
-          zf[i] = *reinterpret_cast<const float *>(&lds[st][0][row * RS + (wn * 64 + i * 16 + r) * 4]);
+          const int xcol = wk * 64 + i * 16 + r, zcol = wn * 64 + i * 16 + r;
+          xf[i] = *reinterpret_cast<const float *>(lx + (row * CPR + ((xcol >> 2) ^ sw)) * 16 + (xcol & 3) * 4);
+          zf[i] = *reinterpret_cast<const float *>(lz + (row * CPR + ((zcol >> 2) ^ sw)) * 16 + (zcol & 3) * 4);
         }
 #pragma unroll
         for (int ki = 0; ki < 4; ++ki)
@@ -169,8 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[ki], zf[ni], acc[ki][ni], 0, 0, 0);
       }
     }
-    if (s + 1 < nsteps) lstore(st ^ 1);
-    __syncthreads();
+    __syncthreads();  // all reads done before the next step's DMA overwrites the tiles
   }
 
   // ---- slab store: lane holds D[k = kb + 4g + j][n = nb + r]
@@ -187,38 +208,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // ---- bias gradient: threads with the same column chunk (tid % CPR) hold partial sums
   if (do_bias) {
-    __syncthreads();
-    float *red = reinterpret_cast<float *>(&lds[0][0][0]);  // [256 / CPR][128]
+    float *red = reinterpret_cast<float *>(&lds[0][0]);  // [256 / CPR][128]
     const int tr = tid / CPR;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) red[tr * TN_T + cc * EPC + e] = bsum[e];
+    for (int e = 0; e < EPC; ++e) red[tr * TN_T + bc * EPC + e] = bsum[e];
     __syncthreads();
     if (tid < TN_T) {
-      float s = 0.f;
-      for (int j = 0; j < 256 / CPR; ++j) s += red[j * TN_T + tid];
-      p.bslab[(int64_t)sp * p.Np + n0 + tid] = s;
+      float sum = 0.f;
+      for (int j = 0; j < 256 / CPR; ++j) sum += red[j * TN_T + tid];
+      p.bslab[(int64_t)sp * p.Np + n0 + tid] = sum;
     }
   }
 }
 
-// out[n][k] = sum_s slab[s][n][k] for n < N, k < K; bias likewise.
-__global__ void tn_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ bslab, int S, int Np, int Kp,
-                                 int N, int K, float *__restrict__ out, int64_t ldo, float *__restrict__ bout) {
-  const int64_t total = (int64_t)N * (K / 4);
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < total) {
-    const int n = i / (K / 4), k = (i % (K / 4)) * 4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sp = 0; sp < S; ++sp) {
-      const float4 v = *reinterpret_cast<const float4 *>(slab + ((int64_t)sp * Np + n) * Kp + k);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+// Slab reduction, parallel over outputs AND over slabs, fixed summation order (deterministic).
+//   in : [S][rows][ld_in] f32        out: [gridDim.y][rows][ld_out] partial sums of S / gridDim.y slabs each
+// A workgroup = 64 float4 outputs x 4 slab lanes; lanes are combined through LDS.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ in, int S, int64_t in_slab, int ld_in,
+                                                        int rows, int cols4, float *__restrict__ out, int64_t out_slab,
+                                                        int64_t ld_out) {
+  __shared__ float4 red[4][64];
+  const int v = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;
+  const int chunks = gridDim.y, ch = blockIdx.y;
+  const int per = (S + chunks - 1) / chunks;
+  const int s0 = ch * per;
+  int s1 = s0 + per;
+  s1 = s1 < S ? s1 : S;
+  const int64_t total = (int64_t)rows * cols4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  int n = 0, k = 0;
+  if (v < total) {
+    n = v / cols4;
+    k = (v % cols4) * 4;
+    const float *base = in + (int64_t)n * ld_in + k;
+    int s = s0 + sl;
+    for (; s + 4 < s1; s += 8) {  // two independent chains keep two loads in flight
+      const float4 x = *reinterpret_cast<const float4 *>(base + (int64_t)s * in_slab);
+      const float4 y = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 4) * in_slab);
+      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+      b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
     }
-    *reinterpret_cast<float4 *>(out + (int64_t)n * ldo + k) = s;
+    for (; s < s1; s += 4) {
+      const float4 x = *reinterpret_cast<const float4 *>(base + (int64_t)s * in_slab);
+      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    }
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
   }
-  if (bout && i < N) {
-    float s = 0.f;
-    for (int sp = 0; sp < S; ++sp) s += bslab[(int64_t)sp * Np + i];
-    bout[i] = s;
+  red[sl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (sl == 0 && v < total) {
+    float4 r = red[0][threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      const float4 t = red[j][threadIdx.x];
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    *reinterpret_cast<float4 *>(out + (int64_t)ch * out_slab + (int64_t)n * ld_out + k) = r;
   }
 }
 
@@ -242,10 +288,13 @@ static void tn_plan(int64_t M, int32_t N, int32_t K, int32_t dtype, int *Np, int
   if (*S < 1) *S = 1;
 }
 
+static int reduce_chunks(int S) { return S >= 64 ? 16 : 1; }
+
 extern "C" int64_t cum_gemm_tn_workspace_elems(int32_t dtype, int64_t M, int32_t N, int32_t K) {
   int Np, Kp, S, rps;
   tn_plan(M, N, K, dtype, &Np, &Kp, &S, &rps);
-  return (int64_t)S * Np * Kp + (int64_t)S * Np;
+  const int64_t C = reduce_chunks(S);
+  return (int64_t)S * Np * Kp + (int64_t)S * Np + C * (int64_t)N * K + C * (int64_t)Np;
 }
 
 extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
@@ -268,18 +317,41 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   TnParams p{};
   p.dZ = dZ; p.X = X; p.ldz = ldz; p.ldx = ldx; p.M = M; p.N = N; p.K = K; p.Np = Np; p.Kp = Kp;
   p.rows_per_split = rps;
+  p.nsplit = S;
   p.slab = workspace;
   p.bslab = db ? workspace + (int64_t)S * Np * Kp : nullptr;
-  dim3 grid(Np / TN_T, Kp / TN_T, S), block(256);
+  dim3 grid(8 * (Np / TN_T) * (Kp / TN_T) * ((S + 7) / 8)), block(256);
   if (dtype == CUM_BF16)
     hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, block, 0, st, p);
   else
     hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();
-  const int64_t total = (int64_t)N * (K / 4);
-  const int64_t threads = total > N ? total : N;
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p.slab, p.bslab, S, Np,
-                     Kp, N, K, dW, ldw, db);
+  // combine the slabs: one pass for few slabs, two passes (16 partial sums, then those) for many
+  const int C = reduce_chunks(S);
+  float *part = workspace + (int64_t)S * Np * Kp + (int64_t)S * Np;
+  float *bpart = part + (int64_t)C * N * K;
+  const int cols4 = K / 4;
+  const unsigned gx = (unsigned)(((int64_t)N * cols4 + 63) / 64);
+  if (C == 1) {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, p.slab, S, (int64_t)Np * Kp, Kp, N, cols4, dW, 0,
+                       ldw);
+  } else {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx, C), dim3(256), 0, st, p.slab, S, (int64_t)Np * Kp, Kp, N, cols4, part,
+                       (int64_t)N * K, (int64_t)K);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, part, C, (int64_t)N * K, K, N, cols4, dW, 0, ldw);
+  }
   CUM_CHECK_LAUNCH();
+  if (db) {  // bias slabs are [S][Np]: treat as S x (1 row of Np/4 float4)
+    const int bc4 = N / 4;
+    const unsigned bx = (unsigned)((bc4 + 63) / 64);
+    if (C == 1) {
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, p.bslab, S, (int64_t)Np, Np, 1, bc4, db, 0, N);
+    } else {
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3(bx, C), dim3(256), 0, st, p.bslab, S, (int64_t)Np, Np, 1, bc4, bpart,
+                         (int64_t)Np, (int64_t)Np);
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, bpart, C, (int64_t)Np, Np, 1, bc4, db, 0, N);
+    }
+    CUM_CHECK_LAUNCH();
+  }
   return CUM_OK;
 }

@@ -77,15 +77,15 @@ __device__ __forceinline__ float row16_allsum(float v) {
 // Half / row exchanges.  hipcc (ROCm 7.2) miscompiles the two-result builtins
 // __builtin_amdgcn_permlane{32,16}_swap when both results feed one expression (it reuses
 // result 0 for result 1: `v_permlane32_swap v3, v7; v_add_f32 v3, v3, v3`), so the
-// instruction is emitted directly.  The two v_nop cover the "VALU write -> permlane
+// instruction is emitted directly.  The s_nop 1 covers the "VALU write -> permlane
 // swap read" hazard (2 wait states), which hipcc does not pad inside asm.
 //   swap32(a, b): lanes 32-63 of a  <->  lanes 0-31 of b
 //   swap16(a, b): odd 16-lane rows of a  <->  even rows of b
 __device__ __forceinline__ void swap32(float &a, float &b) {
-  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void swap16(float &a, float &b) {
-  asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
 }  // namespace cum

@@ -96,20 +96,43 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
 
   float accD = 0.f, accBias = 0.f;
 
+  // raw (t, d) rows of the chunk about to be processed; fetched one chunk ahead
+  float ru[K], rdl[K], rz[K], rdo[K];
+  auto load_rows = [&](int c) {
+    const int t0 = c * TB, tlast = L - 1 - t0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int tl = w + k * NW;
+      const int tc = t0 + (tl <= tlast ? tl : tlast);  // clamped address, masked value
+      ru[k] = up[tc * u_sl];
+      rdl[k] = dtp[tc * dt_sl];
+      rz[k] = zp[tc * z_sl];
+      rdo[k] = dop[tc * o_sl];
+    }
+  };
+  load_rows(nchunks - 1);
+
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * TB;
     const int tlast = L - 1 - t0;  // last valid local step of this chunk (>= 0)
+    // state entering the chunk: needed by both halves, requested now so that its latency hides behind phase A
+    float x0[NS];
+    {
+      const float *ck = p.ckpt_in + (((int64_t)b * nchunks + c) * N + n0) * Dm + dc;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int jj = j < nvalid ? j : nvalid - 1;
+        const float v = ck[(int64_t)jj * Dm];
+        x0[j] = (j < nvalid) ? v : 0.f;
+      }
+    }
     float eu[K], ez[K], edo[K], edt[K], esg[K];
     // ---- phase A: per-(t, d) quantities, once, into LDS
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int tl = w + k * NW;
       const bool ok = dok && tl < TB && tl <= tlast;
-      const int tc = t0 + (tl <= tlast ? tl : tlast);  // clamped address, masked value
-      const float uv = up[tc * u_sl];
-      const float dv = dtp[tc * dt_sl];
-      const float zv = zp[tc * z_sl];
-      const float dov = dop[tc * o_sl];
+      const float uv = ru[k], dv = rdl[k], zv = rz[k], dov = rdo[k];
       const float pre = dv + bias;
       float dtv = pre, sg = 1.f;
       if (softplus) {
@@ -126,54 +149,49 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       }
       eu[k] = uv; ez[k] = zv; edo[k] = dov; edt[k] = dtv; esg[k] = sg;
     }
+    if (c > 0) load_rows(c - 1);
     __syncthreads();
 
-    const float *ck = p.ckpt_in + (((int64_t)b * nchunks + c) * N + n0) * Dm + dc;
-    auto load_ckpt = [&](float (&x)[NS]) {
-#pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const int jj = j < nvalid ? j : nvalid - 1;
-        const float v = ck[(int64_t)jj * Dm];
-        x[j] = (j < nvalid) ? v : 0.f;
-      }
+    // Operands of one time step: B_t / C_t slices (SGPRs via s_load) and the per-(t, d) values from LDS.  They are
+    // fetched one step ahead of their use so that neither the scalar-load nor the LDS latency is exposed.
+    struct StepOps {
+      float bv[NS], cv[NS];
+      float dt, du, dy;
+    };
+    auto fetch = [&](int tl, StepOps &o) {
+      const int tc = tl <= tlast ? tl : tlast;
+      load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, o.bv);
+      load_bc<FAST>(opaque(Cw + (t0 + tc) * C_sl), C_sn, nvalid, o.cv);
+      o.dt = s_dt[tl][lane];
+      o.du = s_du[tl][lane];
+      o.dy = s_dy[tl][lane];
     };
     // one recomputed forward step (state only)
-    auto fwd_step = [&](float (&x)[NS], int tl) {
-      const int tc = tl <= tlast ? tl : tlast;
-      float bv[NS];
-      load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, bv);
-      const float dt = s_dt[tl][lane];
-      const float du = s_du[tl][lane];
+    auto fwd_step = [&](float (&x)[NS], const StepOps &o) {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
-        const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
-        x[j] = fmaf(a, x[j], du * bv[j]);
+        const float a = __builtin_amdgcn_exp2f(o.dt * Ap[j]);
+        x[j] = fmaf(a, x[j], o.du * o.bv[j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
     // one reverse step; xp = state before step tl; slot = tl % SUB
-    auto rev_step = [&](const float (&xp)[NS], int tl, int slot) {
-      const int tc = tl <= tlast ? tl : tlast;
-      float bv[NS], cv[NS];
-      load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, bv);
-      load_bc<FAST>(opaque(Cw + (t0 + tc) * C_sl), C_sn, nvalid, cv);
-      const float dt = s_dt[tl][lane];
-      const float du = s_du[tl][lane];
-      const float dy = s_dy[tl][lane];
+    auto rev_step = [&](const float (&xp)[NS], int tl, int slot, const StepOps &o) {
+      const float dt = o.dt, du = o.du, dy = o.dy;
       float p1 = 0.f, p2 = 0.f, yp = 0.f;
       float dBp[NS], dCp[NS];
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
         const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
-        const float xt = fmaf(a, xp[j], du * bv[j]);
-        const float dx = fmaf(cv[j], dy, dxc[j]);
-        yp = fmaf(cv[j], xt, yp);
+        const float xt = fmaf(a, xp[j], du * o.bv[j]);
+        const float dx = fmaf(o.cv[j], dy, dxc[j]);
+        yp = fmaf(o.cv[j], xt, yp);
         dCp[j] = dy * xt;
         dBp[j] = dx * du;
         const float gg = dx * xp[j] * a;
         dAacc[j] = fmaf(gg, dt, dAacc[j]);
         p1 = fmaf(gg, Ap[j], p1);
-        p2 = fmaf(dx, bv[j], p2);
+        p2 = fmaf(dx, o.bv[j], p2);
         dxc[j] = a * dx;
       }
       s_p1[w][slot][lane] = p1;
@@ -229,20 +247,35 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     };
 
     float xs[SUB][NS];
+    StepOps cur, nxt;
     // ---- second half (local steps 8..15), only if the chunk reaches it
     if (tlast >= SUB) {
       float x[NS];
-      load_ckpt(x);
 #pragma unroll
-      for (int tl = 0; tl < SUB; ++tl) fwd_step(x, tl);
+      for (int j = 0; j < NS; ++j) x[j] = x0[j];
+      fetch(0, cur);
 #pragma unroll
-      for (int s = 0; s < SUB; ++s) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) xs[s][j] = x[j];
-        if (s + 1 < SUB) fwd_step(x, SUB + s);
+      for (int tl = 0; tl < SUB; ++tl) {       // steps 0..7, state only
+        fetch(tl + 1, nxt);
+        fwd_step(x, cur);
+        cur = nxt;
       }
 #pragma unroll
-      for (int s = SUB - 1; s >= 0; --s) rev_step(xs[s], SUB + s, s);
+      for (int s = 0; s < SUB; ++s) {          // steps 8..14, keeping the state before every step
+#pragma unroll
+        for (int j = 0; j < NS; ++j) xs[s][j] = x[j];
+        if (s + 1 < SUB) {
+          fetch(SUB + s + 1, nxt);
+          fwd_step(x, cur);
+          cur = nxt;
+        }
+      }
+#pragma unroll
+      for (int s = SUB - 1; s >= 0; --s) {     // reverse 15..8 (cur holds step 15's operands)
+        if (s > 0) fetch(SUB + s - 1, nxt);
+        rev_step(xs[s], SUB + s, s, cur);
+        if (s > 0) cur = nxt;
+      }
       __syncthreads();
       finish_half(1);
       __syncthreads();  // partial-sum buffers are reused by the first half
@@ -250,15 +283,25 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     // ---- first half (local steps 0..7)
     {
       float x[NS];
-      load_ckpt(x);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) x[j] = x0[j];
+      fetch(0, cur);
 #pragma unroll
       for (int s = 0; s < SUB; ++s) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) xs[s][j] = x[j];
-        if (s + 1 < SUB) fwd_step(x, s);
+        if (s + 1 < SUB) {
+          fetch(s + 1, nxt);
+          fwd_step(x, cur);
+          cur = nxt;
+        }
       }
 #pragma unroll
-      for (int s = SUB - 1; s >= 0; --s) rev_step(xs[s], s, s);
+      for (int s = SUB - 1; s >= 0; --s) {
+        if (s > 0) fetch(s - 1, nxt);
+        rev_step(xs[s], s, s, cur);
+        if (s > 0) cur = nxt;
+      }
       __syncthreads();
       finish_half(0);
     }

@@ -91,44 +91,45 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
         if (dok && j < nvalid) ck[(int64_t)j * Dm] = x[j];
     }
     __syncthreads();
-    // ---- phase B: 16 sequential steps; operands of step t+1 are fetched (s_load for
-    //      B/C, ds_read for delta'/du) while step t computes.
-    float bv[NS], cv[NS], dt, du;
+    // ---- phase B: 16 sequential steps.  Operands (s_load for B/C, ds_read for delta'/du) are fetched TWO steps
+    //      at a time, one pair ahead of their use: scalar loads return out of order, so any wait on them is a
+    //      wait for all of them -- batching by pairs gives each wait two full steps of compute to hide behind.
+    struct PairOps {
+      float bv[2][NS], cv[2][NS];
+      float dt[2], du[2];
+    };
     const float *bp = Bw + t0 * B_sl, *cp = Cw + t0 * C_sl;  // t0 < L always
-    load_bc<FAST>(bp, B_sn, nvalid, bv);
-    load_bc<FAST>(cp, C_sn, nvalid, cv);
-    dt = s_dt[0][lane];
-    du = s_du[0][lane];
+    auto fetch_pair = [&](int tl, PairOps &o) {
 #pragma unroll
-    for (int tl = 0; tl < TB; ++tl) {
-      float nb[NS], nc[NS], ndt = 0.f, ndu = 0.f;
-      if (tl + 1 < TB) {
-        const int inc = (t0 + tl + 1 < L) ? 1 : 0;  // address clamps at the last valid row
+      for (int h = 0; h < 2; ++h) {
+        load_bc<FAST>(bp, B_sn, nvalid, o.bv[h]);
+        load_bc<FAST>(cp, C_sn, nvalid, o.cv[h]);
+        o.dt[h] = s_dt[tl + h][lane];
+        o.du[h] = s_du[tl + h][lane];
+        const int inc = (t0 + tl + h + 1 < L) ? 1 : 0;  // address clamps at the last valid row
         bp = opaque(bp + inc * B_sl);
         cp = opaque(cp + inc * C_sl);
-        load_bc<FAST>(bp, B_sn, nvalid, nb);
-        load_bc<FAST>(cp, C_sn, nvalid, nc);
-        ndt = s_dt[tl + 1][lane];
-        ndu = s_du[tl + 1][lane];
       }
-      float y = 0.f;
+    };
+    PairOps cur, nxt;
+    fetch_pair(0, cur);
 #pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
-        x[j] = fmaf(a, x[j], du * bv[j]);
-        y = fmaf(cv[j], x[j], y);
-      }
-      s_y[w][tl][lane] = y;
-      __builtin_amdgcn_sched_barrier(0);
-      if (tl + 1 < TB) {
+    for (int tp = 0; tp < TB; tp += 2) {
+      if (tp + 2 < TB) fetch_pair(tp + 2, nxt);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float dt = cur.dt[h], du = cur.du[h];
+        float y = 0.f;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-          bv[j] = nb[j];
-          cv[j] = nc[j];
+          const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
+          x[j] = fmaf(a, x[j], du * cur.bv[h][j]);
+          y = fmaf(cur.cv[h][j], x[j], y);
         }
-        dt = ndt;
-        du = ndu;
+        s_y[w][tp + h][lane] = y;
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tp + 2 < TB) cur = nxt;
     }
     __syncthreads();
     // ---- phase C: sum partial y over the state slices, skip term, gate, store

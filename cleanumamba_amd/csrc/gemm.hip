@@ -46,6 +46,7 @@ struct GemmParams {
   int M, N, K;             // N multiple of 16 (32 for GLU), K multiple of the K tile
   int pitch, valid;        // row m is real iff (m % pitch) < valid; other rows are stored as zeros
   int n_store;             // number of output columns to store (<= N, or N/2 for GLU); multiple of 4
+  int64_t zero_head, zero_tail;
 };
 
 template <typename T>
@@ -111,6 +112,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int n0 = (local % NB) * BN;
   const int m0 = m_tile * BM;
   if (m0 >= p.M) return;
+  // The first workgroup also clears the rows that frame the output buffer (leading zero row, slack rows), so the
+  // host never issues fill kernels for them.
+  if (blockIdx.x == 0) {
+    T *o = static_cast<T *>(p.out), *x = (EPI != EPI_GLU) ? static_cast<T *>(p.aux) : nullptr;
+    for (int64_t i = threadIdx.x; i < p.zero_head; i += 256) {
+      o[-1 - i] = Elem<T>::from_f(0.f);
+      if (x) x[-1 - i] = Elem<T>::from_f(0.f);
+    }
+    const int64_t tail0 = (int64_t)p.M * p.ldc, tailx = (int64_t)p.M * p.ldz;
+    for (int64_t i = threadIdx.x; i < p.zero_tail; i += 256) {
+      o[tail0 + i] = Elem<T>::from_f(0.f);
+      if (x) x[tailx + i] = Elem<T>::from_f(0.f);
+    }
+  }
   const T *A = static_cast<const T *>(p.A);
   const T *W = static_cast<const T *>(p.W);
 
@@ -291,7 +306,11 @@ __global__ void glu_bwd_kernel(const T *__restrict__ Z, const T *__restrict__ dO
 // dZ = dOut * (Y > 0)   (Y = ReLU output before any residual add); 4 elements per thread
 template <typename T>
 __global__ void relu_bwd_kernel(const T *__restrict__ Y, const T *__restrict__ dO, T *__restrict__ dZ, int64_t M,
-                                int ncol4, int64_t ldy, int64_t ldo, int64_t ldz) {
+                                int ncol4, int64_t ldy, int64_t ldo, int64_t ldz, int64_t zero_head, int64_t zero_tail) {
+  if (blockIdx.x == 0) {
+    for (int64_t i = threadIdx.x; i < zero_head; i += blockDim.x) dZ[-1 - i] = Elem<T>::from_f(0.f);
+    for (int64_t i = threadIdx.x; i < zero_tail; i += blockDim.x) dZ[M * ldz + i] = Elem<T>::from_f(0.f);
+  }
   const int64_t total = M * ncol4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (i % ncol4) * 4;
@@ -354,13 +373,14 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
   CUM_REQUIRE(d->N % (d->epilogue == 2 ? 32 : 16) == 0, "gemm: N must be a multiple of 16 (32 for GLU)");
   CUM_REQUIRE(d->lda % epc == 0 && d->ldw % epc == 0, "gemm: lda/ldw must keep rows 16-byte aligned");
   CUM_REQUIRE(d->ldc % 4 == 0 && d->ldr % 4 == 0 && d->ldz % 4 == 0 && d->n_store % 4 == 0, "gemm: ldc/ldr/ldz/n_store must be multiples of 4");
-  CUM_REQUIRE(d->pitch > 0 && d->valid >= 0, "gemm: bad pitch/valid");
+  CUM_REQUIRE(d->pitch > 0 && d->valid >= 0 && d->zero_head >= 0 && d->zero_tail >= 0, "gemm: bad pitch/valid/zero ranges");
   CUM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A and W must be 16-byte aligned");
   if (d->M == 0) return CUM_OK;
   GemmParams p{};
   p.A = A; p.W = W; p.bias = bias; p.res = res; p.out = out; p.aux = aux;
   p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr; p.ldz = d->ldz;
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;
+  p.zero_head = d->zero_head; p.zero_tail = d->zero_tail;
   if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);
   return launch_gemm<float>(p, d->epilogue, (hipStream_t)stream);
 }
@@ -383,7 +403,7 @@ extern "C" int cum_glu_bwd(int32_t dtype, int64_t M, int32_t n_groups, int32_t n
 }
 
 extern "C" int cum_relu_bwd(int32_t dtype, int64_t M, int32_t n_cols, const void *Y, int64_t ldy, const void *dOut,
-                            int64_t ldo, void *dZ, int64_t ldz, void *stream) {
+                            int64_t ldo, void *dZ, int64_t ldz, int64_t zero_head, int64_t zero_tail, void *stream) {
   CUM_REQUIRE(Y && dOut && dZ && n_cols > 0 && n_cols % 4 == 0 && M >= 0, "relu_bwd: bad argument");
   CUM_REQUIRE(ldy % 4 == 0 && ldo % 4 == 0 && ldz % 4 == 0, "relu_bwd: strides must be multiples of 4");
   if (M == 0) return CUM_OK;
@@ -391,10 +411,10 @@ extern "C" int cum_relu_bwd(int32_t dtype, int64_t M, int32_t n_cols, const void
   int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (dtype == CUM_BF16)
     hipLaunchKernelGGL(relu_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Y,
-                       (const __bf16 *)dOut, (__bf16 *)dZ, M, n_cols / 4, ldy, ldo, ldz);
+                       (const __bf16 *)dOut, (__bf16 *)dZ, M, n_cols / 4, ldy, ldo, ldz, zero_head, zero_tail);
   else
     hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)Y,
-                       (const float *)dOut, (float *)dZ, M, n_cols / 4, ldy, ldo, ldz);
+                       (const float *)dOut, (float *)dZ, M, n_cols / 4, ldy, ldo, ldz, zero_head, zero_tail);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }

@@ -38,12 +38,19 @@ class Geo:
         self.R = 1 + self.M + self.slack
 
     def new(self, dtype, device, zero=False):
+        """Uninitialised buffer.  The kernel that fills it also clears the leading row and the slack rows
+        (``head`` / ``tail`` elements, passed as zero_head / zero_tail)."""
         if zero:
             return torch.zeros(self.R, self.Cp, dtype=dtype, device=device)
-        buf = torch.empty(self.R, self.Cp, dtype=dtype, device=device)
-        buf[0].zero_()
-        buf[1 + self.M:].zero_()
-        return buf
+        return torch.empty(self.R, self.Cp, dtype=dtype, device=device)
+
+    @property
+    def head(self):
+        return self.Cp
+
+    @property
+    def tail(self):
+        return self.slack * self.Cp
 
     def rows(self, buf):
         """[B, P, Cp] view of the clip rows."""
@@ -68,7 +75,7 @@ def _padv(b, n):
 
 # ------------------------------------------------------------------ GEMM launcher
 def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_store, res=None, r_off=0, ldr=0,
-         aux=None, x_off=0, ldz=0):
+         aux=None, x_off=0, ldz=0, geo=None):
     """A, out, res, aux: flat tensors; *_off element offsets of row 0; Wp [N, K] packed weights."""
     hip.require_gpu(A, Wp, out, res, aux, any_dtype=True)
     dt = A.dtype
@@ -80,6 +87,8 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
     d.M, d.N, d.K = M, Wp.shape[0], Wp.shape[1]
     d.lda, d.ldw, d.ldc, d.ldr, d.ldz = lda, Wp.stride(0), ldc, ldr if res is not None else 4, ldz if aux is not None else 4
     d.pitch, d.valid, d.n_store = pitch, valid, n_store
+    if geo is not None:      # out (and an activation-type aux) is a row buffer of this geometry: frame it with zeros
+        d.zero_head, d.zero_tail = geo.head, geo.tail
     P = lambda t, off: None if t is None else ctypes.c_void_p(t.data_ptr() + off * esz)
     with torch.cuda.device(A.device):
         hip.check(hip.lib().cum_gemm_nt(ctypes.byref(d), P(A, a_off), P(Wp, 0), hip.ptr(bias), P(res, r_off),
@@ -259,7 +268,7 @@ class ConvK4S2ReLU(torch.autograd.Function):
         wp = take(w, ("conv_fwd", sh, gi.Cp, Np, Kp), lambda: lay_conv_fwd(sh, gi.Cp, Np, Kp), dt)
         bp = take(b, ("vec", H, Np), lambda: lay_vec(H, Np), torch.float32)
         ybuf = go.new(dt, dev)
-        gemm(xbuf, gi.Cp, 2 * gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_RELU, go.Cp)
+        gemm(xbuf, gi.Cp, 2 * gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_RELU, go.Cp, geo=go)
         ctx.gi, ctx.go = gi, go
         ctx.save_for_backward(xbuf, w, ybuf)
         return ybuf
@@ -275,7 +284,7 @@ class ConvK4S2ReLU(torch.autograd.Function):
         dz = go.new(dt, dev)
         with torch.cuda.device(dev):
             hip.check(hip.lib().cum_relu_bwd(hip.dtype_code(dt), go.M, go.Cp, hip.ptr(ybuf[1:]), go.Cp,
-                                             hip.ptr(dy[1:]), go.Cp, hip.ptr(dz[1:]), go.Cp, hip.stream_ptr()))
+                                             hip.ptr(dy[1:]), go.Cp, hip.ptr(dz[1:]), go.Cp, go.head, go.tail, hip.stream_ptr()))
         # weight + bias gradient in one launch: X row m = the 4*Cp contiguous inputs of output row m
         dwp, dbp = wgrad(dz, go.Cp, go.Cp, go.Cp, xbuf, gi.Cp, 2 * gi.Cp, 4 * gi.Cp, go.M)
         db = dbp[:H]
@@ -288,7 +297,7 @@ class ConvK4S2ReLU(torch.autograd.Function):
             Nd, Kd = rup(2 * gi.Cp, 16), rup(2 * go.Cp, bk_of(dt))
             wd = take(w, ("conv_dgrad", sh, gi.Cp, go.Cp, Nd, Kd), lambda: lay_conv_dgrad(sh, gi.Cp, go.Cp, Nd, Kd), dt)
             dx = gi.new(dt, dev)
-            gemm(dz, 0, go.Cp, wd, None, dx, gi.Cp, 2 * gi.Cp, go.M, go.P, go.T + 1, hip.EPI_BIAS, 2 * gi.Cp)
+            gemm(dz, 0, go.Cp, wd, None, dx, gi.Cp, 2 * gi.Cp, go.M, go.P, go.T + 1, hip.EPI_BIAS, 2 * gi.Cp, geo=gi)
         return dx, dw.to(w.dtype), db.to(w.dtype), None, None
 
 
@@ -309,7 +318,7 @@ class PointwiseGLU(torch.autograd.Function):
         ybuf = go.new(dt, dev)
         z = torch.empty(go.M, G * 32, dtype=dt, device=dev) if save_z else None
         gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_GLU, go.Cp,
-             aux=z, x_off=0, ldz=G * 32)
+             aux=z, x_off=0, ldz=G * 32, geo=go)
         ctx.gi, ctx.go, ctx.G = gi, go, G
         ctx.save_for_backward(xbuf, w, z)
         return ybuf
@@ -337,7 +346,7 @@ class PointwiseGLU(torch.autograd.Function):
             wt = take(w, ("glu_dgrad", sh, Nd, Kd),
                       lambda: torch.nn.functional.pad(lay_glu_fwd(sh, G * 32, Nd).t(), (0, Kd - G * 32)), dt)
             dx = gi.new(dt, dev)
-            gemm(dz, 0, G * 32, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
+            gemm(dz, 0, G * 32, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp, geo=gi)
         return dx, dw.to(w.dtype), db.to(w.dtype), None, None, None
 
 
@@ -363,7 +372,7 @@ class ConvT4S2(torch.autograd.Function):
         keep = relu and skip is not None            # the ReLU mask is not recoverable from y + skip
         act = go.new(dt, dev) if keep else None
         gemm(xbuf, 0, gi.Cp, wp, bp, ybuf, go.Cp, N, gi.M, gi.P, gi.T + 1, hip.EPI_RELU if relu else hip.EPI_BIAS, N,
-             res=skip, r_off=go.Cp, ldr=N, aux=act, x_off=go.Cp, ldz=N)
+             res=skip, r_off=go.Cp, ldr=N, aux=act, x_off=go.Cp, ldz=N, geo=go)
         ctx.gi, ctx.go, ctx.relu, ctx.has_skip = gi, go, relu, skip is not None
         ctx.save_for_backward(xbuf, w, act if keep else (ybuf if relu else None))
         return ybuf
@@ -380,7 +389,7 @@ class ConvT4S2(torch.autograd.Function):
             dz = go.new(dt, dev)
             with torch.cuda.device(dev):
                 hip.check(hip.lib().cum_relu_bwd(hip.dtype_code(dt), go.M, go.Cp, hip.ptr(act[1:]), go.Cp,
-                                                 hip.ptr(dy[1:]), go.Cp, hip.ptr(dz[1:]), go.Cp, hip.stream_ptr()))
+                                                 hip.ptr(dy[1:]), go.Cp, hip.ptr(dz[1:]), go.Cp, go.head, go.tail, hip.stream_ptr()))
         else:
             dz = dy
         # weight + bias gradient: pair rows of dz against the 2*Cp contiguous inputs (rows m-1, m) of x
@@ -395,7 +404,7 @@ class ConvT4S2(torch.autograd.Function):
             Nd, Kd = rup(gi.Cp, 16), rup(4 * go.Cp, bk_of(dt))
             wc = take(w, ("convt_dgrad", sh, go.Cp, Nd, Kd), lambda: lay_convt_dgrad(sh, go.Cp, Nd, Kd), dt)
             dx = gi.new(dt, dev)
-            gemm(dz, go.Cp, 2 * go.Cp, wc, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
+            gemm(dz, go.Cp, 2 * go.Cp, wc, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp, geo=gi)
         return dx, dw.to(w.dtype), db.to(w.dtype), dskip, None, None, None
 
 
@@ -413,7 +422,7 @@ class Pointwise(torch.autograd.Function):
         bp = take(b, ("vec", Cout, Np), lambda: lay_vec(Cout, Np), torch.float32)
         ybuf = go.new(dt, dev)
         gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_BIAS, go.Cp,
-             res=skip, r_off=go.Cp, ldr=go.Cp)
+             res=skip, r_off=go.Cp, ldr=go.Cp, geo=go)
         ctx.gi, ctx.go, ctx.has_skip = gi, go, skip is not None
         ctx.save_for_backward(xbuf, w)
         return ybuf
@@ -434,7 +443,7 @@ class Pointwise(torch.autograd.Function):
             sh = tuple(w.shape)
             wt = take(w, ("plain_dgrad", sh, Nd, Kd), lambda: lay_plain(sh, Nd, Kd, transpose=True), dt)
             dx = gi.new(dt, dev)
-            gemm(dy, go.Cp, go.Cp, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp)
+            gemm(dy, go.Cp, go.Cp, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp, geo=gi)
         return dx, dw.to(w.dtype), db.to(w.dtype), (dy if ctx.has_skip else None), None, None
 
 

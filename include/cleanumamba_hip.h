@@ -163,6 +163,9 @@ typedef struct {
   int64_t lda, ldw, ldc, ldr, ldz;
   int32_t pitch, valid;
   int32_t n_store;           /* output columns written (multiple of 4) */
+  int64_t zero_head;         /* elements in front of out[0] to clear (the buffer's leading zero row) */
+  int64_t zero_tail;         /* elements behind out[M*ldc] to clear (the buffer's slack rows); both also */
+                             /* applied to aux when it has out's geometry (epilogue != GLU)             */
 } cum_gemm_desc;
 
 int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias,
@@ -173,9 +176,11 @@ int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const floa
 int cum_glu_bwd(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Z,
                 int64_t ldz, const void *dOut, int64_t ldo, void *dZ, void *stream);
 
-/* dZ = dOut * (Y > 0) over M rows x n_cols columns (n_cols multiple of 4). */
+/* dZ = dOut * (Y > 0) over M rows x n_cols columns (n_cols multiple of 4).  zero_head / zero_tail:
+ * elements in front of dZ[0] / behind dZ[M*ldz] to clear (leading zero row / slack rows). */
 int cum_relu_bwd(int32_t dtype, int64_t M, int32_t n_cols, const void *Y, int64_t ldy,
-                 const void *dOut, int64_t ldo, void *dZ, int64_t ldz, void *stream);
+                 const void *dOut, int64_t ldo, void *dZ, int64_t ldz, int64_t zero_head,
+                 int64_t zero_tail, void *stream);
 
 /* out[c] = sum_m X[m*ld + c] in f32 (bias gradients); deterministic two-stage reduction.
  * workspace: cum_colsum_workspace_elems() f32 elements. */

@@ -84,7 +84,7 @@ def cpu_baseline(clip):
     from oracle import cleanumamba_ref as R
     from oracle import synth
     from cleanumamba_amd.network import CleanUMamba
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)     # the 624-step scan loop of small ops does not scale past ~32 threads
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     net = CleanUMamba(**E8)
@@ -110,8 +110,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)      # ranks > devices only in the single-GPU gloo self-test below
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from cleanumamba_amd import hip
     from cleanumamba_amd.network import Net
@@ -122,7 +124,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL over xGMI ("nccl" on ROCm).  CUM_DIST_BACKEND=gloo exists only to exercise this code path with
+        # several ranks on a one-GPU box; it is never what the scaling numbers are measured with.
+        backend = os.environ.get("CUM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     torch.manual_seed(0)                                 # reference seeds 0 (src/training/train.py:51-53)
     net = Net("CleanUMamba", E8).to(dev).train()

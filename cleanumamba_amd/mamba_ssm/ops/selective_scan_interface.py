@@ -52,7 +52,7 @@ class SelectiveScanFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
-                return_last_state=False):
+                return_last_state=False, save_ckpt=True):
         Bm, Cm = _as3(B), _as3(C)
         hip.require_gpu(u, delta, A, Bm, Cm, D, z, delta_bias)
         bsz, dim, L = u.shape
@@ -64,7 +64,7 @@ class SelectiveScanFn(torch.autograd.Function):
         delta_bias = None if delta_bias is None else delta_bias.contiguous()
         lib = hip.lib()
         out = _empty_like_layout(u)
-        need_grad = any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
+        need_grad = bool(save_ckpt)      # decided by the caller: grad mode is always off inside forward()
         ckpt = None
         if need_grad:
             ckpt = torch.empty(max(lib.cum_scan_ckpt_elems(bsz, dim, N, L), 1), dtype=torch.float32, device=u.device)
@@ -121,14 +121,16 @@ class SelectiveScanFn(torch.autograd.Function):
             dB = dB.unsqueeze(1)
         if ctx.b4[1]:
             dC = dC.unsqueeze(1)
-        return du, ddelta, dA, dB, dC, dD, dz, dbias, None, None
+        return du, ddelta, dA, dB, dC, dD, dz, dbias, None, None, None
 
 
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                       return_last_state=False):
     """out (and last_state (B, D, N) if requested); gate ``z`` is applied inside the kernel."""
     in_dtype = u.dtype
-    res = SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    # chunk-boundary states are written only when a backward can follow
+    save = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
+    res = SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state, save)
     if return_last_state:
         return res[0].to(in_dtype), res[1]
     return res.to(in_dtype)

@@ -16,7 +16,12 @@ def fwd():
     u, z = xz[..., :dim].transpose(1, 2), xz[..., dim:].transpose(1, 2)
     return selective_scan_fn(u, delta_.transpose(1, 2), A, xd[..., 32:32 + N].transpose(1, 2), xd[..., 32 + N:].transpose(1, 2), D, z=z, delta_bias=bias, delta_softplus=True)
 dout = rn(bsz, dim, L)
-for name, fn in (("fwd(+ckpt)", lambda: fwd()), ("fwd+bwd", lambda: fwd().backward(dout))):
+def fwd_nograd():
+    with torch.no_grad():
+        return fwd()
+cases = (("fwd(no ckpt)", fwd_nograd),) if "fwdonly" in sys.argv else \
+    (("fwd(no ckpt)", fwd_nograd), ("fwd(+ckpt)", lambda: fwd()), ("fwd+bwd", lambda: fwd().backward(dout)))
+for name, fn in cases:
     for _ in range(3): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -74,7 +74,10 @@ def scan_roofline(dev, iters=20):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "scan_fwd_kernel<8,true> (B=16,D=2048,N=64,L=624,f32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            # HBM bytes per launch from PMC passes of this kernel at this shape: 2 x FETCH_SIZE + WRITE_SIZE
+            # (gfx950 corrections, calibrated on a known kernel): profiles/r01_scan_pmc.md
+            "traffic": 409.7e6, "traffic_source": "profiles/r01_scan_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
             "launch_ms": round(ms, 4), "algorithmic_bytes": alg_bytes,
             "state_updates_per_s": round(bsz * L * dim * N / (ms * 1e-3) / 1e12, 3), "state_updates_unit": "T/s"}
 

@@ -91,13 +91,19 @@ __device__ __forceinline__ void load4<__bf16>(const __bf16 *p, float (&v)[4]) {
   for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
 }
 
-constexpr int BM = 128, BN = 128;
+constexpr int BN = 128;
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_kernel(const GemmParams p) {
+// BM = 128 (4 waves, 32 KB LDS, 4 workgroups/CU) or 256 (8 waves, 48 KB, 2 workgroups/CU).  The kernel is bound
+// by L2 -> LDS bandwidth (a 128x128x64 tile moves 32 KB per 2.1 MFLOP = 64 flop/B); the 256-row tile reuses
+// every weight tile twice as often (85 flop/B) and is used whenever M is large enough to fill the chip with it.
+template <typename T, int EPI, int BM>
+__global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_kernel(const GemmParams p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;  // 64 bf16 / 32 f32: LDS rows are 128 B either way
-  __shared__ uint4 lds[2][BM * 8];  // [0: activations, 1: weights][row * 8 + chunk]
+  constexpr int NT = 2 * BM;   // threads
+  constexpr int WCH = BN * 8 / NT;  // weight chunks per thread (activation chunks per thread: BM * 8 / NT = 4)
+  __shared__ uint4 lds_all[(BM + BN) * 8];  // [row * 8 + chunk]: activations, then weights
+  uint4 *const ldsA = lds_all, *const ldsW = lds_all + BM * 8;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -116,12 +122,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // host never issues fill kernels for them.
   if (blockIdx.x == 0) {
     T *o = static_cast<T *>(p.out), *x = (EPI != EPI_GLU) ? static_cast<T *>(p.aux) : nullptr;
-    for (int64_t i = threadIdx.x; i < p.zero_head; i += 256) {
+    for (int64_t i = threadIdx.x; i < p.zero_head; i += NT) {
       o[-1 - i] = Elem<T>::from_f(0.f);
       if (x) x[-1 - i] = Elem<T>::from_f(0.f);
     }
     const int64_t tail0 = (int64_t)p.M * p.ldc, tailx = (int64_t)p.M * p.ldz;
-    for (int64_t i = threadIdx.x; i < p.zero_tail; i += 256) {
+    for (int64_t i = threadIdx.x; i < p.zero_tail; i += NT) {
       o[tail0 + i] = Elem<T>::from_f(0.f);
       if (x) x[tailx + i] = Elem<T>::from_f(0.f);
     }
@@ -129,29 +135,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const T *A = static_cast<const T *>(p.A);
   const T *W = static_cast<const T *>(p.W);
 
-  // ---- global -> register staging: thread handles linear LDS positions it*256 + tid
-  const T *ga[4], *gw[4];
+  // ---- HBM -> LDS: thread handles linear LDS chunk positions it*NT + tid of each tile
+  const T *ga[4], *gw[WCH];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int pos = it * 256 + tid;
+    const int pos = it * NT + tid;
     const int row = pos >> 3, cphys = pos & 7;
     const int clog = cphys ^ (row & 7);
     int am = m0 + row;
     am = am < p.M ? am : p.M - 1;
+    ga[it] = A + (int64_t)am * p.lda + clog * EPC;
+  }
+#pragma unroll
+  for (int it = 0; it < WCH; ++it) {
+    const int pos = it * NT + tid;
+    const int row = pos >> 3, cphys = pos & 7;
+    const int clog = cphys ^ (row & 7);
     int wr = n0 + row;
     wr = wr < p.N ? wr : p.N - 1;
-    ga[it] = A + (int64_t)am * p.lda + clog * EPC;
     gw[it] = W + (int64_t)wr * p.ldw + clog * EPC;
   }
   typedef __attribute__((address_space(3))) void *lds_ptr;
   typedef const __attribute__((address_space(1))) void *glb_ptr;
   const int wave_u = uniform(wave);
-  // one wave-instruction fills 1 KiB = 8 LDS rows; lane L writes chunk position it*256 + wave*64 + L
-#define CUM_GLDS(k0)                                                                                              \
-  _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                             \
-    __builtin_amdgcn_global_load_lds((glb_ptr)(ga[it] + (k0)), (lds_ptr)(&lds[0][it * 256 + wave_u * 64]), 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((glb_ptr)(gw[it] + (k0)), (lds_ptr)(&lds[1][it * 256 + wave_u * 64]), 16, 0, 0); \
-  }
+  // one wave-instruction fills 1 KiB = 8 LDS rows; lane L writes chunk position it*NT + wave*64 + L
+#define CUM_GLDS(k0)                                                                                           \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                            \
+    __builtin_amdgcn_global_load_lds((glb_ptr)(ga[it] + (k0)), (lds_ptr)(&ldsA[it * NT + wave_u * 64]), 16, 0, 0); \
+  _Pragma("unroll") for (int it = 0; it < WCH; ++it)                                                          \
+    __builtin_amdgcn_global_load_lds((glb_ptr)(gw[it] + (k0)), (lds_ptr)(&ldsW[it * NT + wave_u * 64]), 16, 0, 0);
 
   f32x4 acc[4][4];  // [ni][mi]
 #pragma unroll
@@ -173,8 +185,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           const int wrow = wn * 64 + i * 16 + r;
           const int arow = wm * 64 + i * 16 + r;
           const int cl = ks * 4 + g;
-          wf[i] = __builtin_bit_cast(bf16x8, lds[1][wrow * 8 + (cl ^ (wrow & 7))]);
-          af[i] = __builtin_bit_cast(bf16x8, lds[0][arow * 8 + (cl ^ (arow & 7))]);
+          wf[i] = __builtin_bit_cast(bf16x8, ldsW[wrow * 8 + (cl ^ (wrow & 7))]);
+          af[i] = __builtin_bit_cast(bf16x8, ldsA[arow * 8 + (cl ^ (arow & 7))]);
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -193,8 +205,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int cl = 2 * g + h;
-          const uint4 wv = lds[1][wrow * 8 + (cl ^ (wrow & 7))];
-          const uint4 av = lds[0][arow * 8 + (cl ^ (arow & 7))];
+          const uint4 wv = ldsW[wrow * 8 + (cl ^ (wrow & 7))];
+          const uint4 av = ldsA[arow * 8 + (cl ^ (arow & 7))];
           wf[i][4 * h + 0] = __builtin_bit_cast(float, wv.x); wf[i][4 * h + 1] = __builtin_bit_cast(float, wv.y);
           wf[i][4 * h + 2] = __builtin_bit_cast(float, wv.z); wf[i][4 * h + 3] = __builtin_bit_cast(float, wv.w);
           af[i][4 * h + 0] = __builtin_bit_cast(float, av.x); af[i][4 * h + 1] = __builtin_bit_cast(float, av.y);
@@ -345,17 +357,26 @@ __global__ void colsum_stage2(const float *__restrict__ part, int nparts, int n,
   out[c] = s;
 }
 
-template <typename T>
-static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
+template <typename T, int BM>
+static int launch_gemm_bm(const GemmParams &p, int epi, hipStream_t st) {
   const int NB = (p.N + BN - 1) / BN, MB = (p.M + BM - 1) / BM;
-  dim3 grid(8 * NB * ((MB + 7) / 8)), block(256);
+  dim3 grid(8 * NB * ((MB + 7) / 8)), block(2 * BM);
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, st, p); break;
-    case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU>), grid, block, 0, st, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, BM>), grid, block, 0, st, p); break;
+    case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU, BM>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU, BM>), grid, block, 0, st, p); break;
   }
   CUM_CHECK_LAUNCH();
   return CUM_OK;
+}
+
+template <typename T>
+static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
+  // 256-row tiles once they still give every CU >= 2 workgroups per XCD-round; K >= 256 so the saved weight
+  // traffic matters (the outer layers are bound by their activation traffic, where tile height is irrelevant)
+  const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
+  if (tiles256 >= 1024 && p.K >= 256) return launch_gemm_bm<T, 256>(p, epi, st);
+  return launch_gemm_bm<T, 128>(p, epi, st);
 }
 
 }  // namespace cum

@@ -126,6 +126,11 @@ class CleanUMamba(nn.Module):
         self.inference_params = None
         self.encoder_decoder_state = {}
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_pack_plans", None)      # device-side caches of packed weights are rebuilt on demand
+        return state
+
     # ------------------------------------------------------------------ geometry
     def valid_length(self, length):
         """Smallest length >= ``length`` that survives D strided convs and their transposes exactly."""
@@ -199,6 +204,14 @@ class CleanUMamba(nn.Module):
         if torch.is_autocast_enabled("cuda"):
             dt = torch.bfloat16            # fp16 autocast also maps to bf16 MFMA (f32 accumulate)
         save = torch.is_grad_enabled()
+        # one batched re-pack of all conv weights for this forward (and its backward); see cs.PackPlan
+        plans = self.__dict__.setdefault("_pack_plans", {})
+        plan = plans.get(dt)
+        conv_params = [p for m in (self.encoder, self.decoder, self.tsfm_conv1, self.tsfm_conv2) for p in m.parameters()]
+        if plan is None or [p.data_ptr() for p in plan.params] != [p.data_ptr() for p in conv_params]:
+            plan = plans[dt] = cs.PackPlan(conv_params)
+        plan.refresh()
+        cs.set_active_plan(plan)
         geo = cs.Geo(B, T0, 1)
         buf = cs.to_rows(x, geo, dt)
         skips = []

@@ -135,8 +135,77 @@ def _ids(shape):
     return torch.arange(1, n + 1, dtype=torch.int64).view(shape)      # 0 is reserved for "zero padding"
 
 
+class PackPlan:
+    """Batches every weight / bias pack of one model into two gathers per forward.
+
+    The first step runs un-batched and records each (parameter, layout) request made through ``take``; from the
+    second forward on, ``refresh()`` concatenates the parameters once, casts once, and gathers all packed operands
+    (forward and backward-data ones) with one ``index_select`` per dtype; ``take`` then returns views."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        self.offset, off = {}, 0
+        for p in self.params:
+            self.offset[p.data_ptr()] = off
+            off += p.numel()
+        self.total = off                      # index of the zero slot
+        self.reqs = {}                        # (key, ptr, dtype) -> (global index (cpu), shape)
+        self.dirty = False
+        self.gidx = {}                        # dtype -> (device index tensor, [(reqkey, start, numel, shape)])
+        self.current = {}
+
+    def record(self, key, src, idx, shape, dtype):
+        rk = (key, src.data_ptr(), dtype)
+        if rk in self.reqs:
+            return
+        local = idx.cpu()
+        g = local + self.offset[src.data_ptr()]
+        g[local >= src.numel()] = self.total
+        self.reqs[rk] = (g, shape)
+        self.dirty = True
+
+    def refresh(self):
+        """Recompute every recorded pack from the current parameter values."""
+        self.current = {}
+        if not self.reqs:
+            return
+        dev = self.params[0].device
+        if self.dirty:
+            self.gidx = {}
+            by_dt = {}
+            for rk, (g, shape) in self.reqs.items():
+                by_dt.setdefault(rk[2], []).append((rk, g, shape))
+            for dt, items in by_dt.items():
+                metas, parts, start = [], [], 0
+                for rk, g, shape in items:
+                    metas.append((rk, start, g.numel(), shape))
+                    parts.append(g)
+                    start += g.numel()
+                self.gidx[dt] = (torch.cat(parts).to(dev), metas)
+            self.dirty = False
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self.params] + [torch.zeros(1, dtype=self.params[0].dtype, device=dev)])
+            for dt, (gi, metas) in self.gidx.items():
+                big = (flat if flat.dtype == dt else flat.to(dt)).index_select(0, gi)
+                for rk, start, n, shape in metas:
+                    self.current[rk] = big[start:start + n].view(shape)
+
+
+_ACTIVE_PLAN = None
+
+
+def set_active_plan(plan):
+    global _ACTIVE_PLAN
+    _ACTIVE_PLAN = plan
+
+
 def take(src, key, build, dtype=None):
     """out = [src.flatten(), 0][index].view(shape); ``build()`` returns the id layout (0 = padding)."""
+    plan = _ACTIVE_PLAN
+    if plan is not None and src.data_ptr() in plan.offset:
+        hit = plan.current.get((key, src.data_ptr(), dtype if dtype is not None else src.dtype))
+        if hit is not None:
+            return hit
     ent = _INDEX_CACHE.get((key, src.device))
     if ent is None:
         ids = build()
@@ -145,6 +214,8 @@ def take(src, key, build, dtype=None):
         ent = (idx.to(src.device), tuple(ids.shape))
         _INDEX_CACHE[(key, src.device)] = ent
     idx, shape = ent
+    if plan is not None and src.data_ptr() in plan.offset:
+        plan.record(key, src, idx, shape, dtype if dtype is not None else src.dtype)
     flat = src.reshape(-1)
     if dtype is not None and flat.dtype != dtype:
         flat = flat.to(dtype)

@@ -283,36 +283,56 @@ class CleanUMamba(nn.Module):
     def flush(self):
         """Emit the samples still pending: pad one frame of zeros, run it through the SAME stream
         state (so the decoder overlap of the tail is kept), then reset the stream."""
-        pending_length = self.pending.shape[1]
-        padding = torch.zeros(self.channels_input, self.frame_length, device=self.pending.device, dtype=self.dtype)
-        frames_before, time_before = self.frames, self.total_time
-        out = self.feed(padding)
-        out = out[:, :pending_length]
-        self.reset_stream()
-        self.frames, self.total_time = frames_before, time_before
-        return out
+        return self.flush_batch()
 
     @torch.no_grad()
     def feed(self, noisy_input):
-        """noisy_input: (1, n) samples of one stream -> (1, m) denoised samples, m a multiple of total_stride."""
+        """noisy_input: (1, n) samples of one stream -> (1, m) denoised samples, m a multiple of total_stride
+        (interface of src/network/CleanUMamba.py:370-418)."""
         if noisy_input.dim() != 2:
             raise ValueError("input should be two dimensional.")
         C, _ = noisy_input.shape
         if C != 1:
             raise ValueError(f"Expected 1 channel, got {C}")
+        return self.feed_batch(noisy_input)
+
+    @torch.no_grad()
+    def flush_batch(self):
+        pending_length = self.pending.shape[1]
+        padding = torch.zeros(self.pending.shape[0], self.frame_length, device=self.pending.device, dtype=self.dtype)
+        frames_before, time_before = self.frames, self.total_time
+        out = self.feed_batch(padding)[:, :pending_length]
+        self.reset_stream()
+        self.frames, self.total_time = frames_before, time_before
+        return out
+
+    @torch.no_grad()
+    def feed_batch(self, noisy_input):
+        """S concurrent streams in lock-step: (S, n) new samples per stream -> (S, m).  Every stream owns a row of
+        the pending buffer, of the per-layer conv tails and of the Mamba conv / SSM states; one hop costs the same
+        number of kernel launches whatever S is (the reference streams one clip at a time, batch fixed to 1 at
+        src/network/CleanUMamba.py:375-381)."""
+        if noisy_input.dim() != 2:
+            raise ValueError("input should be two dimensional: (streams, samples)")
+        S = noisy_input.shape[0]
+        if self.pending.shape[0] != S or self.pending.device != noisy_input.device:
+            if self.pending.shape[1] != 0 or self.inference_params is not None:
+                if self.pending.shape[0] != S:
+                    raise ValueError(f"stream count changed from {self.pending.shape[0]} to {S}; call reset_stream()")
+            self.pending = torch.zeros(S, 0, dtype=noisy_input.dtype, device=noisy_input.device)
         if self.inference_params is None:
-            self.inference_params = InferenceParams(max_seqlen=1, max_batch_size=1,
-                                                    key_value_memory_dict=self.allocate_inference_cache(1, 1),
+            self.inference_params = InferenceParams(max_seqlen=1, max_batch_size=S,
+                                                    key_value_memory_dict=self.allocate_inference_cache(S, 1),
                                                     seqlen_offset=1)
         begin = time.time()
         total_stride = self.total_stride
-        self.pending = torch.cat([self.pending.to(noisy_input.device), noisy_input], dim=1)
+        self.pending = torch.cat([self.pending, noisy_input], dim=1)
         denoised_frames = []
         while self.pending.shape[1] >= self.frame_length:
             self.frames += 1
             frame = self.pending[:, :self.frame_length]
             if self.normalize_input:
-                # running mean of the per-frame std (src/network/CleanUMamba.py:399-401)
+                # running mean of the per-frame std, per stream (src/network/CleanUMamba.py:399-401)
                 self.input_std = (frame.std(dim=1, keepdim=True) + 1e-3) / self.frames \
                     + (1 - 1 / self.frames) * self.input_std
                 frame = frame / self.input_std
@@ -324,10 +344,10 @@ class CleanUMamba(nn.Module):
         self.total_time += time.time() - begin
         if denoised_frames:
             return torch.cat(denoised_frames, 1)
-        return torch.zeros(C, 0, device=noisy_input.device)
+        return torch.zeros(S, 0, device=noisy_input.device)
 
     def _denoise_frame(self, frame):
-        """One hop: frame (1, frame_length) -> (1, >= total_stride) samples.  Encoder outputs that overlap
+        """One hop: frame (S, frame_length) -> (S, >= total_stride) samples.  Encoder outputs that overlap
         the previous frame are cached per layer; the decoder keeps the last ``stride`` samples of every
         transposed conv for overlap-add with the next frame."""
         x = frame.unsqueeze(1)
@@ -360,7 +380,7 @@ class CleanUMamba(nn.Module):
                 x = torch.cat([x[..., :self.stride] + prev, x[..., self.stride:]], -1)
             if i != self.encoder_n_layers - 1:
                 x = upsampling_block[3](x)
-        return x[0]
+        return x[:, 0]
 
     # ------------------------------------------------------------ pruned loading
     def load_pruned_state_dict(self, pruned_state_dict):

@@ -210,16 +210,19 @@ def take(src, key, build, dtype=None):
     if ent is None:
         ids = build()
         idx = ids.reshape(-1) - 1
+        pad = bool((idx < 0).any())          # does the layout reference the zero slot at all?
         idx[idx < 0] = src.numel()
-        ent = (idx.to(src.device), tuple(ids.shape))
+        ent = (idx.to(src.device), tuple(ids.shape), pad)
         _INDEX_CACHE[(key, src.device)] = ent
-    idx, shape = ent
+    idx, shape, pad = ent
     if plan is not None and src.data_ptr() in plan.offset:
         plan.record(key, src, idx, shape, dtype if dtype is not None else src.dtype)
     flat = src.reshape(-1)
     if dtype is not None and flat.dtype != dtype:
         flat = flat.to(dtype)
-    return torch.nn.functional.pad(flat, (0, 1)).index_select(0, idx).view(shape)
+    if pad:
+        flat = torch.nn.functional.pad(flat, (0, 1))
+    return flat.index_select(0, idx).view(shape)
 
 
 def _invert(packed_ids, param_shape):

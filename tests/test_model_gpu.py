@@ -132,3 +132,27 @@ def test_loss_and_train_step_on_gpu(cuda):
     l1, _ = step(clean.to(cuda), noisy.to(cuda))
     assert torch.isfinite(l0) and torch.isfinite(l1) and torch.isfinite(gn)
     assert not torch.equal(before, net.tsfm_Mamba_layers[0].mixer.A_log.detach())
+
+
+def test_batched_streams_equal_single_streams(cuda):
+    """feed_batch over S streams == each stream fed alone (and == the parallel forward on full hops)."""
+    net = _net("pruned500k", cuda, pruned=True)
+    net.normalize_input = False
+    g = torch.Generator().manual_seed(11)
+    x = (0.1 * torch.randn(3, 6000, generator=g)).to(cuda)
+    with torch.no_grad():
+        outs = []
+        for i in range(0, 6000, 1500):
+            outs.append(net.feed_batch(x[:, i:i + 1500]))
+        outs.append(net.flush_batch())
+        seq = torch.cat(outs, 1)
+        assert seq.shape == (3, 6000)
+        for sidx in range(3):
+            one = torch.cat([net.feed(x[sidx:sidx + 1]), net.flush()], 1)
+            assert rel_l2(seq[sidx:sidx + 1], one) < 1e-5
+        par = net(x.unsqueeze(1))[:, 0, :6000]
+    exact = ((net.valid_length(6000) - net.frame_length) // net.total_stride + 1) * net.total_stride
+    assert rel_l2(seq[:, :exact], par[:, :exact]) < 1e-4
+    with pytest.raises(ValueError):
+        net.feed_batch(x[:, :100])
+        net.feed_batch(x[:2, :100])

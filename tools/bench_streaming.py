@@ -1,0 +1,39 @@
+"""BASELINE config 5: pruned CleanUMamba-E8 (492K) streaming inference, 256 concurrent 30 s @ 16 kHz streams.
+Real-time factor = audio seconds produced / wall seconds (aggregate over streams).  GPU box only."""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from cleanumamba_amd.network import CleanUMamba
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+SECONDS = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
+dev = torch.device("cuda")
+with np.load("tests/golden/ckpt_pruned500k.npz") as f:
+    cfg = json.loads(bytes(f["__network_config__"]).decode())
+    sd = {k: torch.from_numpy(f[k].astype(np.float32)) for k in f.files if k != "__network_config__"}
+net = CleanUMamba(**cfg)
+net.load_pruned_state_dict(sd)
+net = net.to(dev).eval()
+n = int(SECONDS * 16000)
+x = 0.05 * torch.randn(S, n, device=dev)
+hop = net.total_stride
+with torch.no_grad():
+    net.feed_batch(x[:, :4 * hop + net.frame_length])       # warm-up
+    net.reset_stream()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    chunk = 16 * hop                                      # 256 ms of audio per call
+    for i in range(0, n, chunk):
+        net.feed_batch(x[:, i:i + chunk])
+    net.flush_batch()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+frames = n // hop
+print(json.dumps({"streams": S, "seconds_per_stream": SECONDS, "wall_s": round(dt, 3),
+                  "rtf_aggregate": round(S * SECONDS / dt, 1), "rtf_per_stream": round(SECONDS / dt, 2),
+                  "ms_per_hop": round(1e3 * dt / frames, 3), "hop_ms_audio": 1e3 * hop / 16000}))

@@ -115,6 +115,9 @@ class CleanUMamba(nn.Module):
         # are called as torch modules (needed only when forward hooks on the conv modules must fire, as the
         # reference's pruning tools expect); the Mamba bottleneck uses the HIP kernels either way.
         self.use_fused_convs = True
+        # True: after the first hop of a stream the (launch-bound, ~100 tiny kernels) hop is captured once in a
+        # hipGraph and replayed; stream state lives in static buffers updated in place.
+        self.use_hop_graph = True
 
         # streaming state
         self.total_time = 0
@@ -129,6 +132,7 @@ class CleanUMamba(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop("_pack_plans", None)      # device-side caches of packed weights are rebuilt on demand
+        state.pop("_hop_graph", None)       # captured hipGraph of the streaming hop
         return state
 
     # ------------------------------------------------------------------ geometry
@@ -278,6 +282,7 @@ class CleanUMamba(nn.Module):
         self.encoder_decoder_state = {}
         self.input_std = 0
         self.frames = 0
+        self.__dict__.pop("_hop_graph", None)    # it captured the addresses of the dropped state buffers
 
     @torch.no_grad()
     def flush(self):
@@ -336,7 +341,7 @@ class CleanUMamba(nn.Module):
                 self.input_std = (frame.std(dim=1, keepdim=True) + 1e-3) / self.frames \
                     + (1 - 1 / self.frames) * self.input_std
                 frame = frame / self.input_std
-            out = self._denoise_frame(frame)[:, :total_stride]
+            out = self._hop(frame)[:, :total_stride]
             if self.normalize_input:
                 out = out * self.input_std
             denoised_frames.append(out)
@@ -346,7 +351,44 @@ class CleanUMamba(nn.Module):
             return torch.cat(denoised_frames, 1)
         return torch.zeros(S, 0, device=noisy_input.device)
 
-    def _denoise_frame(self, frame):
+    def _hop(self, frame):
+        """Eager first hop (it creates the state buffers), hipGraph replay afterwards."""
+        if not (getattr(self, "use_hop_graph", False) and frame.is_cuda and self.encoder_decoder_state):
+            return self._denoise_frame(frame)
+        hg = self.__dict__.get("_hop_graph")
+        if hg is None:
+            hg = {"failed": False}
+            try:
+                static_in = frame.clone()
+                stream = torch.cuda.Stream(device=frame.device)
+                stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stream):      # warm-up on a side stream, as graph capture requires
+                    saved = {k: v.clone() for k, v in self.encoder_decoder_state.items()}
+                    cache = {k: tuple(t.clone() for t in v)
+                             for k, v in self.inference_params.key_value_memory_dict.items()}
+                    self._denoise_frame(static_in, inplace=True)
+                    # undo the warm-up's state changes
+                    for k, v in saved.items():
+                        self.encoder_decoder_state[k].copy_(v)
+                    for k, v in cache.items():
+                        for dst, src in zip(self.inference_params.key_value_memory_dict[k], v):
+                            dst.copy_(src)
+                torch.cuda.current_stream().wait_stream(stream)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._denoise_frame(static_in, inplace=True)
+                # capture does not execute: state is untouched
+                hg.update(graph=graph, static_in=static_in, static_out=static_out, shape=tuple(frame.shape))
+            except Exception as exc:                 # noqa: BLE001 - capture is an optimisation; stay eager
+                hg = {"failed": True, "error": repr(exc)}
+            self.__dict__["_hop_graph"] = hg
+        if hg.get("failed") or hg["shape"] != tuple(frame.shape):
+            return self._denoise_frame(frame)
+        hg["static_in"].copy_(frame)
+        hg["graph"].replay()
+        return hg["static_out"].clone()
+
+    def _denoise_frame(self, frame, inplace=False):
         """One hop: frame (S, frame_length) -> (S, >= total_stride) samples.  Encoder outputs that overlap
         the previous frame are cached per layer; the decoder keeps the last ``stride`` samples of every
         transposed conv for overlap-add with the next frame."""
@@ -364,7 +406,10 @@ class CleanUMamba(nn.Module):
             x = encode(x)
             if prev is not None:
                 x = torch.cat([prev, x], -1)
-            state[f"enc{i}"] = x[..., hop:]
+            if inplace:
+                prev.copy_(x[..., hop:])             # static buffer (hipGraph replay reads it next hop)
+            else:
+                state[f"enc{i}"] = x[..., hop:].clone()
             skip_connections.append(x)
 
         x, _ = self._bottleneck(x, inference_params=self.inference_params)
@@ -374,10 +419,14 @@ class CleanUMamba(nn.Module):
             x = x + skip_i[..., :x.shape[-1]]
             x = upsampling_block[2](upsampling_block[1](upsampling_block[0](x)))
             prev = state.get(f"dec{i}")
-            state[f"dec{i}"] = x[..., -self.stride:] - upsampling_block[2].bias.view(-1, 1)
+            tail = x[..., -self.stride:] - upsampling_block[2].bias.view(-1, 1)
             x = x[..., :-self.stride]
             if prev is not None:
                 x = torch.cat([x[..., :self.stride] + prev, x[..., self.stride:]], -1)
+            if inplace:
+                prev.copy_(tail)
+            else:
+                state[f"dec{i}"] = tail
             if i != self.encoder_n_layers - 1:
                 x = upsampling_block[3](x)
         return x[:, 0]

@@ -72,14 +72,77 @@ def scan_roofline(dev, iters=20):
     ms = start.elapsed_time(end) / iters
     alg_bytes = bsz * L * 4 * (4 * dim + 2 * N)           # read u, delta, z, B, C; write out (fp32)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "scan_fwd_kernel<8,true> (B=16,D=2048,N=64,L=624,f32)",
+    return {"bound": "hbm", "kernel": "scan_fwd_lds_kernel<8> (B=16,D=2048,N=64,L=624,f32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             # HBM bytes per launch from PMC passes of this kernel at this shape: 2 x FETCH_SIZE + WRITE_SIZE
             # (gfx950 corrections, calibrated on a known kernel): profiles/r01_scan_pmc.md
-            "traffic": 409.7e6, "traffic_source": "profiles/r01_scan_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
+            "traffic": 368.7e6, "traffic_source": "profiles/r01_scan_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
             "launch_ms": round(ms, 4), "algorithmic_bytes": alg_bytes,
             "state_updates_per_s": round(bsz * L * dim * N / (ms * 1e-3) / 1e12, 3), "state_updates_unit": "T/s"}
+
+
+def _time(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def other_kernels(dev):
+    """Live HIP-event timings of the other heavy kernels of the step at an E8 layer shape, with their roofs
+    (bf16 MFMA 2.5 PFLOP/s dense; HBM 8 TB/s).  Informational: `roofline` stays the scan forward kernel."""
+    from cleanumamba_amd import hip
+    from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    from cleanumamba_amd.network import convstack as cs
+    out = []
+    # encoder layer 5 (768 -> 768, T = 2502, B = 16): conv k4 s2 as GEMM, forward and weight gradient
+    M, N, K, lda = 16 * 2504, 768, 3072, 1536
+    A = torch.randn(M * lda // 8 + K // 8 + 64, 8, device=dev).bfloat16()
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    bias = torch.zeros(N, device=dev)
+    ms = _time(lambda: cs.gemm(A, 0, lda, W, bias, y, 0, N, M, 1 << 30, 1 << 30, hip.EPI_RELU, N))
+    tf = 2.0 * M * N * K / ms / 1e9
+    out.append({"kernel": "gemm_nt_kernel<bf16,relu> enc5 conv (M=40064,N=768,K=3072)", "bound": "mfma",
+                "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                "launch_ms": round(ms, 4)})
+    dz = torch.randn(M, N, device=dev).bfloat16()
+    ms = _time(lambda: cs.wgrad(dz, 0, N, N, A, 0, lda, K, M))
+    tf = 2.0 * M * N * K / ms / 1e9
+    out.append({"kernel": "gemm_tn_kernel<bf16> + reduce, enc5 conv weight gradient", "bound": "mfma",
+                "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                "launch_ms": round(ms, 4)})
+    # selective scan backward at the E8 bottleneck shape
+    bsz, dim, Ns, L = 16, 2048, 64, 624
+    g = torch.Generator(device=dev).manual_seed(1)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+    xz = rn(bsz, L, 2 * dim).requires_grad_(True)
+    dl = (0.3 * rn(bsz, L, dim)).requires_grad_(True)
+    Am = (-torch.exp(torch.log(torch.arange(1, Ns + 1, device=dev).float())[None].repeat(dim, 1))).requires_grad_(True)
+    xd = rn(bsz, L, 32 + 2 * Ns).requires_grad_(True)
+    Dv, bv = rn(dim).requires_grad_(True), (0.3 * rn(dim)).requires_grad_(True)
+    dout = rn(bsz, dim, L)
+
+    def fwd():
+        return selective_scan_fn(xz[..., :dim].transpose(1, 2), dl.transpose(1, 2), Am, xd[..., 32:32 + Ns].transpose(1, 2),
+                                 xd[..., 32 + Ns:].transpose(1, 2), Dv, z=xz[..., dim:].transpose(1, 2), delta_bias=bv,
+                                 delta_softplus=True)
+    t_f = _time(fwd)
+    t_fb = _time(lambda: fwd().backward(dout))
+    ms = t_fb - t_f
+    byt = bsz * L * 4 * (7 * dim + 4 * Ns)
+    gbs = byt / (ms * 1e-3) / 1e9
+    out.append({"kernel": "scan_bwd_kernel<8,true> + finalize (B=16,D=2048,N=64,L=624,f32)", "bound": "hbm",
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "launch_ms": round(ms, 4), "algorithmic_bytes": byt})
+    return out
 
 
 def cpu_baseline(clip):
@@ -92,7 +155,7 @@ def cpu_baseline(clip):
     torch.manual_seed(0)
     net = CleanUMamba(**E8)
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
-    clean, noisy = synth.waveform(1, clip, seed=1234)
+    clean, noisy = synth.waveform(2, clip, seed=1234)
     t0 = time.time()
     y = R.forward_ref(sd, noisy)
     loss = R.loss_ref(y, clean, stft_config={"sc_lambda": 0.5, "mag_lambda": 0.5, "band": "full",
@@ -100,8 +163,8 @@ def cpu_baseline(clip):
                                              "fft_sizes": [512, 1024, 2048]})
     loss.backward()
     dt = time.time() - t0
-    return {"value": round(clip / dt, 1), "unit": "audio samples/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/cleanumamba_ref.py forward+loss+backward, E8, batch 1, {clip} samples, "
+    return {"value": round(2 * clip / dt, 1), "unit": "audio samples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/cleanumamba_ref.py forward+loss+backward, E8, batch 2, {clip} samples per clip, "
                       f"{dt:.1f} s wall (no optimizer step)"}
 
 
@@ -182,6 +245,8 @@ def main():
                "final_loss": round(final_loss, 5)}
         if not args.no_roofline:
             out["roofline"] = scan_roofline(dev)
+            if world == 1:
+                out["kernels"] = other_kernels(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_clip)
         print(json.dumps(out), flush=True)

@@ -7,6 +7,7 @@
 //
 // At d_state = 64 the kernel is bound by v_exp_f32 issue (one per state update), not
 // by HBM -- see DESIGN.md "scan roofline".
+#include <stdlib.h>
 #include "scan_common.h"
 
 namespace cum {
@@ -160,6 +161,164 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
   }
 }
 
+// Variant with B_t / C_t staged through LDS instead of scalar loads: phase A loads the chunk's [16][N] B and C
+// tiles with coalesced vector loads (any strides, padding masked to zero), phase B reads each wave's 8-float slice
+// with wave-uniform ds_read_b128 (LDS broadcast), one step ahead.  LDS returns in order, so waits are counted and
+// nothing in the step loop waits on the scalar cache.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams p) {
+  constexpr int K = (TB + NW - 1) / NW;
+  constexpr int NT = NW * 64;
+  constexpr int NP = NW * NS;                    // padded state count
+  constexpr int BCK = (TB * NP + NT - 1) / NT;   // B (and C) elements per thread per chunk
+  __shared__ float s_dt[TB][64];
+  __shared__ float s_du[TB][64];
+  __shared__ float s_y[NW][TB][64];
+  __shared__ __attribute__((aligned(16))) float s_B[TB][NP];
+  __shared__ __attribute__((aligned(16))) float s_C[TB][NP];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = uniform(tid >> 6);
+  const int b = blockIdx.y;
+  const int d = blockIdx.x * 64 + lane;
+  const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
+  const bool dok = d < Dm;
+  const int dc = dok ? d : Dm - 1;
+  const int n0 = w * NS;
+  const int nvalid = (N - n0) < NS ? (N - n0) : NS;
+
+  float Ap[NS], x[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int jj = j < nvalid ? j : nvalid - 1;
+    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    Ap[j] = (j < nvalid) ? a : 0.f;
+    x[j] = 0.f;
+  }
+  const float Dd = p.D ? p.D[dc] : 0.f;
+  const float bias = p.bias ? p.bias[dc] : 0.f;
+  const float *up = p.u + b * p.s.u_sb + dc * p.s.u_sd;
+  const float *dtp = p.delta + b * p.s.dt_sb + dc * p.s.dt_sd;
+  const bool has_z = p.z != nullptr;
+  const float *zp = has_z ? p.z + b * p.s.z_sb + dc * p.s.z_sd : up;
+  float *op = p.out + b * p.s.o_sb + dc * p.s.o_sd;
+  const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
+  const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
+  const int o_sl = (int)p.s.o_sl;
+  const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
+  const int softplus = p.s.delta_softplus;
+
+  float ru[K], rdt[K], rz[K], rb[BCK], rc[BCK];
+  auto load_rows = [&](int t0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int t = t0 + w + k * NW;
+      t = t < L ? t : L - 1;
+      ru[k] = up[t * u_sl];
+      rdt[k] = dtp[t * dt_sl];
+      rz[k] = zp[t * z_sl];
+    }
+#pragma unroll
+    for (int k = 0; k < BCK; ++k) {
+      const int e = tid + k * NT;
+      const int tl = e / NP, n = e % NP;
+      int t = t0 + tl;
+      t = t < L ? t : L - 1;
+      const int nc = n < N ? n : N - 1;
+      const float bvv = Bb[t * B_sl + nc * B_sn], cvv = Cb[t * C_sl + nc * C_sn];
+      rb[k] = n < N ? bvv : 0.f;
+      rc[k] = n < N ? cvv : 0.f;
+    }
+  };
+  load_rows(0);
+
+  const int nchunks = p.nchunks;
+  for (int c = 0; c < nchunks; ++c) {
+    const int t0 = c * TB;
+    float eu[K], ez[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int tl = w + k * NW;
+      if (tl < TB) {
+        const bool ok = dok && (t0 + tl) < L;
+        float dtv = rdt[k] + bias;
+        if (softplus) dtv = softplus20(dtv);
+        dtv = ok ? dtv : 0.f;
+        s_dt[tl][lane] = dtv;
+        s_du[tl][lane] = ok ? dtv * ru[k] : 0.f;
+      }
+      eu[k] = ru[k];
+      ez[k] = rz[k];
+    }
+#pragma unroll
+    for (int k = 0; k < BCK; ++k) {
+      const int e = tid + k * NT;
+      if (e < TB * NP) {
+        (&s_B[0][0])[e] = rb[k];
+        (&s_C[0][0])[e] = rc[k];
+      }
+    }
+    if (c + 1 < nchunks) load_rows(t0 + TB);
+    if (p.ckpt) {
+      float *ck = p.ckpt + (((int64_t)b * nchunks + c) * N + n0) * Dm + d;
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+        if (dok && j < nvalid) ck[(int64_t)j * Dm] = x[j];
+    }
+    __syncthreads();
+    float4 b0 = *reinterpret_cast<const float4 *>(&s_B[0][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[0][n0 + 4]);
+    float4 c0 = *reinterpret_cast<const float4 *>(&s_C[0][n0]), c1 = *reinterpret_cast<const float4 *>(&s_C[0][n0 + 4]);
+    float dt = s_dt[0][lane], du = s_du[0][lane];
+#pragma unroll
+    for (int tl = 0; tl < TB; ++tl) {
+      float4 nb0 = b0, nb1 = b1, nc0 = c0, nc1 = c1;
+      float ndt = 0.f, ndu = 0.f;
+      if (tl + 1 < TB) {
+        nb0 = *reinterpret_cast<const float4 *>(&s_B[tl + 1][n0]);
+        nb1 = *reinterpret_cast<const float4 *>(&s_B[tl + 1][n0 + 4]);
+        nc0 = *reinterpret_cast<const float4 *>(&s_C[tl + 1][n0]);
+        nc1 = *reinterpret_cast<const float4 *>(&s_C[tl + 1][n0 + 4]);
+        ndt = s_dt[tl + 1][lane];
+        ndu = s_du[tl + 1][lane];
+      }
+      const float bv[NS] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const float cv[NS] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      float y = 0.f;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
+        x[j] = fmaf(a, x[j], du * bv[j]);
+        y = fmaf(cv[j], x[j], y);
+      }
+      s_y[w][tl][lane] = y;
+      __builtin_amdgcn_sched_barrier(0);
+      b0 = nb0; b1 = nb1; c0 = nc0; c1 = nc1; dt = ndt; du = ndu;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int tl = w + k * NW;
+      const int t = t0 + tl;
+      if (tl < TB && t < L && dok) {
+        float y = Dd * eu[k];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) y += s_y[ww][tl][lane];
+        if (has_z) {
+          const float zv = ez[k];
+          y *= zv * sigmoidf_(zv);
+        }
+        op[t * o_sl] = y;
+      }
+    }
+  }
+  if (p.last_state && dok) {
+    float *ls = p.last_state + ((int64_t)b * Dm + d) * N + n0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (j < nvalid) ls[j] = x[j];
+  }
+}
+
 // selective_state_update: one thread per (stream b, channel d); state row of N floats.
 __global__ void state_update_kernel(int batch, int dim, int N, float *__restrict__ state, const float *__restrict__ x,
                                     const float *__restrict__ dt, const float *__restrict__ A,
@@ -191,9 +350,23 @@ __global__ void state_update_kernel(int batch, int dim, int N, float *__restrict
   out[i] = y;
 }
 
+static int scan_fwd_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("CUM_SCAN_FWD_LDS");   // "0" selects the scalar-load variant (kept for A/B runs)
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 template <int NW>
 static int launch_fwd(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
+  if (scan_fwd_variant() == 1) {
+    hipLaunchKernelGGL((scan_fwd_lds_kernel<NW>), grid, block, 0, st, p);
+    CUM_CHECK_LAUNCH();
+    return CUM_OK;
+  }
   const bool fast = p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW;
   if (fast)
     hipLaunchKernelGGL((scan_fwd_kernel<NW, true>), grid, block, 0, st, p);

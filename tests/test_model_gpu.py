@@ -156,3 +156,43 @@ def test_batched_streams_equal_single_streams(cuda):
     with pytest.raises(ValueError):
         net.feed_batch(x[:, :100])
         net.feed_batch(x[:2, :100])
+
+
+@pytest.mark.parametrize("L", [1, 300, 767, 4099])
+def test_ragged_lengths_vs_oracle(cuda, L):
+    """Inputs shorter than one frame, one frame + 1, and odd lengths: padding / cropping paths."""
+    net = _net("442k", cuda)
+    sd, _ = load_ckpt("442k")
+    x = 0.1 * torch.randn(3, 1, L, generator=torch.Generator().manual_seed(L))
+    if L == 1:
+        net.normalize_input = False            # std of a single sample is undefined (NaN) in the reference too
+    with torch.no_grad():
+        y = net(x.to(cuda))
+        ref = R.forward_ref(sd, x, normalize_input=net.normalize_input)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < E2E_TOL
+
+
+def test_full_size_e8_fused_path_equals_module_path(cuda):
+    """BASELINE full size (E8, 10 s @ 16 kHz): the fused GEMM conv stack and the torch-module conv stack are two
+    independent implementations of the same layers; they must agree in f32, forward and input-independent
+    gradient norms (size-independent cross-check where the CPU oracle would take minutes)."""
+    from cleanumamba_amd.network import CleanUMamba
+    g = load_golden("e2e_e8_synth")
+    meta = golden_json(g["meta"])
+    net = CleanUMamba(**meta["cfg"])
+    net.load_state_dict(synth.fill_state_dict(dict(zip(meta["keys"], meta["shapes"])), seed=meta["seed"]), strict=True)
+    net = net.to(cuda).train()
+    _, noisy = synth.waveform(2, 160000, seed=3)
+    noisy = noisy.to(cuda)
+    outs, norms = [], []
+    for fused in (True, False):
+        net.use_fused_convs = fused
+        net.zero_grad(set_to_none=True)
+        y = net(noisy)
+        y.square().mean().backward()
+        outs.append(y.detach())
+        norms.append(torch.stack([p.grad.norm() for p in net.parameters()]))
+    assert outs[0].shape == (2, 1, 160000)
+    assert rel_l2(outs[0], outs[1]) < E2E_TOL
+    assert rel_l2(norms[0], norms[1]) < 2e-2

@@ -12,7 +12,7 @@ value = global_batch * 160000 * K / (max-over-ranks time of K steps).
 roofline: the selective-scan forward kernel at the E8 bottleneck shape, algorithmic bytes
 (B*T*4*(4*d_inner + 2*N)) / mean launch duration measured with HIP events.
 cpu_baseline: the CPU oracle (oracle/cleanumamba_ref.py, kind "port") doing forward + loss + backward
-on a bounded sample (1 clip of 10 s), rank 0, N = 1 only.
+on a bounded sample (2 clips of 10 s), rank 0, N = 1 only.
 """
 import argparse
 import json

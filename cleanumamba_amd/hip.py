@@ -72,6 +72,11 @@ SIGNATURES = {
     "cum_colsum": (c_i32, [c_i32, c_i64, c_i32, _P, c_i64, _P, _P, _P]),
     "cum_gemm_tn_workspace_elems": (c_i64, [c_i32, c_i64, c_i32, c_i32]),
     "cum_gemm_tn": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P, _P, _P]),
+    "cum_stft_frames": (c_i32, [_P, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, _P, _P, c_i64, _P]),
+    "cum_stft_loss_workspace_elems": (c_i64, [c_i64, c_i64]),
+    "cum_stft_loss_fwd": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P]),
+    "cum_stft_loss_bwd": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P, _P]),
+    "cum_stft_fold": (c_i32, [_P, c_i64, c_i64, c_i32, c_i32, c_i32, _P, c_i64, _P, c_i64, c_i32, _P]),
 }
 
 _lib = None

@@ -198,6 +198,29 @@ int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, 
                 const void *X, int64_t ldx, float *dW, int64_t ldw, float *db, float *workspace,
                 void *stream);
 
+/* ---- multi-resolution STFT loss around rocFFT (src/util/stft_loss.py:16-184) -------------------------------------
+ * One resolution = (n_fft, hop, win_length, window[win_length]); torch.stft(center=True, reflect) framing:
+ * n_frames = 1 + len / hop, bins = n_fft / 2 + 1.  The caller runs the batched r2c / c2r (rocFFT) in between.
+ *
+ * cum_stft_frames: frames[b][f][n] = window[n - (n_fft - win_length)/2] * x_reflect[b][f*hop + n]  (:29-33)
+ * cum_stft_loss_fwd: spec_x / spec_y are (batch, n_frames, bins) interleaved complex f32.  With
+ *   X = sqrt(max(re^2 + im^2, 1e-7)) (:38) over frames >= frame0 (band == "high" keeps frames >= n_frames / 2, :117-119):
+ *   stats = { |Y - X|_F / |Y|_F (:59),  mean |log Y - log X| (:80),  |Y - X|_F,  |Y|_F }.
+ * cum_stft_loss_bwd: zspec = d(g_sc * stats[0] + g_mag * stats[1]) / d spec_x with interior bins halved, so that an
+ *   unnormalised c2r (irfft(norm="forward")) of zspec is the gradient wrt the real frames.  g_sc, g_mag: device scalars.
+ * cum_stft_fold: dx[b][m] (+)= sum of window * dframes over every frame position that reads sample m (incl. reflections). */
+int cum_stft_frames(const float *x, int64_t batch, int64_t len, int64_t x_stride_b, int32_t n_fft, int32_t hop,
+                    int32_t win_length, const float *window, float *frames, int64_t n_frames, void *stream);
+int64_t cum_stft_loss_workspace_elems(int64_t batch, int64_t n_frames);
+int cum_stft_loss_fwd(const float *spec_x, const float *spec_y, int64_t batch, int64_t n_frames, int32_t bins,
+                      int64_t frame0, float *workspace, float *stats, void *stream);
+int cum_stft_loss_bwd(const float *spec_x, const float *spec_y, int64_t batch, int64_t n_frames, int32_t bins,
+                      int64_t frame0, const float *stats, const float *g_sc, const float *g_mag, float *zspec,
+                      void *stream);
+int cum_stft_fold(const float *dframes, int64_t batch, int64_t len, int32_t n_fft, int32_t hop, int32_t win_length,
+                  const float *window, int64_t n_frames, float *dx, int64_t dx_stride_b, int32_t accumulate,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@
 // the DMA is linear), single-buffered: 32 KB of LDS and ~110 VGPRs per workgroup let 4 workgroups
 // share a CU, and their interleaving hides the load latency (CDNA guide: the 128x128 "step-3"
 // structure).
+#include <stdlib.h>
 #include "common.h"
 
 namespace cum {
@@ -91,22 +92,27 @@ __device__ __forceinline__ void load4<__bf16>(const __bf16 *p, float (&v)[4]) {
   for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
 }
 
-constexpr int BN = 128;
-
-// BM = 128 (4 waves, 32 KB LDS, 4 workgroups/CU) or 256 (8 waves, 48 KB, 2 workgroups/CU).  The kernel is bound
-// by L2 -> LDS bandwidth (a 128x128x64 tile moves 32 KB per 2.1 MFLOP = 64 flop/B); the 256-row tile reuses
-// every weight tile twice as often (85 flop/B) and is used whenever M is large enough to fill the chip with it.
-template <typename T, int EPI, int BM>
-__global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_kernel(const GemmParams p) {
+// Block tiles BM x BN, one wave per 64x64 sub-tile:
+//   128x128 (4 waves, 32 KB LDS, 4 workgroups/CU), 256x128 (8 waves, 48 KB, 2-3 workgroups/CU): single LDS
+//   buffer, the interleaving of the co-resident workgroups hides the load latency;
+//   256x256 (16 waves, one workgroup per CU): two LDS buffers (128 KB), the DMA of step k+1 runs under the
+//   MFMAs of step k, one barrier per step.
+// The kernel is bound by L2 -> LDS bandwidth (a 128x128x64 tile moves 32 KB per 2.1 MFLOP = 64 flop/B; 256x128:
+// 85 flop/B; 256x256: 128 flop/B), so the largest tile that still fills the chip wins.
+template <typename T, int EPI, int BM, int BN>
+__global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_kernel(const GemmParams p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;  // 64 bf16 / 32 f32: LDS rows are 128 B either way
-  constexpr int NT = 2 * BM;   // threads
-  constexpr int WCH = BN * 8 / NT;  // weight chunks per thread (activation chunks per thread: BM * 8 / NT = 4)
-  __shared__ uint4 lds_all[(BM + BN) * 8];  // [row * 8 + chunk]: activations, then weights
-  uint4 *const ldsA = lds_all, *const ldsW = lds_all + BM * 8;
+  constexpr int NT = BM * BN / 64;   // threads: one wave per 64x64 sub-tile
+  constexpr int WN = BN / 64;        // waves along n
+  constexpr int ACH = BM * 8 / NT;   // activation chunks per thread
+  constexpr int WCH = BN * 8 / NT;   // weight chunks per thread
+  constexpr bool DB = (BM == 256 && BN == 256);
+  constexpr int STAGE = (BM + BN) * 8;
+  __shared__ uint4 lds_all[(DB ? 2 : 1) * STAGE];  // per stage [row * 8 + chunk]: activations, then weights
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r = lane & 15;
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
   // ids b and b+8 share an L2.  All n-tiles of one m-tile get ids that are 8 apart: they run back to back on
@@ -136,9 +142,9 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const T *W = static_cast<const T *>(p.W);
 
   // ---- HBM -> LDS: thread handles linear LDS chunk positions it*NT + tid of each tile
-  const T *ga[4], *gw[WCH];
+  const T *ga[ACH], *gw[WCH];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < ACH; ++it) {
     const int pos = it * NT + tid;
     const int row = pos >> 3, cphys = pos & 7;
     const int clog = cphys ^ (row & 7);
@@ -159,11 +165,15 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   typedef const __attribute__((address_space(1))) void *glb_ptr;
   const int wave_u = uniform(wave);
   // one wave-instruction fills 1 KiB = 8 LDS rows; lane L writes chunk position it*NT + wave*64 + L
-#define CUM_GLDS(k0)                                                                                           \
-  _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                            \
-    __builtin_amdgcn_global_load_lds((glb_ptr)(ga[it] + (k0)), (lds_ptr)(&ldsA[it * NT + wave_u * 64]), 16, 0, 0); \
-  _Pragma("unroll") for (int it = 0; it < WCH; ++it)                                                          \
-    __builtin_amdgcn_global_load_lds((glb_ptr)(gw[it] + (k0)), (lds_ptr)(&ldsW[it * NT + wave_u * 64]), 16, 0, 0);
+#define CUM_GLDS(k0, stage)                                                                                    \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int it = 0; it < ACH; ++it)                                                        \
+      __builtin_amdgcn_global_load_lds((glb_ptr)(ga[it] + (k0)),                                               \
+                                       (lds_ptr)(&lds_all[(stage) * STAGE + it * NT + wave_u * 64]), 16, 0, 0);  \
+    _Pragma("unroll") for (int it = 0; it < WCH; ++it)                                                        \
+      __builtin_amdgcn_global_load_lds((glb_ptr)(gw[it] + (k0)),                                               \
+                                       (lds_ptr)(&lds_all[(stage) * STAGE + BM * 8 + it * NT + wave_u * 64]), 16, 0, 0); \
+  } while (0)
 
   f32x4 acc[4][4];  // [ni][mi]
 #pragma unroll
@@ -172,10 +182,15 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
+  if constexpr (DB) CUM_GLDS(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    CUM_GLDS(kt * BK);
+    if constexpr (!DB) CUM_GLDS(kt * BK, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();   // DB: stage kt has landed for every wave, and every wave is done reading stage kt-1
+    if constexpr (DB) {
+      if (kt + 1 < nk) CUM_GLDS((kt + 1) * BK, (kt + 1) & 1);
+    }
+    const uint4 *const ldsA = lds_all + (DB ? (kt & 1) * STAGE : 0), *const ldsW = ldsA + BM * 8;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(4, 4))) 
           for (int mi = 0; mi < 4; ++mi)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][s], af[mi][s], acc[ni][mi], 0, 0, 0);
     }
-    __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
+    if constexpr (!DB) __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
   }
 #undef CUM_GLDS
 
@@ -357,26 +372,44 @@ __global__ void colsum_stage2(const float *__restrict__ part, int nparts, int n,
   out[c] = s;
 }
 
-template <typename T, int BM>
-static int launch_gemm_bm(const GemmParams &p, int epi, hipStream_t st) {
+template <typename T, int BM, int BN>
+static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   const int NB = (p.N + BN - 1) / BN, MB = (p.M + BM - 1) / BM;
-  dim3 grid(8 * NB * ((MB + 7) / 8)), block(2 * BM);
+  dim3 grid(8 * NB * ((MB + 7) / 8)), block(BM * BN / 64);
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, BM>), grid, block, 0, st, p); break;
-    case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU, BM>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU, BM>), grid, block, 0, st, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, BM, BN>), grid, block, 0, st, p); break;
+    case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU, BM, BN>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU, BM, BN>), grid, block, 0, st, p); break;
   }
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }
 
+// CUM_NT_TILE=128|256|512 pins the tile (128x128 / 256x128 / 256x256) for experiments; default: heuristic below.
+static int nt_tile_override() {
+  static const int v = [] {
+    const char *e = getenv("CUM_NT_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 template <typename T>
 static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
-  // 256-row tiles once they still give every CU >= 2 workgroups per XCD-round; K >= 256 so the saved weight
-  // traffic matters (the outer layers are bound by their activation traffic, where tile height is irrelevant)
-  const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-  if (tiles256 >= 1024 && p.K >= 256) return launch_gemm_bm<T, 256>(p, epi, st);
-  return launch_gemm_bm<T, 128>(p, epi, st);
+  const int64_t mb256 = (p.M + 255) / 256;
+  const int64_t tiles_256x256 = mb256 * ((p.N + 255) / 256), tiles_256x128 = mb256 * ((p.N + 127) / 128);
+  int tile = nt_tile_override();
+  if (!tile) {
+    // 256x256 (one workgroup per CU) once it fills the chip and N wastes little of the 256-wide tile; 256-row
+    // tiles while they still give every CU >= 2 workgroups per XCD-round; K >= 256 so the saved weight traffic
+    // matters (the outer layers are bound by their activation traffic, where the tile shape is irrelevant)
+    if (p.K >= 256 && tiles_256x256 >= 224 && p.N % 256 == 0) tile = 512;
+    else if (p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
+    else tile = 128;
+  }
+  if (tile == 512) return launch_gemm_tile<T, 256, 256>(p, epi, st);
+  if (tile == 256) return launch_gemm_tile<T, 256, 128>(p, epi, st);
+  return launch_gemm_tile<T, 128, 128>(p, epi, st);
 }
 
 }  // namespace cum

@@ -35,14 +35,16 @@ namespace cum {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_GLU = 2 };
+enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_GLU = 2, EPI_MASK = 3, EPI_GLU_BWD = 4 };
 
 struct GemmParams {
   const void *A, *W;
   const float *bias;       // [N] (padded), may be null
   const void *res;         // residual [M][ldr], may be null; added AFTER the activation
+                           //   EPI_MASK: the ReLU output whose sign gates the result; EPI_GLU_BWD: added BEFORE the GLU backward
   void *out;               // [M][ldc]
-  void *aux;               // GLU: pre-activation [M][ldz] (N columns); else activation before the residual add
+  void *aux;               // GLU: pre-activation [M][ldz] (N columns); BIAS/RELU: activation before the residual add;
+                           //   EPI_MASK: the ungated result (second output); EPI_GLU_BWD: the saved pre-activation Z (input)
   int64_t lda, ldw, ldc, ldr, ldz;
   int M, N, K;             // N multiple of 16 (32 for GLU), K multiple of the K tile
   int pitch, valid;        // row m is real iff (m % pitch) < valid; other rows are stored as zeros
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(4,
   // The first workgroup also clears the rows that frame the output buffer (leading zero row, slack rows), so the
   // host never issues fill kernels for them.
   if (blockIdx.x == 0) {
-    T *o = static_cast<T *>(p.out), *x = (EPI != EPI_GLU) ? static_cast<T *>(p.aux) : nullptr;
+    T *o = static_cast<T *>(p.out), *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD) ? static_cast<T *>(p.aux) : nullptr;
     for (int64_t i = threadIdx.x; i < p.zero_head; i += NT) {
       o[-1 - i] = Elem<T>::from_f(0.f);
       if (x) x[-1 - i] = Elem<T>::from_f(0.f);
@@ -277,6 +279,49 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(4,
           store4<T>(out + (int64_t)m * p.ldc + oc, o);
         }
       }
+    } else if constexpr (EPI == EPI_GLU_BWD) {
+      // d = acc (+ res) is the gradient of a GLU output; the 16-column tile t of row m pairs with columns
+      // [32t, 32t+16) (a) and [32t+16, 32t+32) (b) of Z row m, and dZ is written in Z's layout.
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+        if (n >= p.n_store) continue;
+        const int64_t zc = 2 * (n0 + wn * 64 + ni * 16) + 4 * g;
+        float d[4], a[4], b[4], da[4], db[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = acc[ni][mi][j];
+        if (res) {
+          float rr[4];
+          load4<T>(res + (int64_t)m * p.ldr + n, rr);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] += rr[j];
+        }
+        load4<T>(aux + (int64_t)m * p.ldz + zc, a);
+        load4<T>(aux + (int64_t)m * p.ldz + zc + 16, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sg = sigmoidf_(b[j]);
+          const float dj = real ? d[j] : 0.f;
+          da[j] = dj * sg;
+          db[j] = dj * a[j] * sg * (1.f - sg);
+        }
+        store4<T>(out + (int64_t)m * p.ldc + zc, da);
+        store4<T>(out + (int64_t)m * p.ldc + zc + 16, db);
+      }
+    } else if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+        if (n >= p.n_store) continue;
+        float v[4], y[4];
+        load4<T>(res + (int64_t)m * p.ldr + n, y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = real ? acc[ni][mi][j] + (p.bias ? p.bias[n + j] : 0.f) : 0.f;
+        if (aux) store4<T>(aux + (int64_t)m * p.ldz + n, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
+        store4<T>(out + (int64_t)m * p.ldc + n, v);
+      }
     } else {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
@@ -379,6 +424,8 @@ static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   switch (epi) {
     case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, BM, BN>), grid, block, 0, st, p); break;
     case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU, BM, BN>), grid, block, 0, st, p); break;
+    case EPI_MASK: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_MASK, BM, BN>), grid, block, 0, st, p); break;
+    case EPI_GLU_BWD: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU_BWD, BM, BN>), grid, block, 0, st, p); break;
     default: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU, BM, BN>), grid, block, 0, st, p); break;
   }
   CUM_CHECK_LAUNCH();
@@ -420,7 +467,10 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
                            void *out, void *aux, void *stream) {
   CUM_REQUIRE(d && A && W && out, "gemm: null argument");
   CUM_REQUIRE(d->dtype == CUM_F32 || d->dtype == CUM_BF16, "gemm: dtype must be CUM_F32 or CUM_BF16");
-  CUM_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2, "gemm: bad epilogue");
+  CUM_REQUIRE(d->epilogue >= 0 && d->epilogue <= 4, "gemm: bad epilogue");
+  CUM_REQUIRE(d->epilogue != EPI_MASK || res, "gemm: the MASK epilogue needs the gating activation in res");
+  CUM_REQUIRE(d->epilogue != EPI_GLU_BWD || (aux && d->zero_head == 0 && d->zero_tail == 0),
+              "gemm: the GLU_BWD epilogue needs Z in aux and writes no framing rows");
   const int bk = d->dtype == CUM_BF16 ? 64 : 32;
   const int epc = d->dtype == CUM_BF16 ? 8 : 4;
   CUM_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0 && d->K % bk == 0, "gemm: K must be a positive multiple of the K tile");

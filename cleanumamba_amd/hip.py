@@ -47,7 +47,7 @@ class GemmDesc(ctypes.Structure):
 
 
 CUM_F32, CUM_BF16 = 0, 1
-EPI_BIAS, EPI_RELU, EPI_GLU = 0, 1, 2
+EPI_BIAS, EPI_RELU, EPI_GLU, EPI_MASK, EPI_GLU_BWD = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); mirrors include/cleanumamba_hip.h one to one.
 _P = ctypes.c_void_p

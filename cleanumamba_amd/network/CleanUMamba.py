@@ -19,6 +19,7 @@ Differences from the reference, on purpose:
 """
 import copy
 import itertools
+import os
 import time
 from functools import partial
 
@@ -115,6 +116,10 @@ class CleanUMamba(nn.Module):
         # are called as torch modules (needed only when forward hooks on the conv modules must fire, as the
         # reference's pruning tools expect); the Mamba bottleneck uses the HIP kernels either way.
         self.use_fused_convs = True
+        # True: the encoder and the decoder are one autograd node each (cs.EncoderStack / cs.DecoderStack) whose
+        # backward folds the ReLU gate, the GLU backward and the skip-gradient add into GEMM epilogues.  False: one
+        # node per layer with separate elementwise kernels (CUM_STACK_BACKWARD=0 selects it for A/B timing).
+        self.use_stack_backward = os.environ.get("CUM_STACK_BACKWARD", "1") != "0"
         # True: after the first hop of a stream the (launch-bound, ~100 tiny kernels) hop is captured once in a
         # hipGraph and replayed; stream state lives in static buffers updated in place.
         self.use_hop_graph = True
@@ -218,18 +223,26 @@ class CleanUMamba(nn.Module):
         cs.set_active_plan(plan)
         geo = cs.Geo(B, T0, 1)
         buf = cs.to_rows(x, geo, dt)
-        skips = []
+        enc_geos, enc_params = [], []
         for enc in self.encoder:
             T1 = (geo.T - self.kernel_size) // self.stride + 1
             g_mid = cs.Geo(B, T1, enc[0].weight.shape[0])
             if geo.P != 2 * g_mid.P:
                 raise RuntimeError("fused conv stack needs an input of valid_length()")
-            y1 = cs.ConvK4S2ReLU.apply(buf, enc[0].weight, enc[0].bias, geo, g_mid)
             g_out = cs.Geo(B, T1, enc[2].weight.shape[0] // 2)
-            buf = cs.PointwiseGLU.apply(y1, enc[2].weight, enc[2].bias, g_mid, g_out, save)
-            skips.append((buf, g_out))
+            enc_geos.append((geo, g_mid, g_out))
+            enc_params += [enc[0].weight, enc[0].bias, enc[2].weight, enc[2].bias]
             geo = g_out
-        skips = skips[::-1]
+        if getattr(self, "use_stack_backward", True):
+            outs = cs.EncoderStack.apply(buf, enc_geos, save, *enc_params)
+        else:                              # per-layer autograd nodes (unfused elementwise backward), kept for A/B runs
+            outs = []
+            for (gi, gm, go), enc in zip(enc_geos, self.encoder):
+                y1 = cs.ConvK4S2ReLU.apply(buf, enc[0].weight, enc[0].bias, gi, gm)
+                buf = cs.PointwiseGLU.apply(y1, enc[2].weight, enc[2].bias, gm, go, save)
+                outs.append(buf)
+        skips = [(b, g[2]) for b, g in zip(outs, enc_geos)][::-1]
+        buf = outs[-1]
 
         g_t = cs.Geo(B, geo.T, self.tsfm_conv1.weight.shape[0])
         hbuf = cs.Pointwise.apply(buf, self.tsfm_conv1.weight, self.tsfm_conv1.bias, None, geo, g_t)
@@ -244,17 +257,24 @@ class CleanUMamba(nn.Module):
         # tsfm_conv2 with the deepest skip added in its epilogue
         buf = cs.Pointwise.apply(tbuf, self.tsfm_conv2.weight, self.tsfm_conv2.bias, skips[0][0], g_t, geo)
 
+        dec_geos, dec_params, dec_skips = [], [], []
         for j, dec in enumerate(self.decoder):
             g_glu = cs.Geo(B, geo.T, dec[0].weight.shape[0] // 2)
-            gbuf = cs.PointwiseGLU.apply(buf, dec[0].weight, dec[0].bias, geo, g_glu, save)
-            last = j == E - 1
             g_out = cs.Geo(B, 2 * geo.T + 2, dec[2].weight.shape[1])
-            skip = None
-            if not last:
+            if j < E - 1:
                 skip, g_skip = skips[j + 1]
                 assert g_skip.T == g_out.T and g_skip.C == g_out.C
-            buf = cs.ConvT4S2.apply(gbuf, dec[2].weight, dec[2].bias, skip, g_glu, g_out, not last)
+                dec_skips.append(skip)
+            dec_geos.append((geo, g_glu, g_out))
+            dec_params += [dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias]
             geo = g_out
+        if getattr(self, "use_stack_backward", True):
+            buf = cs.DecoderStack.apply(buf, dec_geos, save, len(dec_skips), *dec_skips, *dec_params)
+        else:
+            for j, ((gi, gg, go), dec) in enumerate(zip(dec_geos, self.decoder)):
+                gbuf = cs.PointwiseGLU.apply(buf, dec[0].weight, dec[0].bias, gi, gg, save)
+                buf = cs.ConvT4S2.apply(gbuf, dec[2].weight, dec[2].bias, dec_skips[j] if j < E - 1 else None, gg, go,
+                                        j < E - 1)
         out = cs.from_rows(buf, geo).float()
         return out, [cs.from_rows(b, g) for b, g in skips], tsfm_out
 

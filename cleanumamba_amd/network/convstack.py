@@ -545,3 +545,247 @@ def supported(model):
         if not isinstance(enc[3].activation, torch.nn.Sigmoid) or not isinstance(dec[1].activation, torch.nn.Sigmoid):
             return False
     return True
+
+
+# ===================================================================== whole-stack Functions
+# The per-layer Functions above leave three elementwise passes per layer to the backward (ReLU gate, GLU
+# backward, the add that merges a skip gradient with the gradient from the next layer).  Chaining the layers
+# inside ONE backward lets each of them ride in the epilogue of the GEMM that produces its operand
+# (csrc/gemm.hip EPI_MASK / EPI_GLU_BWD): per layer the backward is then 2 data-gradient GEMMs + 2 weight-gradient
+# GEMMs and nothing else.  Forward kernels are the same as above.  Layers whose channel count is not a multiple
+# of 16 after padding (pruned checkpoints) keep the unfused elementwise kernels.
+def _glu_fwd(xbuf, w, b, gi, go, save_z):
+    dt, dev = xbuf.dtype, xbuf.device
+    H2, Cin, _ = w.shape
+    G = (H2 // 2 + 15) // 16
+    Kp = rup(gi.Cp, bk_of(dt))
+    sh = tuple(w.shape)
+    wp = take(w, ("glu_fwd", sh, G * 32, Kp), lambda: lay_glu_fwd(sh, G * 32, Kp), dt)
+    bp = take(b, ("glu_vec", H2), lambda: lay_glu_vec(H2), torch.float32)
+    ybuf = go.new(dt, dev)
+    z = torch.empty(go.M, G * 32, dtype=dt, device=dev) if save_z else None
+    gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_GLU, go.Cp,
+         aux=z, x_off=0, ldz=G * 32, geo=go)
+    return ybuf, z
+
+
+def _conv_relu_fwd(xbuf, w, b, gi, go):
+    dt, dev = xbuf.dtype, xbuf.device
+    H = w.shape[0]
+    Np, Kp = rup(H, 16), rup(4 * gi.Cp, bk_of(dt))
+    sh = tuple(w.shape)
+    wp = take(w, ("conv_fwd", sh, gi.Cp, Np, Kp), lambda: lay_conv_fwd(sh, gi.Cp, Np, Kp), dt)
+    bp = take(b, ("vec", H, Np), lambda: lay_vec(H, Np), torch.float32)
+    ybuf = go.new(dt, dev)
+    gemm(xbuf, gi.Cp, 2 * gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_RELU, go.Cp, geo=go)
+    return ybuf
+
+
+def _convt_fwd(xbuf, w, b, skip, gi, go, relu):
+    dt, dev = xbuf.dtype, xbuf.device
+    Cout = w.shape[1]
+    N = 2 * go.Cp
+    Np, Kp = rup(N, 16), rup(2 * gi.Cp, bk_of(dt))
+    sh = tuple(w.shape)
+    wp = take(w, ("convt_fwd", sh, gi.Cp, go.Cp, Np, Kp), lambda: lay_convt_fwd(sh, gi.Cp, go.Cp, Np, Kp), dt)
+
+    def bias_layout():
+        out = torch.zeros(Np, dtype=torch.int64)
+        out[:N].view(2, go.Cp)[:, :Cout] = _ids((Cout,))
+        return out
+    bp = take(b, ("convt_vec", Cout, go.Cp, Np), bias_layout, torch.float32)
+    ybuf = go.new(dt, dev)
+    keep = relu and skip is not None            # the ReLU mask is not recoverable from y + skip
+    act = go.new(dt, dev) if keep else None
+    gemm(xbuf, 0, gi.Cp, wp, bp, ybuf, go.Cp, N, gi.M, gi.P, gi.T + 1, hip.EPI_RELU if relu else hip.EPI_BIAS, N,
+         res=skip, r_off=go.Cp, ldr=N, aux=act, x_off=go.Cp, ldz=N, geo=go)
+    return ybuf, (act if keep else (ybuf if relu else None))
+
+
+def _glu_bwd(z, dy, go):
+    """Standalone GLU backward: dy is a row buffer of geometry go, z / result are [go.M, G*32]."""
+    G = z.shape[1] // 32
+    dz = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        hip.check(hip.lib().cum_glu_bwd(hip.dtype_code(z.dtype), go.M, G, go.Cp, hip.ptr(z), G * 32, hip.ptr(dy[1:]),
+                                        go.Cp, hip.ptr(dz), hip.stream_ptr()))
+    return dz
+
+
+def _glu_wgrad(dz, xbuf, w, gi, M):
+    """Weight / bias gradient of a 1x1+GLU layer from dZ [M, G*32] and its input row buffer."""
+    G32 = dz.shape[1]
+    H2 = w.shape[0]
+    sh = tuple(w.shape)
+    dwp, dbp = wgrad(dz, 0, G32, G32, xbuf, gi.Cp, gi.Cp, gi.Cp, M)
+    db = take(dbp, ("glu_vec_unpack", H2), lambda: _invert(lay_glu_vec(H2), (H2,)))
+    dw = take(dwp, ("glu_unpack", sh, G32, gi.Cp), lambda: _invert(lay_glu_fwd(sh, G32, gi.Cp), sh))
+    return dw.to(w.dtype), db.to(w.dtype)
+
+
+def _glu_dgrad_weights(w, gi, G32, dt):
+    sh = tuple(w.shape)
+    Nd, Kd = rup(gi.Cp, 16), rup(G32, bk_of(dt))
+    return take(w, ("glu_dgrad", sh, Nd, Kd),
+                lambda: torch.nn.functional.pad(lay_glu_fwd(sh, G32, Nd).t(), (0, Kd - G32)), dt)
+
+
+class EncoderStack(torch.autograd.Function):
+    """x -> (x_1, ..., x_E): every encoder layer [Conv1d k4 s2, ReLU, Conv1d 1x1, GLU]
+    (src/network/CleanUMamba.py:108-113) on row buffers.  geos[i] = (g_in, g_mid, g_out); params = w1, b1, w2, b2
+    per layer."""
+
+    @staticmethod
+    def forward(ctx, xbuf, geos, save_z, *params):
+        bufs, y1s, zs = [xbuf], [], []
+        for i, (gi, gm, go) in enumerate(geos):
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            assert gi.P == 2 * gm.P and gm.T == go.T and gi.C == w1.shape[1] and gm.C == w1.shape[0] == w2.shape[1]
+            y1 = _conv_relu_fwd(bufs[-1], w1, b1, gi, gm)
+            y, z = _glu_fwd(y1, w2, b2, gm, go, save_z)
+            bufs.append(y)
+            y1s.append(y1)
+            zs.append(z)
+        ctx.geos, ctx.E, ctx.saved_z = geos, len(geos), save_z
+        ctx.save_for_backward(*bufs, *y1s, *[z for z in zs if z is not None], *params)
+        return tuple(bufs[1:])
+
+    @staticmethod
+    def backward(ctx, *dys):
+        if not ctx.saved_z:
+            raise RuntimeError("EncoderStack was run without save_z; backward is unavailable")
+        E, geos = ctx.E, ctx.geos
+        t = ctx.saved_tensors
+        bufs, y1s, zs, params = t[:E + 1], t[E + 1:2 * E + 1], t[2 * E + 1:3 * E + 1], t[3 * E + 1:]
+        dt, dev = bufs[0].dtype, bufs[0].device
+        grads = [None] * (4 * E)
+        dz, dx0 = None, None
+        for i in reversed(range(E)):
+            gi, gm, go = geos[i]
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            if dz is None:                     # top layer: its output gradient arrives from outside only
+                if dys[i] is None:
+                    raise RuntimeError("EncoderStack: the deepest output must be used")
+                dz = _glu_bwd(zs[i], dys[i].contiguous(), go)
+            G32 = dz.shape[1]
+            grads[4 * i + 2], grads[4 * i + 3] = _glu_wgrad(dz, y1s[i], w2, gm, go.M)
+            # 1x1 data gradient, gated by the ReLU below it in the epilogue
+            wt = _glu_dgrad_weights(w2, gm, G32, dt)
+            dzc = gm.new(dt, dev)
+            gemm(dz, 0, G32, wt, None, dzc, gm.Cp, gm.Cp, gm.M, gm.P, gm.T, hip.EPI_MASK, gm.Cp,
+                 res=y1s[i], r_off=gm.Cp, ldr=gm.Cp, geo=gm)
+            # conv weight gradient: X row m = the 4*Cp contiguous inputs of output row m
+            sh = tuple(w1.shape)
+            dwp, dbp = wgrad(dzc, gm.Cp, gm.Cp, gm.Cp, bufs[i], gi.Cp, 2 * gi.Cp, 4 * gi.Cp, gm.M)
+            grads[4 * i] = take(dwp, ("conv_unpack", sh, gi.Cp, gm.Cp),
+                                lambda: _invert(lay_conv_fwd(sh, gi.Cp, gm.Cp, 4 * gi.Cp), sh)).to(w1.dtype)
+            grads[4 * i + 1] = dbp[:sh[0]].to(w1.dtype)
+            dz = None
+            if i == 0 and not ctx.needs_input_grad[0]:
+                break
+            # conv data gradient = transposed conv: pair row t' reads dzc rows t'-1, t'
+            Nd, Kd = rup(2 * gi.Cp, 16), rup(2 * gm.Cp, bk_of(dt))
+            wd = take(w1, ("conv_dgrad", sh, gi.Cp, gm.Cp, Nd, Kd), lambda: lay_conv_dgrad(sh, gi.Cp, gm.Cp, Nd, Kd), dt)
+            ext = None if i == 0 or dys[i - 1] is None else dys[i - 1].contiguous()
+            if i > 0 and gi.Cp % 16 == 0:
+                # ... + the skip gradient, pushed through the GLU of layer i-1 in the epilogue: dZ_{i-1} directly
+                zp = zs[i - 1]
+                dz = torch.empty_like(zp)
+                gemm(dzc, 0, gm.Cp, wd, None, dz, 0, 4 * gi.Cp, gm.M, gm.P, gm.T + 1, hip.EPI_GLU_BWD, 2 * gi.Cp,
+                     res=ext, r_off=gi.Cp, ldr=2 * gi.Cp, aux=zp, x_off=0, ldz=4 * gi.Cp)
+                continue
+            dx = gi.new(dt, dev)
+            gemm(dzc, 0, gm.Cp, wd, None, dx, gi.Cp, 2 * gi.Cp, gm.M, gm.P, gm.T + 1, hip.EPI_BIAS, 2 * gi.Cp, geo=gi)
+            if i == 0:
+                dx0 = dx
+            else:
+                dz = _glu_bwd(zs[i - 1], dx if ext is None else dx + ext, gi)
+        return (dx0, None, None, *grads)
+
+
+class DecoderStack(torch.autograd.Function):
+    """u_0 -> u_E: every decoder layer [Conv1d 1x1, GLU, ConvTranspose1d k4 s2, (ReLU)] with the encoder skip added
+    to its output (src/network/CleanUMamba.py:121-130, 313-316).  geos[j] = (g_in, g_glu, g_out); skips[j] is added
+    to the output of layer j (None for the last); params = w1, b1, wt, bt per layer; ReLU on all but the last layer."""
+
+    @staticmethod
+    def forward(ctx, ubuf, geos, save_z, n_skips, *rest):
+        E = len(geos)
+        skips, params = list(rest[:n_skips]) + [None] * (E - n_skips), rest[n_skips:]
+        us, gs, zs, acts = [ubuf], [], [], []
+        for j, (gi, gg, go) in enumerate(geos):
+            w1, b1, wt, bt = params[4 * j:4 * j + 4]
+            assert gi.T == gg.T and go.P == 2 * gg.P and gg.C == wt.shape[0] and go.C == wt.shape[1]
+            g, z = _glu_fwd(us[-1], w1, b1, gi, gg, save_z)
+            relu = j < E - 1
+            y, act = _convt_fwd(g, wt, bt, skips[j], gg, go, relu)
+            us.append(y)
+            gs.append(g)
+            zs.append(z)
+            acts.append(act)
+        ctx.geos, ctx.E, ctx.saved_z, ctx.n_skips = geos, E, save_z, n_skips
+        ctx.has_act = [a is not None for a in acts]
+        ctx.save_for_backward(*us[:E], *gs, *[z for z in zs if z is not None], *[a for a in acts if a is not None],
+                              *params)
+        return us[E]
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.saved_z:
+            raise RuntimeError("DecoderStack was run without save_z; backward is unavailable")
+        E, geos = ctx.E, ctx.geos
+        t = ctx.saved_tensors
+        us, gs, zs = t[:E], t[E:2 * E], t[2 * E:3 * E]
+        n_act = sum(ctx.has_act)
+        kept, params = list(t[3 * E:3 * E + n_act]), t[3 * E + n_act:]
+        acts = [kept.pop(0) if h else None for h in ctx.has_act]
+        dt, dev = us[0].dtype, us[0].device
+        grads = [None] * (4 * E)
+        dskips = [None] * ctx.n_skips
+        gi, gg, go = geos[E - 1]
+        dpre = dy.contiguous()
+        if acts[E - 1] is not None:            # a ReLU on the last layer (not the reference's configuration)
+            gated = go.new(dt, dev)
+            with torch.cuda.device(dev):
+                hip.check(hip.lib().cum_relu_bwd(hip.dtype_code(dt), go.M, go.Cp, hip.ptr(acts[E - 1][1:]), go.Cp,
+                                                 hip.ptr(dpre[1:]), go.Cp, hip.ptr(gated[1:]), go.Cp, go.head, go.tail,
+                                                 hip.stream_ptr()))
+            dpre = gated
+        du = None
+        for j in reversed(range(E)):
+            gi, gg, go = geos[j]
+            w1, b1, wt, bt = params[4 * j:4 * j + 4]
+            sht = tuple(wt.shape)
+            # transposed-conv weight gradient: pair rows of dpre against the 2*Cp contiguous inputs (rows m-1, m)
+            dwp, dbp = wgrad(dpre, go.Cp, 2 * go.Cp, 2 * go.Cp, gs[j], 0, gg.Cp, 2 * gg.Cp, gg.M)
+            grads[4 * j + 3] = (dbp[:go.Cp] + dbp[go.Cp:])[:sht[1]].to(wt.dtype)
+            grads[4 * j + 2] = take(dwp, ("convt_unpack", sht, gg.Cp, go.Cp),
+                                    lambda: _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)).to(wt.dtype)
+            # its data gradient = strided conv of dpre (row t reads rows 2t..2t+3), through the GLU in the epilogue
+            Nd, Kd = rup(gg.Cp, 16), rup(4 * go.Cp, bk_of(dt))
+            wc = take(wt, ("convt_dgrad", sht, go.Cp, Nd, Kd), lambda: lay_convt_dgrad(sht, go.Cp, Nd, Kd), dt)
+            z = zs[j]
+            G32 = z.shape[1]
+            if gg.Cp % 16 == 0:
+                dz = torch.empty_like(z)
+                gemm(dpre, go.Cp, 2 * go.Cp, wc, None, dz, 0, G32, gg.M, gg.P, gg.T, hip.EPI_GLU_BWD, gg.Cp,
+                     aux=z, x_off=0, ldz=G32)
+            else:
+                dg = gg.new(dt, dev)
+                gemm(dpre, go.Cp, 2 * go.Cp, wc, None, dg, gg.Cp, gg.Cp, gg.M, gg.P, gg.T, hip.EPI_BIAS, gg.Cp, geo=gg)
+                dz = _glu_bwd(z, dg, gg)
+            grads[4 * j], grads[4 * j + 1] = _glu_wgrad(dz, us[j], w1, gi, gg.M)
+            # 1x1 data gradient: ungated it is the gradient of u_j (and of the skip added into it); gated by the ReLU
+            # of layer j-1 it is that layer's dpre -- both written by one epilogue
+            w1t = _glu_dgrad_weights(w1, gi, G32, dt)
+            du = gi.new(dt, dev)
+            if j > 0 and acts[j - 1] is not None:
+                dpre = gi.new(dt, dev)
+                gemm(dz, 0, G32, w1t, None, dpre, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_MASK, gi.Cp,
+                     res=acts[j - 1], r_off=gi.Cp, ldr=gi.Cp, aux=du, x_off=gi.Cp, ldz=gi.Cp, geo=gi)
+            else:
+                gemm(dz, 0, G32, w1t, None, du, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp, geo=gi)
+                dpre = du
+            if j > 0 and j - 1 < ctx.n_skips:
+                dskips[j - 1] = du
+        return (du, None, None, None, *dskips, *grads)

@@ -153,6 +153,15 @@ int cum_causal_conv1d_update(int32_t batch, int32_t dim, int32_t width, float *c
  * 32 rows; the output has N/2 columns).  Rows with (m % pitch) >= valid are written as
  * zeros.  aux (optional): GLU -> the pre-activation [M][ldz] (N columns);
  * otherwise -> the activation before the residual add.  res is added after the activation.
+ * Two backward-data epilogues fold the elementwise backward of the NEXT op into the GEMM
+ * that produces its input gradient (autograd of ReLU / GLU in the same reference lines):
+ *   3 (MASK): res = the ReLU output Y of the layer below; out = (Y > 0) ? acc + bias : 0 and,
+ *     if aux != NULL, aux = acc + bias ungated (the gradient that also feeds a skip path);
+ *   4 (GLU_BWD): d = acc (+ res, e.g. the gradient arriving over a skip path) is the gradient
+ *     of a GLU output; aux = its saved pre-activation Z (INPUT, [M][ldz], 16 a | 16 b per 32
+ *     columns); out = dZ in Z's layout ([M][ldc]): for the 16-column tile t of row m,
+ *     out[32t + j] = d_j * sig(b_j), out[32t + 16 + j] = d_j * a_j * sig(b_j) * (1 - sig(b_j)).
+ *     n_store counts columns of d; zero_head / zero_tail must be 0.
  * dtype: element type of A, W, res, out, aux; accumulation is always f32. */
 #define CUM_F32 0
 #define CUM_BF16 1

@@ -34,3 +34,6 @@ print(f"total self device time per step: {tot / steps / 1e3:.2f} ms")
 for e in rows[:160]:
     shapes = str(e.input_shapes)[:110]
     print(f"{e.self_device_time_total / steps / 1e3:8.3f} ms {e.count / steps:6.1f}x  {e.key[:40]:40s} {shapes}")
+print("---- by CPU time")
+for e in sorted(ka, key=lambda e: -e.self_cpu_time_total)[:25]:
+    print(f"{e.self_cpu_time_total / steps / 1e3:8.3f} ms cpu {e.count / steps:6.1f}x  {e.key[:50]:50s} {str(e.input_shapes)[:60]}")

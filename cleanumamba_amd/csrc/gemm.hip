@@ -94,6 +94,180 @@ __device__ __forceinline__ void load4<__bf16>(const __bf16 *p, float (&v)[4]) {
   for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
 }
 
+// One K-step of a wave's 64x64 sub-tile from the staged tiles (ldsA / ldsW: [row * 8 + chunk], chunk index
+// XOR-swizzled by row & 7).
+template <typename T>
+__device__ __forceinline__ void nt_compute(const uint4 *ldsA, const uint4 *ldsW, f32x4 (&acc)[4][4], int wm, int wn,
+                                           int g, int r) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int wrow = wn * 64 + i * 16 + r;
+        const int arow = wm * 64 + i * 16 + r;
+        const int cl = ks * 4 + g;
+        wf[i] = __builtin_bit_cast(bf16x8, ldsW[wrow * 8 + (cl ^ (wrow & 7))]);
+        af[i] = __builtin_bit_cast(bf16x8, ldsA[arow * 8 + (cl ^ (arow & 7))]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+  } else {
+    // f32: lane reads k = 8g .. 8g+7 (two chunks) of its row; MFMA k-slot g at sub-step s is k = 8g + s
+    // for BOTH operands, so the dot product is a permutation of the same 32 products.
+    float wf[4][8], af[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int wrow = wn * 64 + i * 16 + r;
+      const int arow = wm * 64 + i * 16 + r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cl = 2 * g + h;
+        const uint4 wv = ldsW[wrow * 8 + (cl ^ (wrow & 7))];
+        const uint4 av = ldsA[arow * 8 + (cl ^ (arow & 7))];
+        wf[i][4 * h + 0] = __builtin_bit_cast(float, wv.x); wf[i][4 * h + 1] = __builtin_bit_cast(float, wv.y);
+        wf[i][4 * h + 2] = __builtin_bit_cast(float, wv.z); wf[i][4 * h + 3] = __builtin_bit_cast(float, wv.w);
+        af[i][4 * h + 0] = __builtin_bit_cast(float, av.x); af[i][4 * h + 1] = __builtin_bit_cast(float, av.y);
+        af[i][4 * h + 2] = __builtin_bit_cast(float, av.z); af[i][4 * h + 3] = __builtin_bit_cast(float, av.w);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][s], af[mi][s], acc[ni][mi], 0, 0, 0);
+  }
+}
+
+// The 16 bias values a lane adds in the epilogue (columns n0 + 64 wn + 16 ni + 4 g + j), fetched with four 16-byte
+// loads BEFORE the K loop: loaded inside the epilogue they were 64 dependent L2 round trips per lane, which made the
+// epilogue -- not HBM -- the bound of every layer with few K steps.
+__device__ __forceinline__ void nt_load_bias(const GemmParams &p, int n0, int wn, int g, float (&bv)[4][4]) {
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n + 3 < p.N) t = *reinterpret_cast<const float4 *>(p.bias + n);
+    bv[ni][0] = t.x; bv[ni][1] = t.y; bv[ni][2] = t.z; bv[ni][3] = t.w;
+  }
+}
+
+// Epilogue of a wave's 64x64 sub-tile at (m0 + 64 wm, n0 + 64 wn).
+template <typename T, int EPI>
+__device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&acc)[4][4], const float (&bv)[4][4],
+                                            int m0, int n0, int wm, int wn, int g, int r) {
+  // ---- epilogue: lane holds D[n = nb + 4g + j][m = mb + r], j = 0..3 -> 4 consecutive channels of row m
+  T *out = static_cast<T *>(p.out);
+  T *aux = static_cast<T *>(p.aux);
+  const T *res = static_cast<const T *>(p.res);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + r;
+    if (m >= p.M) continue;
+    const bool real = (m % p.pitch) < p.valid;
+    if constexpr (EPI == EPI_GLU) {
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {  // tile pair (2*pi, 2*pi+1) = (a, b)
+        const int na = n0 + wn * 64 + (2 * pi) * 16 + 4 * g;
+        const int nb = na + 16;
+        if (na >= p.N) continue;
+        float a[4], b[4], o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[j] = acc[2 * pi][mi][j] + bv[2 * pi][j];
+          b[j] = acc[2 * pi + 1][mi][j] + bv[2 * pi + 1][j];
+          o[j] = real ? a[j] * sigmoidf_(b[j]) : 0.f;
+        }
+        if (aux) {
+          store4<T>(aux + (int64_t)m * p.ldz + na, a);
+          store4<T>(aux + (int64_t)m * p.ldz + nb, b);
+        }
+        const int oc = (n0 + wn * 64) / 2 + pi * 16 + 4 * g;
+        if (oc < p.n_store) {
+          if (res) {
+            float rr[4];
+            load4<T>(res + (int64_t)m * p.ldr + oc, rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
+          }
+          store4<T>(out + (int64_t)m * p.ldc + oc, o);
+        }
+      }
+    } else if constexpr (EPI == EPI_GLU_BWD) {
+      // d = acc (+ res) is the gradient of a GLU output; the 16-column tile t of row m pairs with columns
+      // [32t, 32t+16) (a) and [32t+16, 32t+32) (b) of Z row m, and dZ is written in Z's layout.
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+        if (n >= p.n_store) continue;
+        const int64_t zc = 2 * (n0 + wn * 64 + ni * 16) + 4 * g;
+        float d[4], a[4], b[4], da[4], db[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = acc[ni][mi][j];
+        if (res) {
+          float rr[4];
+          load4<T>(res + (int64_t)m * p.ldr + n, rr);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] += rr[j];
+        }
+        load4<T>(aux + (int64_t)m * p.ldz + zc, a);
+        load4<T>(aux + (int64_t)m * p.ldz + zc + 16, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sg = sigmoidf_(b[j]);
+          const float dj = real ? d[j] : 0.f;
+          da[j] = dj * sg;
+          db[j] = dj * a[j] * sg * (1.f - sg);
+        }
+        store4<T>(out + (int64_t)m * p.ldc + zc, da);
+        store4<T>(out + (int64_t)m * p.ldc + zc + 16, db);
+      }
+    } else if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+        if (n >= p.n_store) continue;
+        float v[4], y[4];
+        load4<T>(res + (int64_t)m * p.ldr + n, y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = real ? acc[ni][mi][j] + bv[ni][j] : 0.f;
+        if (aux) store4<T>(aux + (int64_t)m * p.ldz + n, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
+        store4<T>(out + (int64_t)m * p.ldc + n, v);
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+        if (n >= p.n_store) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[ni][mi][j] + bv[ni][j];
+          if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
+          v[j] = real ? v[j] : 0.f;
+        }
+        if (aux) store4<T>(aux + (int64_t)m * p.ldz + n, v);
+        if (res) {
+          float rr[4];
+          load4<T>(res + (int64_t)m * p.ldr + n, rr);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = real ? v[j] + rr[j] : 0.f;
+        }
+        store4<T>(out + (int64_t)m * p.ldc + n, v);
+      }
+    }
+  }
+}
+
 // Block tiles BM x BN, one wave per 64x64 sub-tile:
 //   128x128 (4 waves, 32 KB LDS, 4 workgroups/CU), 256x128 (8 waves, 48 KB, 2-3 workgroups/CU): single LDS
 //   buffer, the interleaving of the co-resident workgroups hides the load latency;
@@ -183,6 +357,8 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float bv[4][4];
+  nt_load_bias(p, n0, wn, g, bv);
   const int nk = p.K / BK;
   if constexpr (DB) CUM_GLDS(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -193,158 +369,12 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(4,
       if (kt + 1 < nk) CUM_GLDS((kt + 1) * BK, (kt + 1) & 1);
     }
     const uint4 *const ldsA = lds_all + (DB ? (kt & 1) * STAGE : 0), *const ldsW = ldsA + BM * 8;
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 wf[4], af[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int wrow = wn * 64 + i * 16 + r;
-          const int arow = wm * 64 + i * 16 + r;
-          const int cl = ks * 4 + g;
-          wf[i] = __builtin_bit_cast(bf16x8, ldsW[wrow * 8 + (cl ^ (wrow & 7))]);
-          af[i] = __builtin_bit_cast(bf16x8, ldsA[arow * 8 + (cl ^ (arow & 7))]);
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-      }
-    } else {
-      // f32: lane reads k = 8g .. 8g+7 (two chunks) of its row; MFMA k-slot g at sub-step s is k = 8g + s
-      // for BOTH operands, so the dot product is a permutation of the same 32 products.
-      float wf[4][8], af[4][8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int wrow = wn * 64 + i * 16 + r;
-        const int arow = wm * 64 + i * 16 + r;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int cl = 2 * g + h;
-          const uint4 wv = ldsW[wrow * 8 + (cl ^ (wrow & 7))];
-          const uint4 av = ldsA[arow * 8 + (cl ^ (arow & 7))];
-          wf[i][4 * h + 0] = __builtin_bit_cast(float, wv.x); wf[i][4 * h + 1] = __builtin_bit_cast(float, wv.y);
-          wf[i][4 * h + 2] = __builtin_bit_cast(float, wv.z); wf[i][4 * h + 3] = __builtin_bit_cast(float, wv.w);
-          af[i][4 * h + 0] = __builtin_bit_cast(float, av.x); af[i][4 * h + 1] = __builtin_bit_cast(float, av.y);
-          af[i][4 * h + 2] = __builtin_bit_cast(float, av.z); af[i][4 * h + 3] = __builtin_bit_cast(float, av.w);
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][s], af[mi][s], acc[ni][mi], 0, 0, 0);
-    }
+    nt_compute<T>(ldsA, ldsW, acc, wm, wn, g, r);
     if constexpr (!DB) __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
   }
 #undef CUM_GLDS
 
-  // ---- epilogue: lane holds D[n = nb + 4g + j][m = mb + r], j = 0..3 -> 4 consecutive channels of row m
-  T *out = static_cast<T *>(p.out);
-  T *aux = static_cast<T *>(p.aux);
-  const T *res = static_cast<const T *>(p.res);
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + r;
-    if (m >= p.M) continue;
-    const bool real = (m % p.pitch) < p.valid;
-    if constexpr (EPI == EPI_GLU) {
-#pragma unroll
-      for (int pi = 0; pi < 2; ++pi) {  // tile pair (2*pi, 2*pi+1) = (a, b)
-        const int na = n0 + wn * 64 + (2 * pi) * 16 + 4 * g;
-        const int nb = na + 16;
-        if (na >= p.N) continue;
-        float a[4], b[4], o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          a[j] = acc[2 * pi][mi][j] + (p.bias ? p.bias[na + j] : 0.f);
-          b[j] = acc[2 * pi + 1][mi][j] + (p.bias ? p.bias[nb + j] : 0.f);
-          o[j] = real ? a[j] * sigmoidf_(b[j]) : 0.f;
-        }
-        if (aux) {
-          store4<T>(aux + (int64_t)m * p.ldz + na, a);
-          store4<T>(aux + (int64_t)m * p.ldz + nb, b);
-        }
-        const int oc = (n0 + wn * 64) / 2 + pi * 16 + 4 * g;
-        if (oc < p.n_store) {
-          if (res) {
-            float rr[4];
-            load4<T>(res + (int64_t)m * p.ldr + oc, rr);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
-          }
-          store4<T>(out + (int64_t)m * p.ldc + oc, o);
-        }
-      }
-    } else if constexpr (EPI == EPI_GLU_BWD) {
-      // d = acc (+ res) is the gradient of a GLU output; the 16-column tile t of row m pairs with columns
-      // [32t, 32t+16) (a) and [32t+16, 32t+32) (b) of Z row m, and dZ is written in Z's layout.
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-        if (n >= p.n_store) continue;
-        const int64_t zc = 2 * (n0 + wn * 64 + ni * 16) + 4 * g;
-        float d[4], a[4], b[4], da[4], db[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = acc[ni][mi][j];
-        if (res) {
-          float rr[4];
-          load4<T>(res + (int64_t)m * p.ldr + n, rr);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[j] += rr[j];
-        }
-        load4<T>(aux + (int64_t)m * p.ldz + zc, a);
-        load4<T>(aux + (int64_t)m * p.ldz + zc + 16, b);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float sg = sigmoidf_(b[j]);
-          const float dj = real ? d[j] : 0.f;
-          da[j] = dj * sg;
-          db[j] = dj * a[j] * sg * (1.f - sg);
-        }
-        store4<T>(out + (int64_t)m * p.ldc + zc, da);
-        store4<T>(out + (int64_t)m * p.ldc + zc + 16, db);
-      }
-    } else if constexpr (EPI == EPI_MASK) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-        if (n >= p.n_store) continue;
-        float v[4], y[4];
-        load4<T>(res + (int64_t)m * p.ldr + n, y);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = real ? acc[ni][mi][j] + (p.bias ? p.bias[n + j] : 0.f) : 0.f;
-        if (aux) store4<T>(aux + (int64_t)m * p.ldz + n, v);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
-        store4<T>(out + (int64_t)m * p.ldc + n, v);
-      }
-    } else {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-        if (n >= p.n_store) continue;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = acc[ni][mi][j] + (p.bias ? p.bias[n + j] : 0.f);
-          if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
-          v[j] = real ? v[j] : 0.f;
-        }
-        if (aux) store4<T>(aux + (int64_t)m * p.ldz + n, v);
-        if (res) {
-          float rr[4];
-          load4<T>(res + (int64_t)m * p.ldr + n, rr);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = real ? v[j] + rr[j] : 0.f;
-        }
-        store4<T>(out + (int64_t)m * p.ldc + n, v);
-      }
-    }
-  }
+  nt_epilogue<T, EPI>(p, acc, bv, m0, n0, wm, wn, g, r);
 }
 
 // ---------------------------------------------------------------- elementwise backward
@@ -478,7 +508,8 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
   CUM_REQUIRE(d->lda % epc == 0 && d->ldw % epc == 0, "gemm: lda/ldw must keep rows 16-byte aligned");
   CUM_REQUIRE(d->ldc % 4 == 0 && d->ldr % 4 == 0 && d->ldz % 4 == 0 && d->n_store % 4 == 0, "gemm: ldc/ldr/ldz/n_store must be multiples of 4");
   CUM_REQUIRE(d->pitch > 0 && d->valid >= 0 && d->zero_head >= 0 && d->zero_tail >= 0, "gemm: bad pitch/valid/zero ranges");
-  CUM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A and W must be 16-byte aligned");
+  CUM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)bias & 15) == 0,
+              "gemm: A, W and bias must be 16-byte aligned");
   if (d->M == 0) return CUM_OK;
   GemmParams p{};
   p.A = A; p.W = W; p.bias = bias; p.res = res; p.out = out; p.aux = aux;

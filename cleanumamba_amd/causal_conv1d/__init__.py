@@ -4,6 +4,9 @@ Same signatures as causal-conv1d 1.1.0 (call pattern in the reference:
 src/network/S4/MambaS4.py:454-463; torch equivalent ``act(conv1d(x)[..., :L])`` at
 :455).  x: (B, D, L) logical, any strides (channel-contiguous preferred);
 weight: (D, W); W <= 4.  No CPU path.
+
+x may be float32 or bfloat16 (what autocast hands over): the kernels read and write that element type
+directly (cum_conv_shape.io_dtype) and compute in fp32; weights and their gradients are always fp32.
 """
 import ctypes
 
@@ -19,6 +22,7 @@ def _shape(x, y, width, silu):
     s.x_sb, s.x_sd, s.x_sl = x.stride()
     s.y_sb, s.y_sd, s.y_sl = y.stride()
     s.silu = int(silu)
+    s.io_dtype = hip.dtype_code(x.dtype)
     return s
 
 
@@ -30,11 +34,13 @@ def _alloc_like(x):
 
 class CausalConv1dFn(torch.autograd.Function):
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, bias=None, activation=None):
         if activation not in (None, "silu", "swish"):
             raise NotImplementedError("activation must be None, silu, or swish")
-        hip.require_gpu(x, weight, bias)
+        hip.require_gpu(x, any_dtype=True)
+        hip.require_gpu(weight, bias)
+        hip.dtype_code(x.dtype)
         if x.dim() != 3 or weight.dim() != 2 or weight.shape[0] != x.shape[1]:
             raise RuntimeError("causal_conv1d: x must be (B, D, L) and weight (D, W)")
         weight = weight.contiguous()
@@ -53,7 +59,7 @@ class CausalConv1dFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
-        dy = dy.float()
+        dy = dy.to(x.dtype)
         lib = hip.lib()
         dx = _alloc_like(x)
         dw = torch.empty_like(weight)
@@ -71,8 +77,9 @@ class CausalConv1dFn(torch.autograd.Function):
 
 def causal_conv1d_fn(x, weight, bias=None, activation=None):
     in_dtype = x.dtype
-    return CausalConv1dFn.apply(x.float(), weight.float(), None if bias is None else bias.float(),
-                                activation).to(in_dtype)
+    if in_dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    return CausalConv1dFn.apply(x, weight.float(), None if bias is None else bias.float(), activation).to(in_dtype)
 
 
 @torch.no_grad()

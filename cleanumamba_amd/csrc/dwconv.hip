@@ -16,13 +16,15 @@ constexpr int MAXW = 4;   // kernel width supported (reference uses d_conv = 4)
 
 struct ConvParams {
   cum_conv_shape s;
-  const float *x, *w, *bias, *dy;
-  float *y, *dx, *ws;   // ws: [batch * nchunks][MAXW + 1][dim] partial dweight / dbias
+  const void *x, *dy;    // x, y, dy, dx: elements of s.io_dtype
+  const float *w, *bias;
+  void *y, *dx;
+  float *ws;   // ws: [batch * nchunks][MAXW + 1][dim] partial dweight / dbias
   int64_t dx_sb, dx_sd, dx_sl;
   int nchunks;
 };
 
-template <int W>
+template <int W, typename TIO>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ConvParams p) {
   const int lane = threadIdx.x & 63;
   const int d = blockIdx.x * 64 + lane;
@@ -35,14 +37,14 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ConvParams p) {
 #pragma unroll
   for (int k = 0; k < W; ++k) wk[k] = p.w[d * W + k];
   const float bs = p.bias ? p.bias[d] : 0.f;
-  const float *xp = p.x + b * p.s.x_sb + d * p.s.x_sd;
-  float *yp = p.y + b * p.s.y_sb + d * p.s.y_sd;
+  const TIO *xp = static_cast<const TIO *>(p.x) + b * p.s.x_sb + d * p.s.x_sd;
+  TIO *yp = static_cast<TIO *>(p.y) + b * p.s.y_sb + d * p.s.y_sd;
   float xv[TC + W - 1];
 #pragma unroll
   for (int i = 0; i < TC + W - 1; ++i) {
     const int t = t0 - (W - 1) + i;
     const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
-    const float v = xp[(int64_t)tc * p.s.x_sl];
+    const float v = (float)xp[(int64_t)tc * p.s.x_sl];
     xv[i] = (t >= 0 && t < L) ? v : 0.f;
   }
 #pragma unroll
@@ -52,11 +54,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ConvParams p) {
 #pragma unroll
     for (int k = 0; k < W; ++k) acc = fmaf(wk[k], xv[i + k], acc);
     if (p.s.silu) acc = acc * sigmoidf_(acc);
-    if (t < L) yp[(int64_t)t * p.s.y_sl] = acc;
+    if (t < L) yp[(int64_t)t * p.s.y_sl] = (TIO)acc;
   }
 }
 
-template <int W>
+template <int W, typename TIO>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ConvParams p) {
   const int lane = threadIdx.x & 63;
   const int d = blockIdx.x * 64 + lane;
@@ -69,23 +71,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ConvParams p) {
 #pragma unroll
   for (int k = 0; k < W; ++k) wk[k] = p.w[d * W + k];
   const float bs = p.bias ? p.bias[d] : 0.f;
-  const float *xp = p.x + b * p.s.x_sb + d * p.s.x_sd;
-  const float *dyp = p.dy + b * p.s.y_sb + d * p.s.y_sd;
-  float *dxp = p.dx + b * p.dx_sb + d * p.dx_sd;
+  const TIO *xp = static_cast<const TIO *>(p.x) + b * p.s.x_sb + d * p.s.x_sd;
+  const TIO *dyp = static_cast<const TIO *>(p.dy) + b * p.s.y_sb + d * p.s.y_sd;
+  TIO *dxp = static_cast<TIO *>(p.dx) + b * p.dx_sb + d * p.dx_sd;
   // x rows t0-(W-1) .. t0+TC+W-2, dy rows t0 .. t0+TC+W-2
   float xv[TC + 2 * (W - 1)], g[TC + W - 1];
 #pragma unroll
   for (int i = 0; i < TC + 2 * (W - 1); ++i) {
     const int t = t0 - (W - 1) + i;
     const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
-    const float v = xp[(int64_t)tc * p.s.x_sl];
+    const float v = (float)xp[(int64_t)tc * p.s.x_sl];
     xv[i] = (t >= 0 && t < L) ? v : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < TC + W - 1; ++i) {
     const int s = t0 + i;
     const int sc = s < L ? s : L - 1;
-    const float v = dyp[(int64_t)sc * p.s.y_sl];
+    const float v = (float)dyp[(int64_t)sc * p.s.y_sl];
     float gi = s < L ? v : 0.f;
     if (p.s.silu) {
       float pre = bs;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ConvParams p) {
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < W; ++k) acc = fmaf(wk[k], g[i + (W - 1) - k], acc);
-    if (t < L) dxp[(int64_t)t * p.dx_sl] = acc;
+    if (t < L) dxp[(int64_t)t * p.dx_sl] = (TIO)acc;
     // dw[k] += g[s] x[s-(W-1)+k] for s = t (each s counted by exactly one chunk)
 #pragma unroll
     for (int k = 0; k < W; ++k) dwk[k] = fmaf(g[i], xv[i + k], dwk[k]);
@@ -158,12 +160,13 @@ static int conv_check(const cum_conv_shape *s) {
   CUM_REQUIRE(s != nullptr, "conv: null shape");
   CUM_REQUIRE(s->batch >= 0 && s->dim >= 1 && s->len >= 0, "conv: bad batch/dim/len");
   CUM_REQUIRE(s->width >= 1 && s->width <= MAXW, "conv: width must be in [1, 4]");
+  CUM_REQUIRE(s->io_dtype == CUM_F32 || s->io_dtype == CUM_BF16, "conv: io_dtype must be CUM_F32 or CUM_BF16");
   CUM_REQUIRE(s->batch <= 65535, "conv: batch > 65535");
   return CUM_OK;
 }
 
-extern "C" int cum_causal_conv1d_fwd(const cum_conv_shape *s, const float *x, const float *weight, const float *bias,
-                                     float *y, void *stream) {
+extern "C" int cum_causal_conv1d_fwd(const cum_conv_shape *s, const void *x, const float *weight, const float *bias,
+                                     void *y, void *stream) {
   if (int rc = conv_check(s)) return rc;
   CUM_REQUIRE(x && weight && y, "conv_fwd: null tensor");
   if (s->batch == 0 || s->len == 0) return CUM_OK;
@@ -172,11 +175,12 @@ extern "C" int cum_causal_conv1d_fwd(const cum_conv_shape *s, const float *x, co
   p.nchunks = (s->len + TC - 1) / TC;
   dim3 grid((s->dim + 63) / 64, (p.nchunks + 3) / 4, s->batch), block(256);
   hipStream_t st = (hipStream_t)stream;
+  const bool h = s->io_dtype == CUM_BF16;
   switch (s->width) {
-    case 1: hipLaunchKernelGGL(dwconv_fwd_kernel<1>, grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL(dwconv_fwd_kernel<2>, grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL(dwconv_fwd_kernel<3>, grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL(dwconv_fwd_kernel<4>, grid, block, 0, st, p); break;
+    case 1: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<1, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<1, float>), grid, block, 0, st, p); break;
+    case 2: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<2, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<2, float>), grid, block, 0, st, p); break;
+    case 3: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<3, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<3, float>), grid, block, 0, st, p); break;
+    default: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<4, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<4, float>), grid, block, 0, st, p); break;
   }
   CUM_CHECK_LAUNCH();
   return CUM_OK;
@@ -188,8 +192,8 @@ extern "C" int64_t cum_conv_bwd_workspace_elems(int32_t batch, int32_t dim, int3
   return (int64_t)batch * nchunks * (MAXW + 1) * dim;
 }
 
-extern "C" int cum_causal_conv1d_bwd(const cum_conv_shape *s, const float *x, const float *weight, const float *bias,
-                                     const float *dy, float *dx, int64_t dx_sb, int64_t dx_sd, int64_t dx_sl,
+extern "C" int cum_causal_conv1d_bwd(const cum_conv_shape *s, const void *x, const float *weight, const float *bias,
+                                     const void *dy, void *dx, int64_t dx_sb, int64_t dx_sd, int64_t dx_sl,
                                      float *dweight, float *dbias, float *workspace, void *stream) {
   if (int rc = conv_check(s)) return rc;
   CUM_REQUIRE(x && weight && dy && dx && dweight, "conv_bwd: null tensor");
@@ -205,11 +209,12 @@ extern "C" int cum_causal_conv1d_bwd(const cum_conv_shape *s, const float *x, co
   p.dx_sb = dx_sb; p.dx_sd = dx_sd; p.dx_sl = dx_sl;
   p.nchunks = (s->len + TC - 1) / TC;
   dim3 grid((s->dim + 63) / 64, (p.nchunks + 3) / 4, s->batch), block(256);
+  const bool h = s->io_dtype == CUM_BF16;
   switch (s->width) {
-    case 1: hipLaunchKernelGGL(dwconv_bwd_kernel<1>, grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL(dwconv_bwd_kernel<2>, grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL(dwconv_bwd_kernel<3>, grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL(dwconv_bwd_kernel<4>, grid, block, 0, st, p); break;
+    case 1: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<1, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<1, float>), grid, block, 0, st, p); break;
+    case 2: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<2, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<2, float>), grid, block, 0, st, p); break;
+    case 3: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<3, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<3, float>), grid, block, 0, st, p); break;
+    default: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<4, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<4, float>), grid, block, 0, st, p); break;
   }
   CUM_CHECK_LAUNCH();
   const int total = (MAXW + 1) * s->dim;

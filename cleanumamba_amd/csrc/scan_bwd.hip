@@ -43,7 +43,7 @@ __device__ __forceinline__ void wave_reduce_scatter8(const float (&v)[NS], float
   r[1] = row16_allsum(q[1]);
 }
 
-template <int NW, bool FAST>
+template <int NW, bool FAST, typename TIO>
 __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   constexpr int K = (TB + NW - 1) / NW;
   __shared__ float s_dt[TB][64];
@@ -76,14 +76,14 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   }
   const float Dd = p.D ? p.D[dc] : 0.f;
   const float bias = p.bias ? p.bias[dc] : 0.f;
-  const float *up = p.u + b * p.s.u_sb + dc * p.s.u_sd;
-  const float *dtp = p.delta + b * p.s.dt_sb + dc * p.s.dt_sd;
+  const TIO *up = static_cast<const TIO *>(p.u) + b * p.s.u_sb + dc * p.s.u_sd;
+  const TIO *dtp = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb + dc * p.s.dt_sd;
   const bool has_z = p.z != nullptr;
-  const float *zp = has_z ? p.z + b * p.s.z_sb + dc * p.s.z_sd : up;
-  const float *dop = p.dout + b * p.s.o_sb + dc * p.s.o_sd;
-  float *dup = p.du + b * p.gs.du_sb + dc * p.gs.du_sd;
-  float *ddtp = p.ddelta + b * p.gs.dd_sb + dc * p.gs.dd_sd;
-  float *dzp = has_z ? p.dz + b * p.gs.dz_sb + dc * p.gs.dz_sd : nullptr;
+  const TIO *zp = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb + dc * p.s.z_sd : up;
+  const TIO *dop = static_cast<const TIO *>(p.dout) + b * p.s.o_sb + dc * p.s.o_sd;
+  TIO *dup = static_cast<TIO *>(p.du) + b * p.gs.du_sb + dc * p.gs.du_sd;
+  TIO *ddtp = static_cast<TIO *>(p.ddelta) + b * p.gs.dd_sb + dc * p.gs.dd_sd;
+  TIO *dzp = has_z ? static_cast<TIO *>(p.dz) + b * p.gs.dz_sb + dc * p.gs.dz_sd : nullptr;
   const int du_sl = (int)p.gs.du_sl, dd_sl = (int)p.gs.dd_sl, dz_sl = (int)p.gs.dz_sl;
   const float *Bw = p.Bm + b * p.s.B_sb + n0 * p.s.B_sn;
   const float *Cw = p.Cm + b * p.s.C_sb + n0 * p.s.C_sn;
@@ -104,10 +104,10 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     for (int k = 0; k < K; ++k) {
       const int tl = w + k * NW;
       const int tc = t0 + (tl <= tlast ? tl : tlast);  // clamped address, masked value
-      ru[k] = up[tc * u_sl];
-      rdl[k] = dtp[tc * dt_sl];
-      rz[k] = zp[tc * z_sl];
-      rdo[k] = dop[tc * o_sl];
+      ru[k] = (float)up[tc * u_sl];
+      rdl[k] = (float)dtp[tc * dt_sl];
+      rz[k] = (float)zp[tc * z_sl];
+      rdo[k] = (float)dop[tc * o_sl];
     }
   };
   load_rows(nchunks - 1);
@@ -234,12 +234,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
           if (has_z) {
             const float sz = sigmoidf_(zv);
             dy = dov * zv * sz;
-            dzp[t * dz_sl] = dov * y * sz * (1.f + zv * (1.f - sz));
+            dzp[t * dz_sl] = (TIO)(dov * y * sz * (1.f + zv * (1.f - sz)));
           }
           const float ddt = kLn2 * q1 + eu[k] * q2;  // d loss / d delta'
           const float dpre = ddt * esg[k];
-          dup[t * du_sl] = fmaf(dy, Dd, edt[k] * q2);
-          ddtp[t * dd_sl] = dpre;
+          dup[t * du_sl] = (TIO)fmaf(dy, Dd, edt[k] * q2);
+          ddtp[t * dd_sl] = (TIO)dpre;
           accD = fmaf(dy, eu[k], accD);
           accBias += dpre;
         }
@@ -367,16 +367,21 @@ __global__ void scan_bwd_finalize_kernel(const ScanParams p, float *dA, float *d
   }
 }
 
-template <int NW>
-static int launch_bwd(const ScanParams &p, hipStream_t st) {
+template <int NW, typename TIO>
+static int launch_bwd_io(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
   const bool fast = p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW;
   if (fast)
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, true, TIO>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, false, TIO>), grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
+}
+
+template <int NW>
+static int launch_bwd(const ScanParams &p, hipStream_t st) {
+  return p.s.io_dtype == CUM_BF16 ? launch_bwd_io<NW, __bf16>(p, st) : launch_bwd_io<NW, float>(p, st);
 }
 
 }  // namespace cum
@@ -388,11 +393,11 @@ extern "C" int64_t cum_scan_bwd_workspace_elems(int32_t batch, int32_t dim, int3
   return (int64_t)batch * dim * dstate + 2 * (int64_t)batch * dim + 2 * (int64_t)batch * G * len * dstate;
 }
 
-extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs, const float *u,
-                                      const float *delta, const float *A,
-                                      const float *Bm, const float *Cm, const float *D, const float *z,
-                                      const float *delta_bias, const float *dout, const float *ckpt, float *du,
-                                      float *ddelta, float *dA, float *dB, float *dC, float *dD, float *dz,
+extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs, const void *u,
+                                      const void *delta, const float *A,
+                                      const float *Bm, const float *Cm, const float *D, const void *z,
+                                      const float *delta_bias, const void *dout, const float *ckpt, void *du,
+                                      void *ddelta, float *dA, float *dB, float *dC, float *dD, void *dz,
                                       float *ddelta_bias, float *workspace, void *stream) {
   if (int rc = scan_check_shape(s)) return rc;
   CUM_REQUIRE(gs && dA, "scan_bwd: null tensor");

@@ -23,10 +23,14 @@ constexpr int NS = 8;   // states per wave
 struct ScanParams {
   cum_scan_shape s;
   cum_scan_grad_strides gs;
-  const float *u, *delta, *A, *Bm, *Cm, *D, *z, *bias;
-  float *out, *last_state, *ckpt;
-  const float *dout, *ckpt_in;
-  float *du, *ddelta, *dz;
+  // u, delta, z, out, dout, du, ddelta, dz hold elements of s.io_dtype (f32 or bf16); everything else is f32
+  const void *u, *delta, *z;
+  const float *A, *Bm, *Cm, *D, *bias;
+  void *out;
+  float *last_state, *ckpt;
+  const void *dout;
+  const float *ckpt_in;
+  void *du, *ddelta, *dz;
   float *ws_dA, *ws_dD, *ws_dbias, *ws_dB, *ws_dC;
   int nchunks, ngroups;
 };

@@ -12,7 +12,7 @@
 
 namespace cum {
 
-template <int NW, bool FAST>
+template <int NW, bool FAST, typename TIO>
 __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
   constexpr int K = (TB + NW - 1) / NW;  // (t, d) rows per thread in phases A / C
   __shared__ float s_dt[TB][64];
@@ -39,11 +39,11 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
   }
   const float Dd = p.D ? p.D[dc] : 0.f;
   const float bias = p.bias ? p.bias[dc] : 0.f;
-  const float *up = p.u + b * p.s.u_sb + dc * p.s.u_sd;
-  const float *dtp = p.delta + b * p.s.dt_sb + dc * p.s.dt_sd;
+  const TIO *up = static_cast<const TIO *>(p.u) + b * p.s.u_sb + dc * p.s.u_sd;
+  const TIO *dtp = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb + dc * p.s.dt_sd;
   const bool has_z = p.z != nullptr;
-  const float *zp = has_z ? p.z + b * p.s.z_sb + dc * p.s.z_sd : up;  // !has_z: valid dummy address
-  float *op = p.out + b * p.s.o_sb + dc * p.s.o_sd;
+  const TIO *zp = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb + dc * p.s.z_sd : up;  // !has_z: valid dummy address
+  TIO *op = static_cast<TIO *>(p.out) + b * p.s.o_sb + dc * p.s.o_sd;
   const float *Bw = p.Bm + b * p.s.B_sb + n0 * p.s.B_sn;
   const float *Cw = p.Cm + b * p.s.C_sb + n0 * p.s.C_sn;
   // within-batch offsets fit 32 bits (checked on the host)
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
     for (int k = 0; k < K; ++k) {
       int t = t0 + w + k * NW;
       t = t < L ? t : L - 1;  // clamped address; the value is masked in phase A
-      ru[k] = up[t * u_sl];
-      rdt[k] = dtp[t * dt_sl];
-      rz[k] = zp[t * z_sl];
+      ru[k] = (float)up[t * u_sl];
+      rdt[k] = (float)dtp[t * dt_sl];
+      rz[k] = (float)zp[t * z_sl];
     }
   };
   load_rows(0);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
           const float zv = ez[k];
           y *= zv * sigmoidf_(zv);
         }
-        op[t * o_sl] = y;
+        op[t * o_sl] = (TIO)y;
       }
     }
     // no third barrier: the next phase A writes s_dt/s_du (read only in phase B, which
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
 // tiles with coalesced vector loads (any strides, padding masked to zero), phase B reads each wave's 8-float slice
 // with wave-uniform ds_read_b128 (LDS broadcast), one step ahead.  LDS returns in order, so waits are counted and
 // nothing in the step loop waits on the scalar cache.
-template <int NW>
+template <int NW, typename TIO>
 __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams p) {
   constexpr int K = (TB + NW - 1) / NW;
   constexpr int NT = NW * 64;
@@ -197,11 +197,11 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
   }
   const float Dd = p.D ? p.D[dc] : 0.f;
   const float bias = p.bias ? p.bias[dc] : 0.f;
-  const float *up = p.u + b * p.s.u_sb + dc * p.s.u_sd;
-  const float *dtp = p.delta + b * p.s.dt_sb + dc * p.s.dt_sd;
+  const TIO *up = static_cast<const TIO *>(p.u) + b * p.s.u_sb + dc * p.s.u_sd;
+  const TIO *dtp = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb + dc * p.s.dt_sd;
   const bool has_z = p.z != nullptr;
-  const float *zp = has_z ? p.z + b * p.s.z_sb + dc * p.s.z_sd : up;
-  float *op = p.out + b * p.s.o_sb + dc * p.s.o_sd;
+  const TIO *zp = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb + dc * p.s.z_sd : up;
+  TIO *op = static_cast<TIO *>(p.out) + b * p.s.o_sb + dc * p.s.o_sd;
   const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
   const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
   const int o_sl = (int)p.s.o_sl;
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
     for (int k = 0; k < K; ++k) {
       int t = t0 + w + k * NW;
       t = t < L ? t : L - 1;
-      ru[k] = up[t * u_sl];
-      rdt[k] = dtp[t * dt_sl];
-      rz[k] = zp[t * z_sl];
+      ru[k] = (float)up[t * u_sl];
+      rdt[k] = (float)dtp[t * dt_sl];
+      rz[k] = (float)zp[t * z_sl];
     }
 #pragma unroll
     for (int k = 0; k < BCK; ++k) {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
           const float zv = ez[k];
           y *= zv * sigmoidf_(zv);
         }
-        op[t * o_sl] = y;
+        op[t * o_sl] = (TIO)y;
       }
     }
   }
@@ -359,27 +359,33 @@ static int scan_fwd_variant() {
   return v;
 }
 
-template <int NW>
-static int launch_fwd(const ScanParams &p, hipStream_t st) {
+template <int NW, typename TIO>
+static int launch_fwd_io(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
   if (scan_fwd_variant() == 1) {
-    hipLaunchKernelGGL((scan_fwd_lds_kernel<NW>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_fwd_lds_kernel<NW, TIO>), grid, block, 0, st, p);
     CUM_CHECK_LAUNCH();
     return CUM_OK;
   }
   const bool fast = p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW;
   if (fast)
-    hipLaunchKernelGGL((scan_fwd_kernel<NW, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_fwd_kernel<NW, true, TIO>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((scan_fwd_kernel<NW, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_fwd_kernel<NW, false, TIO>), grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
+}
+
+template <int NW>
+static int launch_fwd(const ScanParams &p, hipStream_t st) {
+  return p.s.io_dtype == CUM_BF16 ? launch_fwd_io<NW, __bf16>(p, st) : launch_fwd_io<NW, float>(p, st);
 }
 
 int scan_check_shape(const cum_scan_shape *s) {
   CUM_REQUIRE(s != nullptr, "scan: null shape");
   CUM_REQUIRE(s->batch >= 0 && s->dim >= 1 && s->len >= 0, "scan: bad batch/dim/len");
   CUM_REQUIRE(s->dstate >= 1 && s->dstate <= 64, "scan: d_state must be in [1, 64]");
+  CUM_REQUIRE(s->io_dtype == CUM_F32 || s->io_dtype == CUM_BF16, "scan: io_dtype must be CUM_F32 or CUM_BF16");
   const int64_t lim = 2147483647LL;
   const int64_t Lm = s->len > 0 ? s->len - 1 : 0;
   CUM_REQUIRE(s->u_sl >= 0 && s->dt_sl >= 0 && s->z_sl >= 0 && s->o_sl >= 0 && s->B_sl >= 0 && s->C_sl >= 0 &&
@@ -403,9 +409,9 @@ extern "C" int64_t cum_scan_ckpt_elems(int32_t batch, int32_t dim, int32_t dstat
   return (int64_t)batch * nchunks * dstate * dim;
 }
 
-extern "C" int cum_selective_scan_fwd(const cum_scan_shape *s, const float *u, const float *delta, const float *A,
-                                      const float *Bm, const float *Cm, const float *D, const float *z,
-                                      const float *delta_bias, float *out, float *last_state, float *ckpt,
+extern "C" int cum_selective_scan_fwd(const cum_scan_shape *s, const void *u, const void *delta, const float *A,
+                                      const float *Bm, const float *Cm, const float *D, const void *z,
+                                      const float *delta_bias, void *out, float *last_state, float *ckpt,
                                       void *stream) {
   if (int rc = scan_check_shape(s)) return rc;
   if (s->batch == 0) return CUM_OK;

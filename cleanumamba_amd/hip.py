@@ -24,7 +24,7 @@ class ScanShape(ctypes.Structure):
                 ("o_sb", c_i64), ("o_sd", c_i64), ("o_sl", c_i64),
                 ("B_sb", c_i64), ("B_sn", c_i64), ("B_sl", c_i64),
                 ("C_sb", c_i64), ("C_sn", c_i64), ("C_sl", c_i64),
-                ("delta_softplus", c_i32)]
+                ("delta_softplus", c_i32), ("io_dtype", c_i32)]
 
 
 class ScanGradStrides(ctypes.Structure):
@@ -37,7 +37,7 @@ class ConvShape(ctypes.Structure):
     _fields_ = [("batch", c_i32), ("dim", c_i32), ("len", c_i32), ("width", c_i32),
                 ("x_sb", c_i64), ("x_sd", c_i64), ("x_sl", c_i64),
                 ("y_sb", c_i64), ("y_sd", c_i64), ("y_sl", c_i64),
-                ("silu", c_i32)]
+                ("silu", c_i32), ("io_dtype", c_i32)]
 
 
 class GemmDesc(ctypes.Structure):
@@ -94,7 +94,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 1:
+        if L.cum_abi_version() != 2:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

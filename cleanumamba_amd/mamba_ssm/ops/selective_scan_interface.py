@@ -7,6 +7,10 @@ through ``create_block`` at src/network/CleanUMamba.py:172-189 and Mamba.step at
 B, C: (B, N, L) or (B, 1, N, L) -- but any strides are accepted; the kernels are
 tuned for channel-contiguous storage ((B, L, D) memory viewed as (B, D, L)), which
 is what ``Mamba.forward`` here passes.  No CPU path: tensors must be on the GPU.
+
+u, delta, z may be float32 or bfloat16 (what autocast hands over, as upstream takes fp16/bf16): the kernels
+read them and write out / du / ddelta / dz in that element type directly (cum_scan_shape.io_dtype); the
+recurrence, A, B, C, D, the bias and their gradients are fp32.
 """
 import ctypes
 
@@ -45,16 +49,20 @@ def _shape(u, delta, z, out, Bm, Cm, softplus):
     s.B_sb, s.B_sn, s.B_sl = Bm.stride()
     s.C_sb, s.C_sn, s.C_sl = Cm.stride()
     s.delta_softplus = int(bool(softplus))
+    s.io_dtype = hip.dtype_code(u.dtype)
     return s
 
 
 class SelectiveScanFn(torch.autograd.Function):
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                 return_last_state=False, save_ckpt=True):
         Bm, Cm = _as3(B), _as3(C)
-        hip.require_gpu(u, delta, A, Bm, Cm, D, z, delta_bias)
+        hip.require_gpu(u, delta, z, any_dtype=True)
+        hip.require_gpu(A, Bm, Cm, D, delta_bias)
+        if delta.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
+            raise RuntimeError("selective_scan: u, delta and z must share one element type")
         bsz, dim, L = u.shape
         N = A.shape[1]
         if A.shape[0] != dim or Bm.shape != (bsz, N, L) or Cm.shape != (bsz, N, L) or delta.shape != u.shape:
@@ -93,7 +101,7 @@ class SelectiveScanFn(torch.autograd.Function):
         bsz, dim, L = u.shape
         N = A.shape[1]
         lib = hip.lib()
-        dout = dout.float()
+        dout = dout.to(u.dtype)
         du, ddelta = _empty_like_layout(u), _empty_like_layout(delta)
         dz = _empty_like_layout(z) if z is not None else None
         su = _shape(u, delta, z, dout, Bm, Cm, ctx.delta_softplus)     # o_* strides := dout's
@@ -128,6 +136,12 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
                       return_last_state=False):
     """out (and last_state (B, D, N) if requested); gate ``z`` is applied inside the kernel."""
     in_dtype = u.dtype
+    io = in_dtype if in_dtype in (torch.float32, torch.bfloat16) else torch.float32
+    u, delta = u.to(io), delta.to(io)
+    z = None if z is None else z.to(io)
+    A, B, C = A.float(), B.float(), C.float()
+    D = None if D is None else D.float()
+    delta_bias = None if delta_bias is None else delta_bias.float()
     # chunk-boundary states are written only when a backward can follow
     save = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
     res = SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state, save)

@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 1
+#define CUM_ABI_VERSION 2
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -68,13 +68,16 @@ typedef struct {
   int64_t B_sb, B_sn, B_sl;          /* Bm */
   int64_t C_sb, C_sn, C_sl;          /* Cm */
   int32_t delta_softplus;            /* apply softplus (threshold 20) to delta + bias */
+  int32_t io_dtype;                  /* CUM_F32 / CUM_BF16: element type of u, delta, z, out and of dout, du,
+                                        ddelta, dz (what autocast hands over); all arithmetic and every other
+                                        tensor stay fp32 */
 } cum_scan_shape;
 
 int64_t cum_scan_ckpt_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len);
 
-int cum_selective_scan_fwd(const cum_scan_shape *s, const float *u, const float *delta,
+int cum_selective_scan_fwd(const cum_scan_shape *s, const void *u, const void *delta,
                            const float *A, const float *Bm, const float *Cm, const float *D,
-                           const float *z, const float *delta_bias, float *out,
+                           const void *z, const float *delta_bias, void *out,
                            float *last_state, float *ckpt, void *stream);
 
 /* Strides (batch, dim, len) of the three per-element gradient outputs. */
@@ -92,11 +95,11 @@ typedef struct {
 int64_t cum_scan_bwd_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len);
 
 int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs,
-                           const float *u, const float *delta,
+                           const void *u, const void *delta,
                            const float *A, const float *Bm, const float *Cm, const float *D,
-                           const float *z, const float *delta_bias, const float *dout,
-                           const float *ckpt, float *du, float *ddelta, float *dA, float *dB,
-                           float *dC, float *dD, float *dz, float *ddelta_bias,
+                           const void *z, const float *delta_bias, const void *dout,
+                           const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
+                           float *dC, float *dD, void *dz, float *ddelta_bias,
                            float *workspace, void *stream);
 
 /* One time step for `batch` concurrent streams (Mamba.step).  state (batch, dim,
@@ -117,17 +120,18 @@ typedef struct {
   int64_t x_sb, x_sd, x_sl;
   int64_t y_sb, y_sd, y_sl;
   int32_t silu;
+  int32_t io_dtype;                  /* CUM_F32 / CUM_BF16: element type of x, y, dy, dx; weights stay fp32 */
 } cum_conv_shape;
 
-int cum_causal_conv1d_fwd(const cum_conv_shape *s, const float *x, const float *weight,
-                          const float *bias, float *y, void *stream);
+int cum_causal_conv1d_fwd(const cum_conv_shape *s, const void *x, const float *weight,
+                          const float *bias, void *y, void *stream);
 
 /* dy has y's strides; dx has strides (dx_sb, dx_sd, dx_sl).  dweight (dim, width),
  * dbias (dim): overwritten.  workspace: cum_conv_bwd_workspace_elems() fp32 elements. */
 int64_t cum_conv_bwd_workspace_elems(int32_t batch, int32_t dim, int32_t len, int32_t width);
 
-int cum_causal_conv1d_bwd(const cum_conv_shape *s, const float *x, const float *weight,
-                          const float *bias, const float *dy, float *dx, int64_t dx_sb,
+int cum_causal_conv1d_bwd(const cum_conv_shape *s, const void *x, const float *weight,
+                          const float *bias, const void *dy, void *dx, int64_t dx_sb,
                           int64_t dx_sd, int64_t dx_sl, float *dweight, float *dbias,
                           float *workspace, void *stream);
 

@@ -157,3 +157,52 @@ def test_streaming_step_kernels_vs_golden(cuda):
         assert rel_l2(y, g["y64"][s]) < 2e-5
     assert rel_l2(ss, g["ssm_state64"]) < 2e-5
     assert rel_l2(cs, g["conv_state64"]) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 192, 64, 150), (1, 70, 20, 33)])
+def test_scan_and_dwconv_bf16_io_vs_oracle(cuda, shape):
+    """bf16 element type for u / delta / z / out (what autocast hands over; cum_scan_shape.io_dtype): against the
+    f64 oracle on the SAME bf16-rounded inputs the only differences are the kernels' f32 arithmetic and the final
+    rounding of each output to bf16 (2^-9 relative per element), hence rel-L2 <= 4e-3."""
+    from cleanumamba_amd.causal_conv1d import causal_conv1d_fn
+    from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    bsz, dim, N, L = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    rn = lambda *s: torch.randn(*s, generator=g)
+    bf = lambda t: t.bfloat16().float()
+    u, delta, z = bf(rn(bsz, L, dim)), bf(0.5 * rn(bsz, L, dim)), bf(rn(bsz, L, dim))
+    A = -torch.exp(rn(dim, N) * 0.5)
+    Bm, Cm, D, bias = rn(bsz, L, N), rn(bsz, L, N), rn(dim), 0.3 * rn(dim)
+    dout = bf(rn(bsz, L, dim))
+
+    def run(dev, dt_io, dt_ref):
+        leaves = [t.to(dev).to(dt_io).requires_grad_(True) for t in (u, delta, z)]
+        rest = [t.to(dev).to(dt_ref).requires_grad_(True) for t in (A, Bm, Cm, D, bias)]
+        uu, dd, zz = (t.transpose(1, 2) for t in leaves)
+        args = (uu, dd, rest[0], rest[1].transpose(1, 2), rest[2].transpose(1, 2), rest[3])
+        if dev.type == "cuda":
+            out = selective_scan_fn(*args, z=zz, delta_bias=rest[4], delta_softplus=True)
+        else:
+            out = M.selective_scan_ref(*args, z=zz, delta_bias=rest[4], delta_softplus=True)
+        out.backward(dout.to(dev).to(out.dtype).transpose(1, 2))
+        return [out] + [t.grad for t in leaves + rest]
+
+    got = run(cuda, torch.bfloat16, torch.float32)
+    ref = run(torch.device("cpu"), torch.float64, torch.float64)
+    assert got[0].dtype == torch.bfloat16 and all(t.dtype == torch.bfloat16 for t in got[1:4])
+    for name, a, b in zip(("out", "du", "ddelta", "dz", "dA", "dB", "dC", "dD", "dbias"), got, ref):
+        assert rel_l2(a.float(), b) < 4e-3, name
+
+    # depthwise conv + SiLU, same comparison
+    w, cb = rn(dim, 4), rn(dim)
+    xg = u.to(cuda).bfloat16().requires_grad_(True)
+    wg, bg = w.to(cuda).requires_grad_(True), cb.to(cuda).requires_grad_(True)
+    y = causal_conv1d_fn(xg.transpose(1, 2), wg, bg, "silu")
+    y.backward(dout.to(cuda).bfloat16().transpose(1, 2))
+    xr = u.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), cb.double().requires_grad_(True)
+    yr = M.causal_conv1d_ref(xr.transpose(1, 2), wr, br, "silu")
+    yr.backward(dout.double().transpose(1, 2))
+    assert y.dtype == torch.bfloat16 and xg.grad.dtype == torch.bfloat16 and wg.grad.dtype == torch.float32
+    for name, a, b in (("y", y, yr), ("dx", xg.grad, xr.grad), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad)):
+        assert rel_l2(a.float(), b) < 4e-3, name

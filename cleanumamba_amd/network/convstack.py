@@ -128,6 +128,17 @@ def colsum(X, x_off, ld, M, n):
 _INDEX_CACHE = {}
 
 
+def gather(src_flat, idx32, dtype):
+    """[src_flat[idx] or 0 where idx < 0] as ``dtype``; csrc/pack.hip (32-bit index, conversion in the same pass)."""
+    out = torch.empty(idx32.numel(), dtype=dtype, device=src_flat.device)
+    if not src_flat.is_contiguous():
+        src_flat = src_flat.contiguous()
+    with torch.cuda.device(src_flat.device):
+        hip.check(hip.lib().cum_gather(hip.dtype_code(src_flat.dtype), hip.ptr(src_flat), hip.ptr(idx32), idx32.numel(),
+                                       hip.dtype_code(dtype), hip.ptr(out), hip.stream_ptr()))
+    return out
+
+
 def _ids(shape):
     n = 1
     for d in shape:
@@ -148,7 +159,7 @@ class PackPlan:
         for p in self.params:
             self.offset[p.data_ptr()] = off
             off += p.numel()
-        self.total = off                      # index of the zero slot
+        self.total = off
         self.reqs = {}                        # (key, ptr, dtype) -> (global index (cpu), shape)
         self.dirty = False
         self.gidx = {}                        # dtype -> (device index tensor, [(reqkey, start, numel, shape)])
@@ -158,10 +169,10 @@ class PackPlan:
         rk = (key, src.data_ptr(), dtype)
         if rk in self.reqs:
             return
-        local = idx.cpu()
+        local = idx.cpu().to(torch.int64)
         g = local + self.offset[src.data_ptr()]
-        g[local >= src.numel()] = self.total
-        self.reqs[rk] = (g, shape)
+        g[local < 0] = -1                     # zero padding
+        self.reqs[rk] = (g.to(torch.int32), shape)
         self.dirty = True
 
     def refresh(self):
@@ -184,9 +195,9 @@ class PackPlan:
                 self.gidx[dt] = (torch.cat(parts).to(dev), metas)
             self.dirty = False
         with torch.no_grad():
-            flat = torch.cat([p.detach().reshape(-1) for p in self.params] + [torch.zeros(1, dtype=self.params[0].dtype, device=dev)])
+            flat = torch.cat([p.detach().reshape(-1) for p in self.params])
             for dt, (gi, metas) in self.gidx.items():
-                big = (flat if flat.dtype == dt else flat.to(dt)).index_select(0, gi)
+                big = gather(flat, gi, dt)
                 for rk, start, n, shape in metas:
                     self.current[rk] = big[start:start + n].view(shape)
 
@@ -209,20 +220,13 @@ def take(src, key, build, dtype=None):
     ent = _INDEX_CACHE.get((key, src.device))
     if ent is None:
         ids = build()
-        idx = ids.reshape(-1) - 1
-        pad = bool((idx < 0).any())          # does the layout reference the zero slot at all?
-        idx[idx < 0] = src.numel()
-        ent = (idx.to(src.device), tuple(ids.shape), pad)
+        idx = (ids.reshape(-1) - 1).to(torch.int32)          # -1 = zero padding
+        ent = (idx.to(src.device), tuple(ids.shape))
         _INDEX_CACHE[(key, src.device)] = ent
-    idx, shape, pad = ent
+    idx, shape = ent
     if plan is not None and src.data_ptr() in plan.offset:
         plan.record(key, src, idx, shape, dtype if dtype is not None else src.dtype)
-    flat = src.reshape(-1)
-    if dtype is not None and flat.dtype != dtype:
-        flat = flat.to(dtype)
-    if pad:
-        flat = torch.nn.functional.pad(flat, (0, 1))
-    return flat.index_select(0, idx).view(shape)
+    return gather(src.detach().reshape(-1), idx, dtype if dtype is not None else src.dtype).view(shape)
 
 
 def _invert(packed_ids, param_shape):

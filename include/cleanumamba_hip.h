@@ -234,6 +234,12 @@ int cum_stft_fold(const float *dframes, int64_t batch, int64_t len, int32_t n_ff
                   const float *window, int64_t n_frames, float *dx, int64_t dx_stride_b, int32_t accumulate,
                   void *stream);
 
+/* ---- operand packing: dst[i] = idx[i] < 0 ? 0 : (dst_dtype) src[idx[i]], i < n.  The GEMM operand layouts above are
+ * index permutations (with zero padding) of the reference's parameter tensors (encoder/decoder state-dict keys,
+ * src/network/CleanUMamba.py:108-130); the same call unpacks weight gradients into parameter layout. */
+int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n, int32_t dst_dtype, void *dst,
+               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

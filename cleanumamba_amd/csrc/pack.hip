@@ -7,20 +7,41 @@
 
 namespace cum {
 
+template <typename TD>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ type make(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+};
+template <>
+struct Vec4<__bf16> {
+  typedef __attribute__((ext_vector_type(4))) __bf16 type;
+  static __device__ __forceinline__ type make(float a, float b, float c, float d) {
+    type v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return v;
+  }
+};
+
+// 8 elements per thread and sweep: two 16-byte index loads, eight independent gathers in flight, two vector stores
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void gather_kernel(const TS *__restrict__ src, const int32_t *__restrict__ idx,
                                                      TD *__restrict__ dst, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
-  for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
-    if (i0 + 3 < n) {
-      const int4 j = *reinterpret_cast<const int4 *>(idx + i0);
+  typedef typename Vec4<TD>::type V;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+  for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i0 < n; i0 += stride) {
+    if (i0 + 7 < n) {
+      const int4 j = *reinterpret_cast<const int4 *>(idx + i0), k = *reinterpret_cast<const int4 *>(idx + i0 + 4);
       const float v0 = j.x < 0 ? 0.f : (float)src[j.x], v1 = j.y < 0 ? 0.f : (float)src[j.y];
       const float v2 = j.z < 0 ? 0.f : (float)src[j.z], v3 = j.w < 0 ? 0.f : (float)src[j.w];
-      dst[i0] = (TD)v0; dst[i0 + 1] = (TD)v1; dst[i0 + 2] = (TD)v2; dst[i0 + 3] = (TD)v3;
+      const float v4 = k.x < 0 ? 0.f : (float)src[k.x], v5 = k.y < 0 ? 0.f : (float)src[k.y];
+      const float v6 = k.z < 0 ? 0.f : (float)src[k.z], v7 = k.w < 0 ? 0.f : (float)src[k.w];
+      *reinterpret_cast<V *>(dst + i0) = Vec4<TD>::make(v0, v1, v2, v3);
+      *reinterpret_cast<V *>(dst + i0 + 4) = Vec4<TD>::make(v4, v5, v6, v7);
     } else {
       for (int64_t i = i0; i < n; ++i) {
-        const int32_t j = idx[i];
-        dst[i] = (TD)(j < 0 ? 0.f : (float)src[j]);
+        const int32_t jj = idx[i];
+        dst[i] = (TD)(jj < 0 ? 0.f : (float)src[jj]);
       }
     }
   }
@@ -36,9 +57,10 @@ extern "C" int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx
               "gather: dtypes must be CUM_F32 or CUM_BF16");
   CUM_REQUIRE(n >= 0, "gather: negative length");
   if (n == 0) return CUM_OK;
-  CUM_REQUIRE(src && idx && dst && ((uintptr_t)idx & 15) == 0, "gather: null or misaligned pointer");
-  const int64_t want = (n + 1023) / 1024;
-  dim3 grid((unsigned)(want < 4096 ? want : 4096)), block(256);
+  CUM_REQUIRE(src && idx && dst && ((uintptr_t)idx & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+              "gather: null or misaligned pointer");
+  const int64_t want = (n + 2047) / 2048;
+  dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (src_dtype == CUM_F32 && dst_dtype == CUM_F32)
     hipLaunchKernelGGL((gather_kernel<float, float>), grid, block, 0, st, (const float *)src, idx, (float *)dst, n);

@@ -15,6 +15,7 @@ coalesce on.  The (B, D, L) tensors of the upstream formulation appear only as
 transposed views.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -25,6 +26,55 @@ from ..ops.selective_scan_interface import selective_scan_fn, selective_state_up
 # Module-level names that callers monkey-patch (src/examples/using_pruning_groups.py:26-27
 # sets ``causal_conv1d_fn = None`` to force the nn.Conv1d path so that hooks fire).
 from ...causal_conv1d import causal_conv1d_fn, causal_conv1d_update
+
+
+class _ProjFn(torch.autograd.Function):
+    """y = x @ w.T for the four bias-free projections.  Forward and the data gradient stay on hipBLASLt; the weight
+    gradient dW[n][k] = sum_m dY[m][n] X[m][k] runs on cum_gemm_tn: its reduction axis is only B*L = 9984 long while
+    the outputs are small (160 x 2048, 2048 x 32, ...), so a library GEMM without a split over m leaves most CUs
+    idle (46-98 us per call measured), whereas the weight-gradient kernel of the conv stack splits m across
+    workgroups and reduces the f32 slabs deterministically."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, w, cd):
+        xc, wc = x.to(cd), w.to(cd)
+        ctx.save_for_backward(xc, wc)
+        ctx.x_dtype, ctx.w_dtype = x.dtype, w.dtype
+        return F.linear(xc, wc)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        from ...network import convstack as cs
+        xc, wc = ctx.saved_tensors
+        N, K = wc.shape
+        dyc = dy.to(wc.dtype)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(dyc, wc).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            x2, d2 = xc.reshape(-1, K), dyc.reshape(-1, N)
+            if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+                x2 = x2.contiguous()
+            if d2.stride(1) != 1 or d2.stride(0) % 8 or d2.data_ptr() % 16:
+                d2 = d2.contiguous()
+            dw, _ = cs.wgrad(d2, 0, d2.stride(0), N, x2, 0, x2.stride(0), K, x2.shape[0], want_bias=False)
+            dw = dw.to(ctx.w_dtype)
+        return dx, dw, None
+
+
+_PROJ_TN = os.environ.get("CUM_PROJ_TN", "1") != "0"      # "0": plain F.linear everywhere (A/B timing)
+
+
+def _proj(x, w, bias=None):
+    """F.linear, with the weight gradient on the HIP kernel when training on the GPU (see _ProjFn)."""
+    if _PROJ_TN and bias is None and x.is_cuda and torch.is_grad_enabled() and w.requires_grad and w.shape[0] % 8 == 0 \
+            and w.shape[1] % 8 == 0:
+        cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if cd in (torch.bfloat16, torch.float32) and (cd == torch.bfloat16 or w.dtype == torch.float32):
+            return _ProjFn.apply(x, w, cd)
+    return F.linear(x, w, bias)
 
 
 class Mamba(nn.Module):
@@ -88,7 +138,7 @@ class Mamba(nn.Module):
         d_state = (self.x_proj.weight.shape[0] - dt_rank) // 2
         d_conv = self.conv1d.weight.shape[-1]
 
-        xz = F.linear(hidden_states, self.in_proj.weight, self.in_proj.bias)      # (B, L, 2 d_inner)
+        xz = _proj(hidden_states, self.in_proj.weight, self.in_proj.bias)         # (B, L, 2 d_inner)
         x = xz[..., :d_inner].transpose(1, 2)                                     # (B, d_inner, L) views,
         z = xz[..., d_inner:].transpose(1, 2)                                     # channel stride 1
         A = -torch.exp(self.A_log.float())
@@ -99,16 +149,16 @@ class Mamba(nn.Module):
             x = x.transpose(1, 2).contiguous().transpose(1, 2)
         else:
             x = causal_conv1d_fn(x, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
-        x_dbl = F.linear(x.transpose(1, 2), self.x_proj.weight)                   # (B, L, R + 2N)
+        x_dbl = _proj(x.transpose(1, 2), self.x_proj.weight)                      # (B, L, R + 2N)
         dt, Bm, Cm = torch.split(x_dbl, [dt_rank, d_state, d_state], dim=-1)
-        dt = F.linear(dt, self.dt_proj.weight).transpose(1, 2)                    # (B, d_inner, L); bias goes in the scan
+        dt = _proj(dt, self.dt_proj.weight).transpose(1, 2)                       # (B, d_inner, L); bias goes in the scan
         y = selective_scan_fn(x, dt, A, Bm.transpose(1, 2), Cm.transpose(1, 2), self.D.float(), z=z,
                               delta_bias=self.dt_proj.bias.float(), delta_softplus=True,
                               return_last_state=ssm_state is not None)
         if ssm_state is not None:
             y, last_state = y
             ssm_state.copy_(last_state)
-        return F.linear(y.transpose(1, 2), self.out_proj.weight, self.out_proj.bias)
+        return _proj(y.transpose(1, 2), self.out_proj.weight, self.out_proj.bias)
 
     def step(self, hidden_states, conv_state, ssm_state):
         """One token for every stream.  hidden_states: (B, 1, d_model); states updated in place."""

@@ -197,7 +197,8 @@ class PackPlan:
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1) for p in self.params])
             for dt, (gi, metas) in self.gidx.items():
-                big = gather(flat, gi, dt)
+                # cast first: the gather then reads 2-byte elements of a source that stays cache-resident
+                big = gather(flat if flat.dtype == dt else flat.to(dt), gi, dt)
                 for rk, start, n, shape in metas:
                     self.current[rk] = big[start:start + n].view(shape)
 

@@ -9,8 +9,10 @@ N > 1), clip_grad_norm_(10), fused Adam, LR schedule -- on synthetic 10 s @ 16 k
 (BASELINE configs[2]/[3]), random-init E8 weights.  Rank 0 prints ONE JSON line.
 
 value = global_batch * 160000 * K / (max-over-ranks time of K steps).
-roofline: the selective-scan forward kernel at the E8 bottleneck shape, algorithmic bytes
-(B*T*4*(4*d_inner + 2*N)) / mean launch duration measured with HIP events.
+roofline: the kernel with the largest share of the step (rocprofv3 --stats: gemm_tn_kernel<bf16>, the conv-stack
+weight gradients): algorithmic flops 2*M*N*K / mean launch duration measured with HIP events over the 16 encoder
+launch shapes of the step, against the dense bf16 MFMA peak.  `kernels` lists the other heavy kernels the same way
+(forward GEMMs; selective scan forward / backward with the SURVEY.md 8d byte counts and state updates / s).
 cpu_baseline: the CPU oracle (oracle/cleanumamba_ref.py, kind "port") doing forward + loss + backward
 on a bounded sample (2 clips of 10 s), rank 0, N = 1 only.
 """
@@ -34,8 +36,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"],
                     help="autocast dtype of the GEMM/conv stack (reference trains under fp16 autocast); "
@@ -46,48 +48,22 @@ def parse():
     return ap.parse_args()
 
 
-def scan_roofline(dev, iters=20):
-    """Mean duration of the scan forward kernel at the E8 train shape, HIP events on the launch stream."""
-    from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
-    bsz, dim, N, L = 16, 2048, 64, 624
-    g = torch.Generator(device=dev).manual_seed(0)
-    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
-    xz = rn(bsz, L, 2 * dim)
-    u, z = xz[..., :dim].transpose(1, 2), xz[..., dim:].transpose(1, 2)
-    delta = (0.3 * rn(bsz, L, dim)).transpose(1, 2)
-    A = -torch.exp(torch.log(torch.arange(1, N + 1, device=dev).float())[None].repeat(dim, 1)).contiguous()
-    xd = rn(bsz, L, 32 + 2 * N)
-    Bm, Cm = xd[..., 32:32 + N].transpose(1, 2), xd[..., 32 + N:].transpose(1, 2)
-    D, bias = rn(dim), 0.3 * rn(dim)
-    with torch.no_grad():
-        for _ in range(3):
-            selective_scan_fn(u, delta, A, Bm, Cm, D, z=z, delta_bias=bias, delta_softplus=True)
-        torch.cuda.synchronize()
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        for _ in range(iters):
-            selective_scan_fn(u, delta, A, Bm, Cm, D, z=z, delta_bias=bias, delta_softplus=True)
-        end.record()
-        torch.cuda.synchronize()
-    ms = start.elapsed_time(end) / iters
-    alg_bytes = bsz * L * 4 * (4 * dim + 2 * N)           # read u, delta, z, B, C; write out (fp32)
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "scan_fwd_lds_kernel<8> (B=16,D=2048,N=64,L=624,f32)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            # HBM bytes per launch from PMC passes of this kernel at this shape: 2 x FETCH_SIZE + WRITE_SIZE
-            # (gfx950 corrections, calibrated on a known kernel): profiles/r01_scan_pmc.md
-            "traffic": 368.7e6, "traffic_source": "profiles/r01_scan_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
-            "launch_ms": round(ms, 4), "algorithmic_bytes": alg_bytes,
-            "state_updates_per_s": round(bsz * L * dim * N / (ms * 1e-3) / 1e12, 3), "state_updates_unit": "T/s"}
+MFMA_PEAK_TFS = 2500.0      # MI355X_MICROARCH.md: bf16 dense
+# PMC passes of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over tools/bench_gemm.py tn (profiles/r01_gemm_tn_pmc.md):
+# HBM bytes per gemm_tn launch (kernel + slab reduce), mean over the 16 encoder weight-gradient shapes
+TN_TRAFFIC_BYTES = 446.0e6
+
+B16 = 16
+ENC_T = [160254, 80126, 40062, 20030, 10014, 5006, 2502, 1250, 624]
+ENC_C = [1, 64, 128, 256, 512, 768, 768, 768, 768]
 
 
-def _time(fn, iters=10):
-    for _ in range(2):
+def _time(fn, iters=10, warm=3):
+    for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
+    start.record()                     # on torch's current stream = the stream every kernel here is launched on
     for _ in range(iters):
         fn()
     end.record()
@@ -95,53 +71,103 @@ def _time(fn, iters=10):
     return start.elapsed_time(end) / iters
 
 
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def tn_roofline(dev):
+    """The kernel with the largest share of the step (rocprofv3: gemm_tn_kernel<bf16>, 34 launches per step):
+    weight gradients dW = dZ^T X of the conv stack.  Timed live with HIP events on the 16 launch shapes the
+    ENCODER contributes to one E8 / B=16 step (conv and 1x1 of each layer; the decoder's 16 launches mirror them
+    with the same M*N*K).  achieved = sum of algorithmic flops (2*M*N*K) / sum of mean
+    launch durations (kernel + its deterministic slab reduce)."""
+    from cleanumamba_amd.network import convstack as cs
+    dt = torch.bfloat16
+    rows, flops_sum, ms_sum = [], 0.0, 0.0
+    for i in range(8):
+        M, Cin, H = B16 * (ENC_T[i + 1] + 2), _rup(ENC_C[i], 8), ENC_C[i + 1]
+        for name, N, K, ldx in ((f"enc{i}.conv.w", H, 4 * Cin, 2 * Cin), (f"enc{i}.1x1.w", 2 * H, H, H)):
+            dz = torch.randn(M, N, device=dev).to(dt)
+            X = torch.randn(M * ldx // 8 + K // 8 + 64, 8, device=dev).to(dt)
+            ms = _time(lambda: cs.wgrad(dz, 0, N, N, X, 0, ldx, K, M))
+            fl = 2.0 * M * N * K
+            rows.append({"shape": f"{name} M={M} N={N} K={K}", "launch_ms": round(ms, 4),
+                         "tflops": round(fl / ms / 1e9, 1)})
+            flops_sum += fl
+            ms_sum += ms
+            del dz, X
+    tf = flops_sum / ms_sum / 1e9
+    return {"bound": "mfma", "kernel": "gemm_tn_kernel<bf16> + tn_reduce_kernel, the 16 encoder weight-gradient "
+                                       "launches of one E8 B=16 step",
+            "achieved": round(tf, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFS, 4),
+            "traffic": TN_TRAFFIC_BYTES, "traffic_source": "profiles/r01_gemm_tn_pmc.md",
+            "launch_ms": round(ms_sum / len(rows), 4), "algorithmic_flops": flops_sum / len(rows),
+            "launches": len(rows), "per_shape": rows}
+
+
 def other_kernels(dev):
-    """Live HIP-event timings of the other heavy kernels of the step at an E8 layer shape, with their roofs
-    (bf16 MFMA 2.5 PFLOP/s dense; HBM 8 TB/s).  Informational: `roofline` stays the scan forward kernel."""
+    """Live HIP-event timings of the other heavy kernels of the step, each against the roof that bounds it
+    (bf16 MFMA 2.5 PFLOP/s dense; HBM 8 TB/s).  Informational; `roofline` is the weight-gradient GEMM."""
     from cleanumamba_amd import hip
     from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
     from cleanumamba_amd.network import convstack as cs
     out = []
-    # encoder layer 5 (768 -> 768, T = 2502, B = 16): conv k4 s2 as GEMM, forward and weight gradient
-    M, N, K, lda = 16 * 2504, 768, 3072, 1536
-    A = torch.randn(M * lda // 8 + K // 8 + 64, 8, device=dev).bfloat16()
-    W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
-    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    bias = torch.zeros(N, device=dev)
-    ms = _time(lambda: cs.gemm(A, 0, lda, W, bias, y, 0, N, M, 1 << 30, 1 << 30, hip.EPI_RELU, N))
-    tf = 2.0 * M * N * K / ms / 1e9
-    out.append({"kernel": "gemm_nt_kernel<bf16,relu> enc5 conv (M=40064,N=768,K=3072)", "bound": "mfma",
-                "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                "launch_ms": round(ms, 4)})
-    dz = torch.randn(M, N, device=dev).bfloat16()
-    ms = _time(lambda: cs.wgrad(dz, 0, N, N, A, 0, lda, K, M))
-    tf = 2.0 * M * N * K / ms / 1e9
-    out.append({"kernel": "gemm_tn_kernel<bf16> + reduce, enc5 conv weight gradient", "bound": "mfma",
-                "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                "launch_ms": round(ms, 4)})
-    # selective scan backward at the E8 bottleneck shape
+    dt = torch.bfloat16
+    # forward GEMMs of the encoder (conv k4 s2 + ReLU, 1x1 + GLU), all 16 launch shapes of one step
+    fl_sum = ms_sum = 0.0
+    for i in range(8):
+        M, Cin, H = B16 * (ENC_T[i + 1] + 2), _rup(ENC_C[i], 8), ENC_C[i + 1]
+        for N, K, lda, epi in ((H, 4 * Cin, 2 * Cin, hip.EPI_RELU), (2 * H, H, H, hip.EPI_GLU)):
+            A = torch.randn(M * lda // 8 + K // 8 + 64, 8, device=dev).to(dt)
+            W = (torch.randn(_rup(N, 32), _rup(K, 64), device=dev) / K ** 0.5).to(dt)
+            nout = N // 2 if epi == hip.EPI_GLU else N
+            y = torch.empty(M, nout, device=dev, dtype=dt)
+            bias = torch.zeros(W.shape[0], device=dev)
+            ms_sum += _time(lambda: cs.gemm(A, 0, lda, W, bias, y, 0, nout, M, 1 << 30, 1 << 30, epi, nout))
+            fl_sum += 2.0 * M * N * K
+            del A, W, y
+    tf = fl_sum / ms_sum / 1e9
+    out.append({"kernel": "gemm_nt_kernel<bf16> (ReLU / GLU epilogues), the 16 encoder forward launches of one step",
+                "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_PEAK_TFS, 4), "launch_ms": round(ms_sum / 16, 4)})
+    # selective scan at the E8 bottleneck shape, bf16 element type as in the autocast step
     bsz, dim, Ns, L = 16, 2048, 64, 624
     g = torch.Generator(device=dev).manual_seed(1)
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)
-    xz = rn(bsz, L, 2 * dim).requires_grad_(True)
-    dl = (0.3 * rn(bsz, L, dim)).requires_grad_(True)
+    xz = rn(bsz, L, 2 * dim).bfloat16().requires_grad_(True)
+    dl = (0.3 * rn(bsz, L, dim)).bfloat16().requires_grad_(True)
     Am = (-torch.exp(torch.log(torch.arange(1, Ns + 1, device=dev).float())[None].repeat(dim, 1))).requires_grad_(True)
     xd = rn(bsz, L, 32 + 2 * Ns).requires_grad_(True)
     Dv, bv = rn(dim).requires_grad_(True), (0.3 * rn(dim)).requires_grad_(True)
-    dout = rn(bsz, dim, L)
+    dout = rn(bsz, dim, L).bfloat16()
 
     def fwd():
         return selective_scan_fn(xz[..., :dim].transpose(1, 2), dl.transpose(1, 2), Am, xd[..., 32:32 + Ns].transpose(1, 2),
                                  xd[..., 32 + Ns:].transpose(1, 2), Dv, z=xz[..., dim:].transpose(1, 2), delta_bias=bv,
                                  delta_softplus=True)
+
+    def fwd_nograd():
+        with torch.no_grad():
+            return fwd()
+    t_i = _time(fwd_nograd)
     t_f = _time(fwd)
     t_fb = _time(lambda: fwd().backward(dout))
-    ms = t_fb - t_f
-    byt = bsz * L * 4 * (7 * dim + 4 * Ns)
-    gbs = byt / (ms * 1e-3) / 1e9
-    out.append({"kernel": "scan_bwd_kernel<8,true> + finalize (B=16,D=2048,N=64,L=624,f32)", "bound": "hbm",
+    upd = bsz * L * dim * Ns
+    byt = bsz * L * (2 * 4 * dim + 4 * 2 * Ns)           # u, delta, z, out in bf16; B, C in f32  (SURVEY.md 8d, s = 2 / 4)
+    gbs = byt / (t_i * 1e-3) / 1e9
+    out.append({"kernel": "scan_fwd_lds_kernel<8,bf16> (B=16,D=2048,N=64,L=624), no checkpoints", "bound": "hbm",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "launch_ms": round(ms, 4), "algorithmic_bytes": byt})
+                "launch_ms": round(t_i, 4), "algorithmic_bytes": byt,
+                "state_updates_per_s": round(upd / (t_i * 1e-3) / 1e12, 3), "state_updates_unit": "T/s",
+                "note": "one v_exp_f32 per state update: transcendental-issue bound at N=64 (DESIGN.md 3.1)"})
+    ms = t_fb - t_f
+    byt = bsz * L * (2 * 7 * dim + 4 * 4 * Ns)           # u, delta, z, dout, du, ddelta, dz in bf16; B, C, dB, dC in f32
+    gbs = byt / (ms * 1e-3) / 1e9
+    out.append({"kernel": "scan_bwd_kernel<8,true,bf16> + finalize (B=16,D=2048,N=64,L=624)", "bound": "hbm",
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "launch_ms": round(ms, 4), "algorithmic_bytes": byt,
+                "state_updates_per_s": round(upd / (ms * 1e-3) / 1e12, 3), "state_updates_unit": "T/s",
+                "note": "2.4 v_exp_f32 + ~20 VALU per state element: instruction-issue bound (DESIGN.md 3.2)"})
     return out
 
 
@@ -244,7 +270,7 @@ def main():
                           "parallelism": f"dp{world}", "weights": "random init (reference init, seed 0)"},
                "final_loss": round(final_loss, 5)}
         if not args.no_roofline:
-            out["roofline"] = scan_roofline(dev)
+            out["roofline"] = tn_roofline(dev)
             if world == 1:
                 out["kernels"] = other_kernels(dev)
         if world == 1 and not args.no_cpu_baseline:

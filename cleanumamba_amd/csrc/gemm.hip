@@ -45,7 +45,9 @@ struct GemmParams {
   void *out;               // [M][ldc]
   void *aux;               // GLU: pre-activation [M][ldz] (N columns); BIAS/RELU: activation before the residual add;
                            //   EPI_MASK: the ungated result (second output); EPI_GLU_BWD: the saved pre-activation Z (input)
-  int64_t lda, ldw, ldc, ldr, ldz;
+  const void *aux2;        // gate_only GLU_BWD: the GLU output y saved by the forward [M][ldy]
+  int64_t lda, ldw, ldc, ldr, ldz, ldy;
+  int gate_only;           // GLU / GLU_BWD: aux holds only the gate pre-activation b ([M][ldz], output-column order)
   int M, N, K;             // N multiple of 16 (32 for GLU), K multiple of the K tile
   int pitch, valid;        // row m is real iff (m % pitch) < valid; other rows are stored as zeros
   int n_store;             // number of output columns to store (<= N, or N/2 for GLU); multiple of 4
@@ -185,11 +187,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
           b[j] = acc[2 * pi + 1][mi][j] + bv[2 * pi + 1][j];
           o[j] = real ? a[j] * sigmoidf_(b[j]) : 0.f;
         }
-        if (aux) {
-          store4<T>(aux + (int64_t)m * p.ldz + na, a);
-          store4<T>(aux + (int64_t)m * p.ldz + nb, b);
-        }
         const int oc = (n0 + wn * 64) / 2 + pi * 16 + 4 * g;
+        if (aux) {
+          if (p.gate_only) {
+            store4<T>(aux + (int64_t)m * p.ldz + oc, b);
+          } else {
+            store4<T>(aux + (int64_t)m * p.ldz + na, a);
+            store4<T>(aux + (int64_t)m * p.ldz + nb, b);
+          }
+        }
         if (oc < p.n_store) {
           if (res) {
             float rr[4];
@@ -217,14 +223,27 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
 #pragma unroll
           for (int j = 0; j < 4; ++j) d[j] += rr[j];
         }
-        load4<T>(aux + (int64_t)m * p.ldz + zc, a);
-        load4<T>(aux + (int64_t)m * p.ldz + zc + 16, b);
+        if (p.gate_only) {
+          // a * sig(b) is the saved output y:  db = d * y * (1 - sig(b)) needs no a
+          load4<T>(aux + (int64_t)m * p.ldz + n, b);
+          load4<T>(static_cast<const T *>(p.aux2) + (int64_t)m * p.ldy + n, a);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float sg = sigmoidf_(b[j]);
-          const float dj = real ? d[j] : 0.f;
-          da[j] = dj * sg;
-          db[j] = dj * a[j] * sg * (1.f - sg);
+          for (int j = 0; j < 4; ++j) {
+            const float sg = sigmoidf_(b[j]);
+            const float dj = real ? d[j] : 0.f;
+            da[j] = dj * sg;
+            db[j] = dj * a[j] * (1.f - sg);
+          }
+        } else {
+          load4<T>(aux + (int64_t)m * p.ldz + zc, a);
+          load4<T>(aux + (int64_t)m * p.ldz + zc + 16, b);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float sg = sigmoidf_(b[j]);
+            const float dj = real ? d[j] : 0.f;
+            da[j] = dj * sg;
+            db[j] = dj * a[j] * sg * (1.f - sg);
+          }
         }
         store4<T>(out + (int64_t)m * p.ldc + zc, da);
         store4<T>(out + (int64_t)m * p.ldc + zc + 16, db);
@@ -405,6 +424,36 @@ __global__ void glu_bwd_kernel(const T *__restrict__ Z, const T *__restrict__ dO
   }
 }
 
+// Same from the gate pre-activation alone: Bg [M][ldb] (16 per group) and the saved GLU output Y [M][ldy]:
+// da = d * sig(b), db = d * y * (1 - sig(b)).  dZ [M][ldz] is written in the packed (16 a | 16 b) layout.
+template <typename T>
+__global__ void glu_bwd_gate_kernel(const T *__restrict__ Bg, const T *__restrict__ Y, const T *__restrict__ dO,
+                                    T *__restrict__ dZ, int64_t M, int ngroups, int64_t ldb, int64_t ldy, int64_t ldo,
+                                    int64_t ldz, int n_out) {
+  const int64_t total = M * ngroups * 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = i & 3;
+    const int64_t t = i >> 2;
+    const int grp = t % ngroups;
+    const int64_t m = t / ngroups;
+    const int oc = grp * 16 + q * 4;
+    float y[4] = {0.f, 0.f, 0.f, 0.f}, b[4], d[4] = {0.f, 0.f, 0.f, 0.f}, da[4], db[4];
+    load4<T>(Bg + m * ldb + oc, b);
+    if (oc < n_out) {
+      load4<T>(dO + m * ldo + oc, d);
+      load4<T>(Y + m * ldy + oc, y);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float s = sigmoidf_(b[j]);
+      da[j] = d[j] * s;
+      db[j] = d[j] * y[j] * (1.f - s);
+    }
+    store4<T>(dZ + m * ldz + grp * 32 + q * 4, da);
+    store4<T>(dZ + m * ldz + grp * 32 + 16 + q * 4, db);
+  }
+}
+
 // dZ = dOut * (Y > 0)   (Y = ReLU output before any residual add); 4 elements per thread
 template <typename T>
 __global__ void relu_bwd_kernel(const T *__restrict__ Y, const T *__restrict__ dO, T *__restrict__ dZ, int64_t M,
@@ -494,7 +543,7 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
 using namespace cum;
 
 extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias, const void *res,
-                           void *out, void *aux, void *stream) {
+                           void *out, void *aux, const void *aux2, void *stream) {
   CUM_REQUIRE(d && A && W && out, "gemm: null argument");
   CUM_REQUIRE(d->dtype == CUM_F32 || d->dtype == CUM_BF16, "gemm: dtype must be CUM_F32 or CUM_BF16");
   CUM_REQUIRE(d->epilogue >= 0 && d->epilogue <= 4, "gemm: bad epilogue");
@@ -512,12 +561,33 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
               "gemm: A, W and bias must be 16-byte aligned");
   if (d->M == 0) return CUM_OK;
   GemmParams p{};
-  p.A = A; p.W = W; p.bias = bias; p.res = res; p.out = out; p.aux = aux;
-  p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr; p.ldz = d->ldz;
+  CUM_REQUIRE(!d->gate_only || d->epilogue == EPI_GLU || (d->epilogue == EPI_GLU_BWD && aux2 && d->ldy % 4 == 0),
+              "gemm: gate_only applies to the GLU epilogues; GLU_BWD then needs the saved output in aux2");
+  p.A = A; p.W = W; p.bias = bias; p.res = res; p.out = out; p.aux = aux; p.aux2 = aux2;
+  p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr; p.ldz = d->ldz; p.ldy = d->ldy;
+  p.gate_only = d->gate_only;
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;
   p.zero_head = d->zero_head; p.zero_tail = d->zero_tail;
   if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);
   return launch_gemm<float>(p, d->epilogue, (hipStream_t)stream);
+}
+
+extern "C" int cum_glu_bwd_gate(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Bg, int64_t ldb,
+                                const void *Y, int64_t ldy, const void *dOut, int64_t ldo, void *dZ, int64_t ldz,
+                                void *stream) {
+  CUM_REQUIRE(Bg && Y && dOut && dZ && n_groups > 0 && M >= 0, "glu_bwd_gate: bad argument");
+  CUM_REQUIRE(ldb % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && ldz % 4 == 0, "glu_bwd_gate: strides must be multiples of 4");
+  if (M == 0) return CUM_OK;
+  const int64_t total = M * n_groups * 4;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == CUM_BF16)
+    hipLaunchKernelGGL(glu_bwd_gate_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Bg,
+                       (const __bf16 *)Y, (const __bf16 *)dOut, (__bf16 *)dZ, M, n_groups, ldb, ldy, ldo, ldz, n_out);
+  else
+    hipLaunchKernelGGL(glu_bwd_gate_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)Bg,
+                       (const float *)Y, (const float *)dOut, (float *)dZ, M, n_groups, ldb, ldy, ldo, ldz, n_out);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
 }
 
 extern "C" int cum_glu_bwd(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Z, int64_t ldz,

@@ -43,7 +43,8 @@ class ConvShape(ctypes.Structure):
 class GemmDesc(ctypes.Structure):
     _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("lda", c_i64), ("ldw", c_i64), ("ldc", c_i64), ("ldr", c_i64), ("ldz", c_i64),
-                ("pitch", c_i32), ("valid", c_i32), ("n_store", c_i32), ("zero_head", c_i64), ("zero_tail", c_i64)]
+                ("pitch", c_i32), ("valid", c_i32), ("n_store", c_i32), ("zero_head", c_i64), ("zero_tail", c_i64),
+                ("gate_only", c_i32), ("ldy", c_i64)]
 
 
 CUM_F32, CUM_BF16 = 0, 1
@@ -65,7 +66,8 @@ SIGNATURES = {
     "cum_conv_bwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "cum_causal_conv1d_bwd": (c_i32, [ctypes.POINTER(ConvShape)] + [_P] * 5 + [c_i64] * 3 + [_P] * 4),
     "cum_causal_conv1d_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, c_i32, _P, _P]),
-    "cum_gemm_nt": (c_i32, [ctypes.POINTER(GemmDesc)] + [_P] * 7),
+    "cum_gemm_nt": (c_i32, [ctypes.POINTER(GemmDesc)] + [_P] * 8),
+    "cum_glu_bwd_gate": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P, c_i64, _P]),
     "cum_glu_bwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, _P]),
     "cum_relu_bwd": (c_i32, [c_i32, c_i64, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, c_i64, c_i64, _P]),
     "cum_colsum_workspace_elems": (c_i64, [c_i64, c_i32]),
@@ -95,7 +97,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 2:
+        if L.cum_abi_version() != 3:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -75,9 +75,9 @@ def _padv(b, n):
 
 # ------------------------------------------------------------------ GEMM launcher
 def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_store, res=None, r_off=0, ldr=0,
-         aux=None, x_off=0, ldz=0, geo=None):
-    """A, out, res, aux: flat tensors; *_off element offsets of row 0; Wp [N, K] packed weights."""
-    hip.require_gpu(A, Wp, out, res, aux, any_dtype=True)
+         aux=None, x_off=0, ldz=0, geo=None, aux2=None, y_off=0, ldy=0, gate_only=False):
+    """A, out, res, aux, aux2: flat tensors; *_off element offsets of row 0; Wp [N, K] packed weights."""
+    hip.require_gpu(A, Wp, out, res, aux, aux2, any_dtype=True)
     dt = A.dtype
     if Wp.dtype != dt or out.dtype != dt:
         raise RuntimeError("gemm: A, W and out must share one dtype")
@@ -87,12 +87,13 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
     d.M, d.N, d.K = M, Wp.shape[0], Wp.shape[1]
     d.lda, d.ldw, d.ldc, d.ldr, d.ldz = lda, Wp.stride(0), ldc, ldr if res is not None else 4, ldz if aux is not None else 4
     d.pitch, d.valid, d.n_store = pitch, valid, n_store
+    d.gate_only, d.ldy = int(gate_only), ldy if aux2 is not None else 4
     if geo is not None:      # out (and an activation-type aux) is a row buffer of this geometry: frame it with zeros
         d.zero_head, d.zero_tail = geo.head, geo.tail
     P = lambda t, off: None if t is None else ctypes.c_void_p(t.data_ptr() + off * esz)
     with torch.cuda.device(A.device):
         hip.check(hip.lib().cum_gemm_nt(ctypes.byref(d), P(A, a_off), P(Wp, 0), hip.ptr(bias), P(res, r_off),
-                                        P(out, o_off), P(aux, x_off), hip.stream_ptr()))
+                                        P(out, o_off), P(aux, x_off), P(aux2, y_off), hip.stream_ptr()))
 
 
 def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True):
@@ -560,6 +561,9 @@ def supported(model):
 # GEMMs and nothing else.  Forward kernels are the same as above.  Layers whose channel count is not a multiple
 # of 16 after padding (pruned checkpoints) keep the unfused elementwise kernels.
 def _glu_fwd(xbuf, w, b, gi, go, save_z):
+    """1x1 conv + GLU.  Saved for the backward: only the gate pre-activation b ([go.M, G*16], output-column order);
+    together with the output itself (kept anyway: it is the next layer's input) it determines the GLU backward,
+    da = d*sig(b), db = d*y*(1 - sig(b)) -- half the bytes of the (a | b) pre-activation."""
     dt, dev = xbuf.dtype, xbuf.device
     H2, Cin, _ = w.shape
     G = (H2 // 2 + 15) // 16
@@ -568,9 +572,9 @@ def _glu_fwd(xbuf, w, b, gi, go, save_z):
     wp = take(w, ("glu_fwd", sh, G * 32, Kp), lambda: lay_glu_fwd(sh, G * 32, Kp), dt)
     bp = take(b, ("glu_vec", H2), lambda: lay_glu_vec(H2), torch.float32)
     ybuf = go.new(dt, dev)
-    z = torch.empty(go.M, G * 32, dtype=dt, device=dev) if save_z else None
+    z = torch.empty(go.M, G * 16, dtype=dt, device=dev) if save_z else None
     gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_GLU, go.Cp,
-         aux=z, x_off=0, ldz=G * 32, geo=go)
+         aux=z, x_off=0, ldz=G * 16, geo=go, gate_only=True)
     return ybuf, z
 
 
@@ -607,13 +611,15 @@ def _convt_fwd(xbuf, w, b, skip, gi, go, relu):
     return ybuf, (act if keep else (ybuf if relu else None))
 
 
-def _glu_bwd(z, dy, go):
-    """Standalone GLU backward: dy is a row buffer of geometry go, z / result are [go.M, G*32]."""
-    G = z.shape[1] // 32
-    dz = torch.empty_like(z)
+def _glu_bwd(z, ybuf, dy, go):
+    """Standalone GLU backward from the gate pre-activation z [go.M, G*16] and the layer's output row buffer ybuf;
+    dy is a row buffer of geometry go; the result is [go.M, G*32] in the packed (16 a | 16 b) layout."""
+    G = z.shape[1] // 16
+    dz = torch.empty(go.M, G * 32, dtype=z.dtype, device=z.device)
     with torch.cuda.device(z.device):
-        hip.check(hip.lib().cum_glu_bwd(hip.dtype_code(z.dtype), go.M, G, go.Cp, hip.ptr(z), G * 32, hip.ptr(dy[1:]),
-                                        go.Cp, hip.ptr(dz), hip.stream_ptr()))
+        hip.check(hip.lib().cum_glu_bwd_gate(hip.dtype_code(z.dtype), go.M, G, go.Cp, hip.ptr(z), G * 16,
+                                             hip.ptr(ybuf[1:]), go.Cp, hip.ptr(dy[1:]), go.Cp, hip.ptr(dz), G * 32,
+                                             hip.stream_ptr()))
     return dz
 
 
@@ -671,7 +677,7 @@ class EncoderStack(torch.autograd.Function):
             if dz is None:                     # top layer: its output gradient arrives from outside only
                 if dys[i] is None:
                     raise RuntimeError("EncoderStack: the deepest output must be used")
-                dz = _glu_bwd(zs[i], dys[i].contiguous(), go)
+                dz = _glu_bwd(zs[i], bufs[i + 1], dys[i].contiguous(), go)
             G32 = dz.shape[1]
             grads[4 * i + 2], grads[4 * i + 3] = _glu_wgrad(dz, y1s[i], w2, gm, go.M)
             # 1x1 data gradient, gated by the ReLU below it in the epilogue
@@ -694,17 +700,17 @@ class EncoderStack(torch.autograd.Function):
             ext = None if i == 0 or dys[i - 1] is None else dys[i - 1].contiguous()
             if i > 0 and gi.Cp % 16 == 0:
                 # ... + the skip gradient, pushed through the GLU of layer i-1 in the epilogue: dZ_{i-1} directly
-                zp = zs[i - 1]
-                dz = torch.empty_like(zp)
+                dz = torch.empty(gi.M, 2 * gi.Cp, dtype=dt, device=dev)
                 gemm(dzc, 0, gm.Cp, wd, None, dz, 0, 4 * gi.Cp, gm.M, gm.P, gm.T + 1, hip.EPI_GLU_BWD, 2 * gi.Cp,
-                     res=ext, r_off=gi.Cp, ldr=2 * gi.Cp, aux=zp, x_off=0, ldz=4 * gi.Cp)
+                     res=ext, r_off=gi.Cp, ldr=2 * gi.Cp, aux=zs[i - 1], x_off=0, ldz=2 * gi.Cp,
+                     aux2=bufs[i], y_off=gi.Cp, ldy=2 * gi.Cp, gate_only=True)
                 continue
             dx = gi.new(dt, dev)
             gemm(dzc, 0, gm.Cp, wd, None, dx, gi.Cp, 2 * gi.Cp, gm.M, gm.P, gm.T + 1, hip.EPI_BIAS, 2 * gi.Cp, geo=gi)
             if i == 0:
                 dx0 = dx
             else:
-                dz = _glu_bwd(zs[i - 1], dx if ext is None else dx + ext, gi)
+                dz = _glu_bwd(zs[i - 1], bufs[i], dx if ext is None else dx + ext, gi)
         return (dx0, None, None, *grads)
 
 
@@ -770,15 +776,15 @@ class DecoderStack(torch.autograd.Function):
             Nd, Kd = rup(gg.Cp, 16), rup(4 * go.Cp, bk_of(dt))
             wc = take(wt, ("convt_dgrad", sht, go.Cp, Nd, Kd), lambda: lay_convt_dgrad(sht, go.Cp, Nd, Kd), dt)
             z = zs[j]
-            G32 = z.shape[1]
+            G32 = 2 * z.shape[1]
             if gg.Cp % 16 == 0:
-                dz = torch.empty_like(z)
+                dz = torch.empty(gg.M, G32, dtype=dt, device=dev)
                 gemm(dpre, go.Cp, 2 * go.Cp, wc, None, dz, 0, G32, gg.M, gg.P, gg.T, hip.EPI_GLU_BWD, gg.Cp,
-                     aux=z, x_off=0, ldz=G32)
+                     aux=z, x_off=0, ldz=gg.Cp, aux2=gs[j], y_off=gg.Cp, ldy=gg.Cp, gate_only=True)
             else:
                 dg = gg.new(dt, dev)
                 gemm(dpre, go.Cp, 2 * go.Cp, wc, None, dg, gg.Cp, gg.Cp, gg.M, gg.P, gg.T, hip.EPI_BIAS, gg.Cp, geo=gg)
-                dz = _glu_bwd(z, dg, gg)
+                dz = _glu_bwd(z, gs[j], dg, gg)
             grads[4 * j], grads[4 * j + 1] = _glu_wgrad(dz, us[j], w1, gi, gg.M)
             # 1x1 data gradient: ungated it is the gradient of u_j (and of the skip added into it); gated by the ReLU
             # of layer j-1 it is that layer's dpre -- both written by one epilogue

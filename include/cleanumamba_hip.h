@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 2
+#define CUM_ABI_VERSION 3
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -179,15 +179,25 @@ typedef struct {
   int64_t zero_head;         /* elements in front of out[0] to clear (the buffer's leading zero row) */
   int64_t zero_tail;         /* elements behind out[M*ldc] to clear (the buffer's slack rows); both also */
                              /* applied to aux when it has out's geometry (epilogue != GLU)             */
+  int32_t gate_only;         /* GLU (2): aux receives only the gate pre-activation b, [M][ldz] in the output's   */
+                             /* column order (half the bytes of the (a | b) form).  GLU_BWD (4): aux is that b   */
+                             /* and aux2 the GLU output y = a*sig(b) saved by the forward ([M][ldy]):            */
+                             /* da = d*sig(b), db = d*y*(1 - sig(b)) -- a itself is never needed                 */
+  int64_t ldy;
 } cum_gemm_desc;
 
 int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias,
-                const void *res, void *out, void *aux, void *stream);
+                const void *res, void *out, void *aux, const void *aux2, void *stream);
 
 /* GLU backward on the packed pre-activation Z [M][ldz] (n_groups x (16 a | 16 b));
  * dOut [M][ldo] has 16 channels per group (n_out valid columns); dZ has Z's layout. */
 int cum_glu_bwd(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Z,
                 int64_t ldz, const void *dOut, int64_t ldo, void *dZ, void *stream);
+/* Same from the gate-only form: Bg [M][ldb] (gate pre-activations, 16 per group) and Y [M][ldy] (the GLU
+ * output); dZ [M][ldz] in the packed (16 a | 16 b) layout. */
+int cum_glu_bwd_gate(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Bg,
+                     int64_t ldb, const void *Y, int64_t ldy, const void *dOut, int64_t ldo, void *dZ,
+                     int64_t ldz, void *stream);
 
 /* dZ = dOut * (Y > 0) over M rows x n_cols columns (n_cols multiple of 4).  zero_head / zero_tail:
  * elements in front of dZ[0] / behind dZ[M*ldz] to clear (leading zero row / slack rows). */

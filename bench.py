@@ -163,7 +163,7 @@ def other_kernels(dev):
     ms = t_fb - t_f
     byt = bsz * L * (2 * 7 * dim + 4 * 4 * Ns)           # u, delta, z, dout, du, ddelta, dz in bf16; B, C, dB, dC in f32
     gbs = byt / (ms * 1e-3) / 1e9
-    out.append({"kernel": "scan_bwd_kernel<8,true,bf16> + finalize (B=16,D=2048,N=64,L=624)", "bound": "hbm",
+    out.append({"kernel": "scan_bwd_kernel<8,LDS B/C,bf16> + finalize (B=16,D=2048,N=64,L=624)", "bound": "hbm",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "launch_ms": round(ms, 4), "algorithmic_bytes": byt,
                 "state_updates_per_s": round(upd / (ms * 1e-3) / 1e12, 3), "state_updates_unit": "T/s",

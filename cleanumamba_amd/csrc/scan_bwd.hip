@@ -15,6 +15,7 @@
 // v_permlane32_swap / v_permlane16_swap + DPP row adds; sums over workgroups (dB, dC)
 // and over the batch (dA, dD, dbias) go through fp32 slabs and a deterministic finalize
 // kernel -- no float atomics, bit-reproducible run to run.
+#include <stdlib.h>
 #include "scan_common.h"
 
 namespace cum {
@@ -43,9 +44,20 @@ __device__ __forceinline__ void wave_reduce_scatter8(const float (&v)[NS], float
   r[1] = row16_allsum(q[1]);
 }
 
-template <int NW, bool FAST, typename TIO>
+// BC = 0: B_t / C_t through scalar loads, generic strides; 1: scalar loads, unit stride, all NS states valid;
+// 2: the chunk's B / C tiles staged in LDS by the whole workgroup (one coalesced load per chunk, broadcast
+// ds_read_b128 per step): no SGPR pressure -- the scalar variants keep 256 B/C values per chunk in flight and spend
+// ~20 % of their VALU instructions moving spilled SGPRs through VGPR lanes.
+template <int NW, int BC, typename TIO>
 __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
+  constexpr bool FAST = BC == 1;
+  constexpr bool LDSBC = BC == 2;
   constexpr int K = (TB + NW - 1) / NW;
+  constexpr int NT = NW * 64;
+  constexpr int NP = NW * NS;
+  constexpr int BCK = LDSBC ? (TB * NP + NT - 1) / NT : 1;
+  __shared__ __attribute__((aligned(16))) float s_B[LDSBC ? TB : 1][LDSBC ? NP : 4];
+  __shared__ __attribute__((aligned(16))) float s_C[LDSBC ? TB : 1][LDSBC ? NP : 4];
   __shared__ float s_dt[TB][64];
   __shared__ float s_du[TB][64];
   __shared__ float s_dy[TB][64];
@@ -53,6 +65,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   __shared__ float s_p2[NW][SUB][64];  // sum_n dx * B   (-> ddelta, du)
   __shared__ float s_y[NW][SUB][64];   // sum_n C * x_t  (-> dz)
 
+  const int tid = threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int w = uniform(threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -97,9 +110,22 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   float accD = 0.f, accBias = 0.f;
 
   // raw (t, d) rows of the chunk about to be processed; fetched one chunk ahead
-  float ru[K], rdl[K], rz[K], rdo[K];
+  float ru[K], rdl[K], rz[K], rdo[K], rb[BCK], rc[BCK];
+  const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
   auto load_rows = [&](int c) {
     const int t0 = c * TB, tlast = L - 1 - t0;
+    if constexpr (LDSBC) {
+#pragma unroll
+      for (int k = 0; k < BCK; ++k) {
+        const int e = tid + k * NT;
+        const int tl = e / NP, n = e % NP;
+        const int t = t0 + (tl <= tlast ? tl : tlast);
+        const int nc = n < N ? n : N - 1;
+        const float bvv = Bb[t * B_sl + nc * B_sn], cvv = Cb[t * C_sl + nc * C_sn];
+        rb[k] = n < N ? bvv : 0.f;
+        rc[k] = n < N ? cvv : 0.f;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int tl = w + k * NW;
@@ -149,6 +175,16 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       }
       eu[k] = uv; ez[k] = zv; edo[k] = dov; edt[k] = dtv; esg[k] = sg;
     }
+    if constexpr (LDSBC) {
+#pragma unroll
+      for (int k = 0; k < BCK; ++k) {
+        const int e = tid + k * NT;
+        if (e < TB * NP) {
+          (&s_B[0][0])[e] = rb[k];
+          (&s_C[0][0])[e] = rc[k];
+        }
+      }
+    }
     if (c > 0) load_rows(c - 1);
     __syncthreads();
 
@@ -160,8 +196,15 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     };
     auto fetch = [&](int tl, StepOps &o) {
       const int tc = tl <= tlast ? tl : tlast;
-      load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, o.bv);
-      load_bc<FAST>(opaque(Cw + (t0 + tc) * C_sl), C_sn, nvalid, o.cv);
+      if constexpr (LDSBC) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(&s_B[tc][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[tc][n0 + 4]);
+        const float4 c0 = *reinterpret_cast<const float4 *>(&s_C[tc][n0]), c1 = *reinterpret_cast<const float4 *>(&s_C[tc][n0 + 4]);
+        o.bv[0] = b0.x; o.bv[1] = b0.y; o.bv[2] = b0.z; o.bv[3] = b0.w; o.bv[4] = b1.x; o.bv[5] = b1.y; o.bv[6] = b1.z; o.bv[7] = b1.w;
+        o.cv[0] = c0.x; o.cv[1] = c0.y; o.cv[2] = c0.z; o.cv[3] = c0.w; o.cv[4] = c1.x; o.cv[5] = c1.y; o.cv[6] = c1.z; o.cv[7] = c1.w;
+      } else {
+        load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, o.bv);
+        load_bc<FAST>(opaque(Cw + (t0 + tc) * C_sl), C_sn, nvalid, o.cv);
+      }
       o.dt = s_dt[tl][lane];
       o.du = s_du[tl][lane];
       o.dy = s_dy[tl][lane];
@@ -367,14 +410,24 @@ __global__ void scan_bwd_finalize_kernel(const ScanParams p, float *dA, float *d
   }
 }
 
+static int scan_bwd_variant() {
+  static const int v = [] {
+    const char *e = getenv("CUM_SCAN_BWD_LDS");   // "0" selects the scalar-load variants (kept for A/B runs)
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return v;
+}
+
 template <int NW, typename TIO>
 static int launch_bwd_io(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
   const bool fast = p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW;
-  if (fast)
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, true, TIO>), grid, block, 0, st, p);
+  if (scan_bwd_variant() == 1)
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO>), grid, block, 0, st, p);
+  else if (fast)
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, 1, TIO>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, false, TIO>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, 0, TIO>), grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }

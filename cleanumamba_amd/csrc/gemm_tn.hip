@@ -17,6 +17,7 @@
 // lane ends with 4 consecutive k of one output row n: 16-byte slab stores.
 // Column sums of dZ (the bias gradient) are accumulated from the registers that stage
 // dZ, for free, by the workgroups of the first k tile.
+#include <stdlib.h>
 #include "common.h"
 
 namespace cum {
@@ -277,7 +278,17 @@ static void tn_plan(int64_t M, int32_t N, int32_t K, int32_t dtype, int *Np, int
   *Kp = (K + TN_T - 1) / TN_T * TN_T;
   const int tiles = (*Np / TN_T) * (*Kp / TN_T);
   const int bmk = dtype == CUM_BF16 ? 32 : 16;
-  int64_t want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
+  // Splits are dealt to the 8 XCDs round-robin and an XCD holds 96 workgroups at a time (32 CUs x 3).  One split
+  // with >= 96 tiles already fills its XCD: 8 splits.  Smaller tile counts take as many splits per XCD as fit into
+  // ONE resident round (32 tiles -> 3 per XCD = 24 splits): a second, partly filled round costs a full round's
+  // time (measured on the E8 shapes: -18...-27 % against "about 1024 workgroups"), and every extra split adds a
+  // slab of Np x Kp floats to write and reduce.  CUM_TN_SPLITS pins the count for experiments.
+  const int per_xcd = tiles >= 96 ? 1 : 96 / tiles;
+  int64_t want = 8 * per_xcd;
+  {
+    static const int force = [] { const char *e = getenv("CUM_TN_SPLITS"); return e ? atoi(e) : 0; }();
+    if (force > 0) want = force;
+  }
   const int64_t max_s = (M + 8 * bmk - 1) / (8 * bmk);  // at least 8 steps per split
   if (want > max_s) want = max_s;
   if (want < 1) want = 1;

@@ -161,25 +161,63 @@ __device__ __forceinline__ void nt_load_bias(const GemmParams &p, int n0, int wn
   }
 }
 
+// Raw 4-element vector of T: loads are issued first and converted only where they are consumed, so that the loads of
+// a whole 16-row slab are in flight together.
+template <typename T>
+struct Raw4;
+template <>
+struct Raw4<float> {
+  float4 v;
+  __device__ __forceinline__ void ld(const float *p) { v = *reinterpret_cast<const float4 *>(p); }
+  __device__ __forceinline__ void get(float (&o)[4]) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+template <>
+struct Raw4<__bf16> {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  bf16x4 v;
+  __device__ __forceinline__ void ld(const __bf16 *p) { v = *reinterpret_cast<const bf16x4 *>(p); }
+  __device__ __forceinline__ void get(float (&o)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+  }
+};
+
 // Epilogue of a wave's 64x64 sub-tile at (m0 + 64 wm, n0 + 64 wn).
+//
+// Per 16-row slab (mi): every global load the slab needs (residual / ReLU mask / gate / saved output) is issued from
+// a clamped, always-valid address with no branch in between, then the values are combined and stored under
+// predicates.  The straightforward form -- load, wait, compute, store per 16x16 tile inside per-lane `continue`s --
+// serialised 16 (MASK) to 48 (GLU_BWD) memory round trips per tile.
 template <typename T, int EPI>
 __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&acc)[4][4], const float (&bv)[4][4],
                                             int m0, int n0, int wm, int wn, int g, int r) {
-  // ---- epilogue: lane holds D[n = nb + 4g + j][m = mb + r], j = 0..3 -> 4 consecutive channels of row m
-  T *out = static_cast<T *>(p.out);
-  T *aux = static_cast<T *>(p.aux);
-  const T *res = static_cast<const T *>(p.res);
+  // lane holds D[n = nb + 4g + j][m = mb + r], j = 0..3 -> 4 consecutive channels of row m.
+  // No two of these buffers overlap.
+  T *__restrict__ out = static_cast<T *>(p.out);
+  T *__restrict__ aux = static_cast<T *>(p.aux);
+  const T *__restrict__ res = static_cast<const T *>(p.res);
+  const T *__restrict__ aux2 = static_cast<const T *>(p.aux2);
+  const int nw0 = n0 + wn * 64;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + r;
-    if (m >= p.M) continue;
-    const bool real = (m % p.pitch) < p.valid;
+    const int m_raw = m0 + wm * 64 + mi * 16 + r;
+    const bool live = m_raw < p.M;
+    const int64_t m = live ? m_raw : p.M - 1;            // clamped row for the loads
+    const bool real = live && (m_raw % p.pitch) < p.valid;
     if constexpr (EPI == EPI_GLU) {
+      Raw4<T> rres[2];
+      bool on[2];
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const int oc = nw0 / 2 + pi * 16 + 4 * g;
+        on[pi] = live && oc < p.n_store;
+        if (res) rres[pi].ld(res + m * p.ldr + (oc < p.n_store ? oc : 0));
+      }
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {  // tile pair (2*pi, 2*pi+1) = (a, b)
-        const int na = n0 + wn * 64 + (2 * pi) * 16 + 4 * g;
+        const int na = nw0 + (2 * pi) * 16 + 4 * g;
         const int nb = na + 16;
-        if (na >= p.N) continue;
+        const int oc = nw0 / 2 + pi * 16 + 4 * g;
         float a[4], b[4], o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -187,101 +225,99 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
           b[j] = acc[2 * pi + 1][mi][j] + bv[2 * pi + 1][j];
           o[j] = real ? a[j] * sigmoidf_(b[j]) : 0.f;
         }
-        const int oc = (n0 + wn * 64) / 2 + pi * 16 + 4 * g;
-        if (aux) {
+        if (aux && live && na < p.N) {
           if (p.gate_only) {
-            store4<T>(aux + (int64_t)m * p.ldz + oc, b);
+            store4<T>(aux + m * p.ldz + oc, b);
           } else {
-            store4<T>(aux + (int64_t)m * p.ldz + na, a);
-            store4<T>(aux + (int64_t)m * p.ldz + nb, b);
+            store4<T>(aux + m * p.ldz + na, a);
+            store4<T>(aux + m * p.ldz + nb, b);
           }
         }
-        if (oc < p.n_store) {
-          if (res) {
-            float rr[4];
-            load4<T>(res + (int64_t)m * p.ldr + oc, rr);
+        if (res) {
+          float rr[4];
+          rres[pi].get(rr);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
-          }
-          store4<T>(out + (int64_t)m * p.ldc + oc, o);
+          for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
         }
+        if (on[pi] && na < p.N) store4<T>(out + m * p.ldc + oc, o);
       }
     } else if constexpr (EPI == EPI_GLU_BWD) {
       // d = acc (+ res) is the gradient of a GLU output; the 16-column tile t of row m pairs with columns
       // [32t, 32t+16) (a) and [32t+16, 32t+32) (b) of Z row m, and dZ is written in Z's layout.
+      Raw4<T> rres[4], ra[4], rb[4];
+      bool on[4];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-        if (n >= p.n_store) continue;
-        const int64_t zc = 2 * (n0 + wn * 64 + ni * 16) + 4 * g;
+        const int n = nw0 + ni * 16 + 4 * g;
+        on[ni] = live && n < p.n_store;
+        const bool nok = n < p.n_store;
+        const int nc = nok ? n : 0;
+        const int64_t zc = nok ? 2 * (int64_t)(nw0 + ni * 16) + 4 * g : 4 * g;
+        if (res) rres[ni].ld(res + m * p.ldr + nc);
+        if (p.gate_only) {
+          rb[ni].ld(aux + m * p.ldz + nc);
+          ra[ni].ld(aux2 + m * p.ldy + nc);       // the saved output y = a * sig(b)
+        } else {
+          ra[ni].ld(aux + m * p.ldz + zc);
+          rb[ni].ld(aux + m * p.ldz + zc + 16);
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int64_t zc = 2 * (int64_t)(nw0 + ni * 16) + 4 * g;
         float d[4], a[4], b[4], da[4], db[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = acc[ni][mi][j];
         if (res) {
           float rr[4];
-          load4<T>(res + (int64_t)m * p.ldr + n, rr);
+          rres[ni].get(rr);
 #pragma unroll
           for (int j = 0; j < 4; ++j) d[j] += rr[j];
         }
-        if (p.gate_only) {
-          // a * sig(b) is the saved output y:  db = d * y * (1 - sig(b)) needs no a
-          load4<T>(aux + (int64_t)m * p.ldz + n, b);
-          load4<T>(static_cast<const T *>(p.aux2) + (int64_t)m * p.ldy + n, a);
+        ra[ni].get(a);
+        rb[ni].get(b);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float sg = sigmoidf_(b[j]);
-            const float dj = real ? d[j] : 0.f;
-            da[j] = dj * sg;
-            db[j] = dj * a[j] * (1.f - sg);
-          }
-        } else {
-          load4<T>(aux + (int64_t)m * p.ldz + zc, a);
-          load4<T>(aux + (int64_t)m * p.ldz + zc + 16, b);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float sg = sigmoidf_(b[j]);
-            const float dj = real ? d[j] : 0.f;
-            da[j] = dj * sg;
-            db[j] = dj * a[j] * sg * (1.f - sg);
-          }
+        for (int j = 0; j < 4; ++j) {
+          const float sg = sigmoidf_(b[j]);
+          const float dj = real ? d[j] : 0.f;
+          da[j] = dj * sg;
+          db[j] = p.gate_only ? dj * a[j] * (1.f - sg) : dj * a[j] * sg * (1.f - sg);
         }
-        store4<T>(out + (int64_t)m * p.ldc + zc, da);
-        store4<T>(out + (int64_t)m * p.ldc + zc + 16, db);
-      }
-    } else if constexpr (EPI == EPI_MASK) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-        if (n >= p.n_store) continue;
-        float v[4], y[4];
-        load4<T>(res + (int64_t)m * p.ldr + n, y);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = real ? acc[ni][mi][j] + bv[ni][j] : 0.f;
-        if (aux) store4<T>(aux + (int64_t)m * p.ldz + n, v);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
-        store4<T>(out + (int64_t)m * p.ldc + n, v);
+        if (on[ni]) {
+          store4<T>(out + m * p.ldc + zc, da);
+          store4<T>(out + m * p.ldc + zc + 16, db);
+        }
       }
     } else {
+      Raw4<T> rres[4];
+      bool on[4];
+      constexpr bool kMask = EPI == EPI_MASK;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-        if (n >= p.n_store) continue;
-        float v[4];
+        const int n = nw0 + ni * 16 + 4 * g;
+        on[ni] = live && n < p.n_store;
+        if (kMask || res) rres[ni].ld(res + m * p.ldr + (n < p.n_store ? n : 0));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = nw0 + ni * 16 + 4 * g;
+        float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           v[j] = acc[ni][mi][j] + bv[ni][j];
           if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
           v[j] = real ? v[j] : 0.f;
         }
-        if (aux) store4<T>(aux + (int64_t)m * p.ldz + n, v);
-        if (res) {
-          float rr[4];
-          load4<T>(res + (int64_t)m * p.ldr + n, rr);
+        if (kMask || res) rres[ni].get(rr);
+        if (aux && on[ni]) store4<T>(aux + m * p.ldz + n, v);      // ungated / pre-residual value
+        if constexpr (kMask) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = rr[j] > 0.f ? v[j] : 0.f;
+        } else if (res) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = real ? v[j] + rr[j] : 0.f;
         }
-        store4<T>(out + (int64_t)m * p.ldc + n, v);
+        if (on[ni]) store4<T>(out + m * p.ldc + n, v);
       }
     }
   }

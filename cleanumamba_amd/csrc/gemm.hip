@@ -184,10 +184,12 @@ struct Raw4<__bf16> {
 
 // Epilogue of a wave's 64x64 sub-tile at (m0 + 64 wm, n0 + 64 wn).
 //
-// Per 16-row slab (mi): every global load the slab needs (residual / ReLU mask / gate / saved output) is issued from
-// a clamped, always-valid address with no branch in between, then the values are combined and stored under
-// predicates.  The straightforward form -- load, wait, compute, store per 16x16 tile inside per-lane `continue`s --
-// serialised 16 (MASK) to 48 (GLU_BWD) memory round trips per tile.
+// Per 16-row slab (mi) every global load the slab needs (residual / ReLU mask / gate / saved output) is issued from
+// a clamped, always-valid address with no branch in between, and (where registers allow) the loads of slab mi+1 are
+// issued BEFORE the stores of slab mi (vmcnt counts in order: waiting for those loads never waits for younger
+// stores).  The
+// straightforward form -- load, wait, compute, store per 16x16 tile inside per-lane `continue`s -- serialised 16
+// (MASK) to 48 (GLU_BWD) memory round trips per tile.
 template <typename T, int EPI>
 __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&acc)[4][4], const float (&bv)[4][4],
                                             int m0, int n0, int wm, int wn, int g, int r) {
@@ -198,21 +200,54 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
   const T *__restrict__ res = static_cast<const T *>(p.res);
   const T *__restrict__ aux2 = static_cast<const T *>(p.aux2);
   const int nw0 = n0 + wn * 64;
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  constexpr bool kMask = EPI == EPI_MASK;
+  constexpr int NL = EPI == EPI_GLU ? 2 : 4;           // loads of one kind per slab
+  struct Slab {
+    Raw4<T> r[NL], a[EPI == EPI_GLU_BWD ? 4 : 1], b[EPI == EPI_GLU_BWD ? 4 : 1];
+  };
+  auto row_of = [&](int mi, bool &live) {
     const int m_raw = m0 + wm * 64 + mi * 16 + r;
-    const bool live = m_raw < p.M;
-    const int64_t m = live ? m_raw : p.M - 1;            // clamped row for the loads
-    const bool real = live && (m_raw % p.pitch) < p.valid;
+    live = m_raw < p.M;
+    return (int64_t)(live ? m_raw : p.M - 1);          // clamped row for the loads
+  };
+  auto issue = [&](int mi, Slab &s) {
+    bool live;
+    const int64_t m = row_of(mi, live);
     if constexpr (EPI == EPI_GLU) {
-      Raw4<T> rres[2];
-      bool on[2];
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         const int oc = nw0 / 2 + pi * 16 + 4 * g;
-        on[pi] = live && oc < p.n_store;
-        if (res) rres[pi].ld(res + m * p.ldr + (oc < p.n_store ? oc : 0));
+        if (res) s.r[pi].ld(res + m * p.ldr + (oc < p.n_store ? oc : 0));
       }
+    } else if constexpr (EPI == EPI_GLU_BWD) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = nw0 + ni * 16 + 4 * g;
+        const bool nok = n < p.n_store;
+        const int nc = nok ? n : 0;
+        const int64_t zc = nok ? 2 * (int64_t)(nw0 + ni * 16) + 4 * g : 4 * g;
+        if (res) s.r[ni].ld(res + m * p.ldr + nc);
+        if (p.gate_only) {
+          s.b[ni].ld(aux + m * p.ldz + nc);
+          s.a[ni].ld(aux2 + m * p.ldy + nc);       // the saved output y = a * sig(b)
+        } else {
+          s.a[ni].ld(aux + m * p.ldz + zc);
+          s.b[ni].ld(aux + m * p.ldz + zc + 16);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = nw0 + ni * 16 + 4 * g;
+        if (kMask || res) s.r[ni].ld(res + m * p.ldr + (n < p.n_store ? n : 0));
+      }
+    }
+  };
+  auto finish = [&](int mi, const Slab &s) {
+    bool live;
+    const int64_t m = row_of(mi, live);
+    const bool real = live && (m % p.pitch) < p.valid;
+    if constexpr (EPI == EPI_GLU) {
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {  // tile pair (2*pi, 2*pi+1) = (a, b)
         const int na = nw0 + (2 * pi) * 16 + 4 * g;
@@ -235,47 +270,30 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
         }
         if (res) {
           float rr[4];
-          rres[pi].get(rr);
+          s.r[pi].get(rr);
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
         }
-        if (on[pi] && na < p.N) store4<T>(out + m * p.ldc + oc, o);
+        if (live && oc < p.n_store && na < p.N) store4<T>(out + m * p.ldc + oc, o);
       }
     } else if constexpr (EPI == EPI_GLU_BWD) {
       // d = acc (+ res) is the gradient of a GLU output; the 16-column tile t of row m pairs with columns
       // [32t, 32t+16) (a) and [32t+16, 32t+32) (b) of Z row m, and dZ is written in Z's layout.
-      Raw4<T> rres[4], ra[4], rb[4];
-      bool on[4];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         const int n = nw0 + ni * 16 + 4 * g;
-        on[ni] = live && n < p.n_store;
-        const bool nok = n < p.n_store;
-        const int nc = nok ? n : 0;
-        const int64_t zc = nok ? 2 * (int64_t)(nw0 + ni * 16) + 4 * g : 4 * g;
-        if (res) rres[ni].ld(res + m * p.ldr + nc);
-        if (p.gate_only) {
-          rb[ni].ld(aux + m * p.ldz + nc);
-          ra[ni].ld(aux2 + m * p.ldy + nc);       // the saved output y = a * sig(b)
-        } else {
-          ra[ni].ld(aux + m * p.ldz + zc);
-          rb[ni].ld(aux + m * p.ldz + zc + 16);
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
         const int64_t zc = 2 * (int64_t)(nw0 + ni * 16) + 4 * g;
         float d[4], a[4], b[4], da[4], db[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = acc[ni][mi][j];
         if (res) {
           float rr[4];
-          rres[ni].get(rr);
+          s.r[ni].get(rr);
 #pragma unroll
           for (int j = 0; j < 4; ++j) d[j] += rr[j];
         }
-        ra[ni].get(a);
-        rb[ni].get(b);
+        s.a[ni].get(a);
+        s.b[ni].get(b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float sg = sigmoidf_(b[j]);
@@ -283,24 +301,16 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
           da[j] = dj * sg;
           db[j] = p.gate_only ? dj * a[j] * (1.f - sg) : dj * a[j] * sg * (1.f - sg);
         }
-        if (on[ni]) {
+        if (live && n < p.n_store) {
           store4<T>(out + m * p.ldc + zc, da);
           store4<T>(out + m * p.ldc + zc + 16, db);
         }
       }
     } else {
-      Raw4<T> rres[4];
-      bool on[4];
-      constexpr bool kMask = EPI == EPI_MASK;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         const int n = nw0 + ni * 16 + 4 * g;
-        on[ni] = live && n < p.n_store;
-        if (kMask || res) rres[ni].ld(res + m * p.ldr + (n < p.n_store ? n : 0));
-      }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = nw0 + ni * 16 + 4 * g;
+        const bool on = live && n < p.n_store;
         float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -308,8 +318,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
           if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
           v[j] = real ? v[j] : 0.f;
         }
-        if (kMask || res) rres[ni].get(rr);
-        if (aux && on[ni]) store4<T>(aux + m * p.ldz + n, v);      // ungated / pre-residual value
+        if (kMask || res) s.r[ni].get(rr);
+        if (aux && on) store4<T>(aux + m * p.ldz + n, v);      // ungated / pre-residual value
         if constexpr (kMask) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = rr[j] > 0.f ? v[j] : 0.f;
@@ -317,8 +327,26 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = real ? v[j] + rr[j] : 0.f;
         }
-        if (on[ni]) store4<T>(out + m * p.ldc + n, v);
+        if (on) store4<T>(out + m * p.ldc + n, v);
       }
+    }
+  };
+  if constexpr (EPI == EPI_GLU_BWD) {
+    // 12 loads per slab: two slabs in flight would spill (128-VGPR budget of 4 waves per SIMD)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      Slab cur;
+      issue(mi, cur);
+      finish(mi, cur);
+    }
+  } else {
+    Slab cur, nxt;
+    issue(0, cur);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      if (mi + 1 < 4) issue(mi + 1, nxt);
+      finish(mi, cur);
+      cur = nxt;
     }
   }
 }

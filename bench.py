@@ -51,7 +51,7 @@ def parse():
 MFMA_PEAK_TFS = 2500.0      # MI355X_MICROARCH.md: bf16 dense
 # PMC passes of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over tools/bench_gemm.py tn (profiles/r01_gemm_tn_pmc.md):
 # HBM bytes per gemm_tn launch (kernel + slab reduce), mean over the 16 encoder weight-gradient shapes
-TN_TRAFFIC_BYTES = 446.0e6
+TN_TRAFFIC_BYTES = 409.1e6
 
 B16 = 16
 ENC_T = [160254, 80126, 40062, 20030, 10014, 5006, 2502, 1250, 624]

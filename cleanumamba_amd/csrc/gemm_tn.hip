@@ -224,34 +224,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 // Slab reduction, parallel over outputs AND over slabs, fixed summation order (deterministic).
 //   in : [S][rows][ld_in] f32        out: [gridDim.y][rows][ld_out] partial sums of S / gridDim.y slabs each
-// A workgroup = 64 float4 outputs x 4 slab lanes; lanes are combined through LDS.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict__ in, int S, int64_t in_slab, int ld_in,
-                                                        int rows, int cols4, float *__restrict__ out, int64_t out_slab,
-                                                        int64_t ld_out) {
+// A workgroup = 64 float4 outputs x 4 slab lanes; lanes are combined through LDS.  One launch carries two jobs (the
+// weight-gradient slabs and the bias-gradient slabs): workgroups [0, nb0) serve job 0, the rest job 1.
+struct ReduceJob {
+  const float *in;
+  float *out;
+  int64_t in_slab, out_slab, ld_out;
+  int ld_in, rows, cols4;
+};
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const ReduceJob j0, const ReduceJob j1, int nb0, int S) {
   __shared__ float4 red[4][64];
-  const int v = blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool first = (int)blockIdx.x < nb0;
+  const ReduceJob &j = first ? j0 : j1;
+  const int bx = first ? blockIdx.x : blockIdx.x - nb0;
+  const int v = bx * 64 + (threadIdx.x & 63);
   const int sl = threadIdx.x >> 6;
   const int chunks = gridDim.y, ch = blockIdx.y;
   const int per = (S + chunks - 1) / chunks;
   const int s0 = ch * per;
   int s1 = s0 + per;
   s1 = s1 < S ? s1 : S;
-  const int64_t total = (int64_t)rows * cols4;
+  const int64_t total = (int64_t)j.rows * j.cols4;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   int n = 0, k = 0;
   if (v < total) {
-    n = v / cols4;
-    k = (v % cols4) * 4;
-    const float *base = in + (int64_t)n * ld_in + k;
+    n = v / j.cols4;
+    k = (v % j.cols4) * 4;
+    const float *base = j.in + (int64_t)n * j.ld_in + k;
     int s = s0 + sl;
     for (; s + 4 < s1; s += 8) {  // two independent chains keep two loads in flight
-      const float4 x = *reinterpret_cast<const float4 *>(base + (int64_t)s * in_slab);
-      const float4 y = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 4) * in_slab);
+      const float4 x = *reinterpret_cast<const float4 *>(base + (int64_t)s * j.in_slab);
+      const float4 y = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 4) * j.in_slab);
       a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
       b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
     }
     for (; s < s1; s += 4) {
-      const float4 x = *reinterpret_cast<const float4 *>(base + (int64_t)s * in_slab);
+      const float4 x = *reinterpret_cast<const float4 *>(base + (int64_t)s * j.in_slab);
       a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
     }
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
@@ -261,11 +270,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict_
   if (sl == 0 && v < total) {
     float4 r = red[0][threadIdx.x];
 #pragma unroll
-    for (int j = 1; j < 4; ++j) {
-      const float4 t = red[j][threadIdx.x];
+    for (int q = 1; q < 4; ++q) {
+      const float4 t = red[q][threadIdx.x];
       r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
     }
-    *reinterpret_cast<float4 *>(out + (int64_t)ch * out_slab + (int64_t)n * ld_out + k) = r;
+    *reinterpret_cast<float4 *>(j.out + (int64_t)ch * j.out_slab + (int64_t)n * j.ld_out + k) = r;
   }
 }
 
@@ -341,28 +350,21 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   const int C = reduce_chunks(S);
   float *part = workspace + (int64_t)S * Np * Kp + (int64_t)S * Np;
   float *bpart = part + (int64_t)C * N * K;
-  const int cols4 = K / 4;
-  const unsigned gx = (unsigned)(((int64_t)N * cols4 + 63) / 64);
+  const int cols4 = K / 4, bc4 = N / 4;
+  const int gx = (int)(((int64_t)N * cols4 + 63) / 64), bx = db ? (bc4 + 63) / 64 : 0;
+  // job 0: dW slabs [S][Np][Kp]; job 1: bias slabs [S][Np] seen as one row of Np / 4 float4
   if (C == 1) {
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, p.slab, S, (int64_t)Np * Kp, Kp, N, cols4, dW, 0,
-                       ldw);
+    const ReduceJob w{p.slab, dW, (int64_t)Np * Kp, 0, ldw, Kp, N, cols4};
+    const ReduceJob bj{p.bslab, db, (int64_t)Np, 0, N, Np, 1, bc4};
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx + bx, 1), dim3(256), 0, st, w, bj, gx, S);
   } else {
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx, C), dim3(256), 0, st, p.slab, S, (int64_t)Np * Kp, Kp, N, cols4, part,
-                       (int64_t)N * K, (int64_t)K);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, part, C, (int64_t)N * K, K, N, cols4, dW, 0, ldw);
+    const ReduceJob w1{p.slab, part, (int64_t)Np * Kp, (int64_t)N * K, (int64_t)K, Kp, N, cols4};
+    const ReduceJob b1{p.bslab, bpart, (int64_t)Np, (int64_t)Np, (int64_t)Np, Np, 1, bc4};
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx + bx, C), dim3(256), 0, st, w1, b1, gx, S);
+    const ReduceJob w2{part, dW, (int64_t)N * K, 0, ldw, K, N, cols4};
+    const ReduceJob b2{bpart, db, (int64_t)Np, 0, N, Np, 1, bc4};
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx + bx, 1), dim3(256), 0, st, w2, b2, gx, C);
   }
   CUM_CHECK_LAUNCH();
-  if (db) {  // bias slabs are [S][Np]: treat as S x (1 row of Np/4 float4)
-    const int bc4 = N / 4;
-    const unsigned bx = (unsigned)((bc4 + 63) / 64);
-    if (C == 1) {
-      hipLaunchKernelGGL(tn_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, p.bslab, S, (int64_t)Np, Np, 1, bc4, db, 0, N);
-    } else {
-      hipLaunchKernelGGL(tn_reduce_kernel, dim3(bx, C), dim3(256), 0, st, p.bslab, S, (int64_t)Np, Np, 1, bc4, bpart,
-                         (int64_t)Np, (int64_t)Np);
-      hipLaunchKernelGGL(tn_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, bpart, C, (int64_t)Np, Np, 1, bc4, db, 0, N);
-    }
-    CUM_CHECK_LAUNCH();
-  }
   return CUM_OK;
 }

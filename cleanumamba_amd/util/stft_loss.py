@@ -6,8 +6,8 @@ ParallelWaveGAN): per resolution a spectral-convergence term
 averaged over resolutions and weighted by sc_lambda / mag_lambda.
 
 On the GPU one resolution is: cum_stft_frames (window + reflect padding, both signals) -> one batched
-rocFFT r2c -> cum_stft_loss_fwd (both terms, deterministic tree sums); backward is cum_stft_loss_bwd ->
-one unnormalised c2r -> cum_stft_fold (overlap-add gather).  The reference's ~25 elementwise passes per
+rocFFT r2c (cum_rfft) -> cum_stft_loss_fwd (both terms, deterministic tree sums); backward is cum_stft_loss_bwd ->
+one unnormalised c2r (cum_irfft) -> cum_stft_fold (overlap-add gather).  The reference's ~25 elementwise passes per
 resolution and direction never touch HBM.  CPU tensors take the plain torch.stft route below (host-side
 checks only; the train step never does).
 """
@@ -45,9 +45,11 @@ class STFTLossFn(torch.autograd.Function):
             for i, sig in enumerate((x, y)):
                 hip.check(lib.cum_stft_frames(hip.ptr(sig), bsz, L, sig.stride(0), n_fft, hop, win_length,
                                               hip.ptr(window), hip.ptr(frames[i]), n_frames, st))
-            spec = torch.fft.rfft(frames, dim=-1)               # rocFFT, one batched r2c for both signals
-            del frames
+            # rocFFT, one batched r2c for both signals; `frames` is scratch and may be overwritten
+            spec = torch.empty(2, bsz, n_frames, bins, dtype=torch.complex64, device=x.device)
             sr = torch.view_as_real(spec)
+            hip.check(lib.cum_rfft(n_fft, 2 * bsz * n_frames, hip.ptr(frames), hip.ptr(sr), st))
+            del frames
             hip.check(lib.cum_stft_loss_fwd(hip.ptr(sr[0]), hip.ptr(sr[1]), bsz, n_frames, bins, frame0, hip.ptr(ws),
                                             hip.ptr(stats), st))
         ctx.save_for_backward(spec, stats, window)
@@ -74,7 +76,8 @@ class STFTLossFn(torch.autograd.Function):
             st = hip.stream_ptr()
             hip.check(lib.cum_stft_loss_bwd(hip.ptr(sr[0]), hip.ptr(sr[1]), bsz, n_frames, bins, frame0, hip.ptr(stats),
                                             hip.ptr(g_sc), hip.ptr(g_mag), hip.ptr(torch.view_as_real(z)), st))
-            dframes = torch.fft.irfft(z, n=n_fft, dim=-1, norm="forward")      # unnormalised c2r
+            dframes = torch.empty(bsz, n_frames, n_fft, dtype=torch.float32, device=spec.device)
+            hip.check(lib.cum_irfft(n_fft, bsz * n_frames, hip.ptr(torch.view_as_real(z)), hip.ptr(dframes), st))
             hip.check(lib.cum_stft_fold(hip.ptr(dframes), bsz, L, n_fft, hop, win_length, hip.ptr(window), n_frames,
                                         hip.ptr(dx), dx.stride(0), 0, st))
         return dx, None, None, None, None, None, None

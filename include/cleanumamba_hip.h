@@ -250,6 +250,14 @@ int cum_stft_fold(const float *dframes, int64_t batch, int64_t len, int32_t n_ff
 int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n, int32_t dst_dtype, void *dst,
                void *stream);
 
+/* Batched 1-D real FFTs for the STFT loss, on hipFFT / rocFFT (torch.stft's transform, src/util/stft_loss.py:29-33, and
+ * its autograd).  Unnormalised in both directions.  The INPUT buffer may be overwritten (rocFFT's real transforms
+ * do that for some lengths): pass scratch.  cum_rfft: in [batch][n] real -> out [batch][n/2+1] interleaved complex;
+ * cum_irfft: in [batch][n/2+1] complex -> out [batch][n] real.  Plans (and their hipFFT work areas) are created on
+ * first use of a (device, n, batch, direction) and cached for the life of the process. */
+int cum_rfft(int32_t n, int64_t batch, float *in, float *out, void *stream);
+int cum_irfft(int32_t n, int64_t batch, float *in, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

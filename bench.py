@@ -209,7 +209,7 @@ def main():
 
     from cleanumamba_amd import hip
     from cleanumamba_amd.network import Net
-    from cleanumamba_amd.training.train_distributed import apply_gradient_allreduce, init_distributed
+    from cleanumamba_amd.training.train_distributed import apply_gradient_allreduce
     from cleanumamba_amd.training.train_step import TrainStep
     hip.lib()
 

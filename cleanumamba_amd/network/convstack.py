@@ -61,18 +61,6 @@ def bk_of(dtype):
     return 64 if dtype == torch.bfloat16 else 32
 
 
-def _pad2(w, rows, cols):
-    out = torch.zeros(rows, cols, dtype=w.dtype, device=w.device)
-    out[:w.shape[0], :w.shape[1]] = w
-    return out
-
-
-def _padv(b, n):
-    out = torch.zeros(n, dtype=torch.float32, device=b.device)
-    out[:b.shape[0]] = b.float()
-    return out
-
-
 # ------------------------------------------------------------------ GEMM launcher
 def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_store, res=None, r_off=0, ldr=0,
          aux=None, x_off=0, ldz=0, geo=None, aux2=None, y_off=0, ldy=0, gate_only=False):

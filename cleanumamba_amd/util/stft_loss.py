@@ -11,8 +11,6 @@ one unnormalised c2r (cum_irfft) -> cum_stft_fold (overlap-add gather).  The ref
 resolution and direction never touch HBM.  CPU tensors take the plain torch.stft route below (host-side
 checks only; the train step never does).
 """
-import ctypes
-
 import torch
 import torch.nn.functional as F
 

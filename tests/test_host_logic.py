@@ -135,3 +135,11 @@ print("ok")
     from conftest import ROOT
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_graft_entry_build_is_consistent_with_the_header():
+    """build() compiles (incrementally) and checks the library's ABI version against include/cleanumamba_hip.h."""
+    import __graft_entry__ as g
+    g.build()
+    from cleanumamba_amd import hip
+    assert set(hip.SIGNATURES) and hip.lib().cum_abi_version() >= 3

@@ -273,6 +273,8 @@ def main():
             out["roofline"] = tn_roofline(dev)
             if world == 1:
                 out["kernels"] = other_kernels(dev)
+                # the kernel north_star names, against the HBM roof it nominates (issue-bound at N = 64: DESIGN.md 3.1)
+                out["north_star_kernel"] = next(k for k in out["kernels"] if k["kernel"].startswith("scan_fwd"))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_clip)
         print(json.dumps(out), flush=True)

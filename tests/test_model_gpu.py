@@ -173,12 +173,14 @@ def test_ragged_lengths_vs_oracle(cuda, L):
     assert rel_l2(y, ref) < E2E_TOL
 
 
-def test_full_size_e8_fused_path_equals_module_path(cuda):
-    """BASELINE full size (E8, 10 s @ 16 kHz): the fused GEMM conv stack and the torch-module conv stack are two
-    independent implementations of the same layers; they must agree in f32, forward and input-independent
-    gradient norms (size-independent cross-check where the CPU oracle would take minutes)."""
+@pytest.mark.parametrize("name", ["e2e_e8_synth", "e2e_e6_synth"])
+def test_full_size_fused_path_equals_module_path(cuda, name):
+    """BASELINE full sizes (E8: T = 624 at the bottleneck; E6: T = 2499; 10 s @ 16 kHz): the fused GEMM conv stack and
+    the torch-module conv stack are two independent implementations of the same layers; they must agree in f32,
+    forward and input-independent gradient norms (size-independent cross-check where the CPU oracle would take
+    minutes)."""
     from cleanumamba_amd.network import CleanUMamba
-    g = load_golden("e2e_e8_synth")
+    g = load_golden(name)
     meta = golden_json(g["meta"])
     net = CleanUMamba(**meta["cfg"])
     net.load_state_dict(synth.fill_state_dict(dict(zip(meta["keys"], meta["shapes"])), seed=meta["seed"]), strict=True)

@@ -48,6 +48,9 @@ struct GemmParams {
   const void *aux2;        // gate_only GLU_BWD: the GLU output y saved by the forward [M][ldy]
   int64_t lda, ldw, ldc, ldr, ldz, ldy;
   int gate_only;           // GLU / GLU_BWD: aux holds only the gate pre-activation b ([M][ldz], output-column order)
+  int mask_bits;           // RELU: aux receives the SIGN (value > 0) of each element instead of the activation, four
+                           // consecutive channels per byte (low nibble; byte index (m * ld + n) / 4) -- what a lane
+                           // holds after the MFMA, so no cross-lane packing; MASK: res is such an array.
   int M, N, K;             // N multiple of 16 (32 for GLU), K multiple of the K tile
   int pitch, valid;        // row m is real iff (m % pitch) < valid; other rows are stored as zeros
   int n_store;             // number of output columns to store (<= N, or N/2 for GLU); multiple of 4
@@ -204,6 +207,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
   constexpr int NL = EPI == EPI_GLU ? 2 : 4;           // loads of one kind per slab
   struct Slab {
     Raw4<T> r[NL], a[EPI == EPI_GLU_BWD ? 4 : 1], b[EPI == EPI_GLU_BWD ? 4 : 1];
+    unsigned char mw[4];       // MASK with mask_bits: this lane's sign nibbles of the slab's four tiles
   };
   auto row_of = [&](int mi, bool &live) {
     const int m_raw = m0 + wm * 64 + mi * 16 + r;
@@ -239,7 +243,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         const int n = nw0 + ni * 16 + 4 * g;
-        if (kMask || res) s.r[ni].ld(res + m * p.ldr + (n < p.n_store ? n : 0));
+        if (kMask && p.mask_bits) {
+          s.mw[ni] = reinterpret_cast<const unsigned char *>(p.res)[(m * p.ldr + (n < p.n_store ? n : 0)) >> 2];
+        } else if (kMask || res) {
+          s.r[ni].ld(res + m * p.ldr + (n < p.n_store ? n : 0));
+        }
       }
     }
   };
@@ -318,8 +326,23 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
           if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
           v[j] = real ? v[j] : 0.f;
         }
-        if (kMask || res) s.r[ni].get(rr);
-        if (aux && on) store4<T>(aux + m * p.ldz + n, v);      // ungated / pre-residual value
+        if (kMask && p.mask_bits) {
+          const unsigned nib = s.mw[ni];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rr[j] = (nib >> j) & 1u ? 1.f : 0.f;
+        } else if (kMask || res) {
+          s.r[ni].get(rr);
+        }
+        if (aux) {
+          if (!kMask && p.mask_bits) {
+            unsigned w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w |= (v[j] > 0.f ? 1u : 0u) << j;
+            if (on) reinterpret_cast<unsigned char *>(p.aux)[(m * p.ldz + n) >> 2] = (unsigned char)w;
+          } else if (on) {
+            store4<T>(aux + m * p.ldz + n, v);      // ungated / pre-residual value
+          }
+        }
         if constexpr (kMask) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = rr[j] > 0.f ? v[j] : 0.f;
@@ -386,7 +409,8 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(4,
   // The first workgroup also clears the rows that frame the output buffer (leading zero row, slack rows), so the
   // host never issues fill kernels for them.
   if (blockIdx.x == 0) {
-    T *o = static_cast<T *>(p.out), *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD) ? static_cast<T *>(p.aux) : nullptr;
+    T *o = static_cast<T *>(p.out);
+    T *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD && !(EPI == EPI_RELU && p.mask_bits)) ? static_cast<T *>(p.aux) : nullptr;
     for (int64_t i = threadIdx.x; i < p.zero_head; i += NT) {
       o[-1 - i] = Elem<T>::from_f(0.f);
       if (x) x[-1 - i] = Elem<T>::from_f(0.f);
@@ -630,6 +654,9 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
   p.A = A; p.W = W; p.bias = bias; p.res = res; p.out = out; p.aux = aux; p.aux2 = aux2;
   p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr; p.ldz = d->ldz; p.ldy = d->ldy;
   p.gate_only = d->gate_only;
+  p.mask_bits = d->mask_bits;
+  CUM_REQUIRE(!d->mask_bits || (d->epilogue == EPI_RELU && aux) || d->epilogue == EPI_MASK,
+              "gemm: mask_bits applies to RELU (aux = sign array) and MASK (res = sign array)");
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;
   p.zero_head = d->zero_head; p.zero_tail = d->zero_tail;
   if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);

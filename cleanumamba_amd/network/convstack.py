@@ -16,6 +16,7 @@ transposed conv single GEMMs over the flat buffer:
   convT k4 s2: A row m = 2*Cp contiguous elements at element offset m * Cp  (rows m-1, m)
 """
 import ctypes
+import os
 
 import torch
 
@@ -63,7 +64,7 @@ def bk_of(dtype):
 
 # ------------------------------------------------------------------ GEMM launcher
 def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_store, res=None, r_off=0, ldr=0,
-         aux=None, x_off=0, ldz=0, geo=None, aux2=None, y_off=0, ldy=0, gate_only=False):
+         aux=None, x_off=0, ldz=0, geo=None, aux2=None, y_off=0, ldy=0, gate_only=False, mask_bits=False):
     """A, out, res, aux, aux2: flat tensors; *_off element offsets of row 0; Wp [N, K] packed weights."""
     hip.require_gpu(A, Wp, out, res, aux, aux2, any_dtype=True)
     dt = A.dtype
@@ -76,9 +77,11 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
     d.lda, d.ldw, d.ldc, d.ldr, d.ldz = lda, Wp.stride(0), ldc, ldr if res is not None else 4, ldz if aux is not None else 4
     d.pitch, d.valid, d.n_store = pitch, valid, n_store
     d.gate_only, d.ldy = int(gate_only), ldy if aux2 is not None else 4
+    d.mask_bits = int(mask_bits)
     if geo is not None:      # out (and an activation-type aux) is a row buffer of this geometry: frame it with zeros
         d.zero_head, d.zero_tail = geo.head, geo.tail
-    P = lambda t, off: None if t is None else ctypes.c_void_p(t.data_ptr() + off * esz)
+    # offsets are in elements of the GEMM dtype; bit arrays (mask_bits) are passed as views that start at the right word
+    P = lambda t, off: None if t is None else ctypes.c_void_p(t.data_ptr() + off * (esz if t.dtype == dt else 0))
     with torch.cuda.device(A.device):
         hip.check(hip.lib().cum_gemm_nt(ctypes.byref(d), P(A, a_off), P(Wp, 0), hip.ptr(bias), P(res, r_off),
                                         P(out, o_off), P(aux, x_off), P(aux2, y_off), hip.stream_ptr()))
@@ -548,6 +551,9 @@ def supported(model):
 # (csrc/gemm.hip EPI_MASK / EPI_GLU_BWD): per layer the backward is then 2 data-gradient GEMMs + 2 weight-gradient
 # GEMMs and nothing else.  Forward kernels are the same as above.  Layers whose channel count is not a multiple
 # of 16 after padding (pruned checkpoints) keep the unfused elementwise kernels.
+_SIGN_MASK = os.environ.get("CUM_SIGN_MASK", "1") != "0"
+
+
 def _glu_fwd(xbuf, w, b, gi, go, save_z):
     """1x1 conv + GLU.  Saved for the backward: only the gate pre-activation b ([go.M, G*16], output-column order);
     together with the output itself (kept anyway: it is the next layer's input) it determines the GLU backward,
@@ -593,7 +599,13 @@ def _convt_fwd(xbuf, w, b, skip, gi, go, relu):
     bp = take(b, ("convt_vec", Cout, go.Cp, Np), bias_layout, torch.float32)
     ybuf = go.new(dt, dev)
     keep = relu and skip is not None            # the ReLU mask is not recoverable from y + skip
-    act = go.new(dt, dev) if keep else None
+    if keep and _SIGN_MASK:
+        # only the sign of the activation is kept (row buffer geometry, 4 channels per byte): 1/8 of a bf16 copy
+        act = torch.empty(go.R * go.Cp // 4, dtype=torch.uint8, device=dev)
+        gemm(xbuf, 0, gi.Cp, wp, bp, ybuf, go.Cp, N, gi.M, gi.P, gi.T + 1, hip.EPI_RELU, N,
+             res=skip, r_off=go.Cp, ldr=N, aux=act[go.Cp // 4:], x_off=0, ldz=N, geo=go, mask_bits=True)
+        return ybuf, act
+    act = go.new(dt, dev) if keep else None       # CUM_SIGN_MASK=0: a full copy of the activation (A/B timing)
     gemm(xbuf, 0, gi.Cp, wp, bp, ybuf, go.Cp, N, gi.M, gi.P, gi.T + 1, hip.EPI_RELU if relu else hip.EPI_BIAS, N,
          res=skip, r_off=go.Cp, ldr=N, aux=act, x_off=go.Cp, ldz=N, geo=go)
     return ybuf, (act if keep else (ybuf if relu else None))
@@ -780,8 +792,10 @@ class DecoderStack(torch.autograd.Function):
             du = gi.new(dt, dev)
             if j > 0 and acts[j - 1] is not None:
                 dpre = gi.new(dt, dev)
+                bits = acts[j - 1].dtype == torch.uint8          # sign array written by the forward
                 gemm(dz, 0, G32, w1t, None, dpre, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_MASK, gi.Cp,
-                     res=acts[j - 1], r_off=gi.Cp, ldr=gi.Cp, aux=du, x_off=gi.Cp, ldz=gi.Cp, geo=gi)
+                     res=acts[j - 1][gi.Cp // 4:] if bits else acts[j - 1], r_off=0 if bits else gi.Cp, ldr=gi.Cp,
+                     aux=du, x_off=gi.Cp, ldz=gi.Cp, geo=gi, mask_bits=bits)
             else:
                 gemm(dz, 0, G32, w1t, None, du, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp, geo=gi)
                 dpre = du

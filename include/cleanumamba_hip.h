@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 3
+#define CUM_ABI_VERSION 4
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -184,6 +184,9 @@ typedef struct {
                              /* and aux2 the GLU output y = a*sig(b) saved by the forward ([M][ldy]):            */
                              /* da = d*sig(b), db = d*y*(1 - sig(b)) -- a itself is never needed                 */
   int64_t ldy;
+  int32_t mask_bits;         /* RELU (1): aux receives only the SIGN (activation > 0) of each element, four       */
+                             /* consecutive channels per byte (low nibble; byte index (m*ldz + n) / 4).  MASK (3): */
+                             /* res is such an array (byte index (m*ldr + n) / 4).  1/8 of the bytes of a bf16 mask */
 } cum_gemm_desc;
 
 int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias,

@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"],
                     help="autocast dtype of the GEMM/conv stack (reference trains under fp16 autocast); "

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops import layernorm as _ln
 from ..ops.selective_scan_interface import selective_scan_fn, selective_state_update
 
 # Module-level names that callers monkey-patch (src/examples/using_pruning_groups.py:26-27
@@ -212,10 +213,14 @@ class Block(nn.Module):
         self.norm = norm_cls(dim)
 
     def forward(self, hidden_states, residual=None, inference_params=None):
-        residual = (hidden_states + residual) if residual is not None else hidden_states
-        hidden_states = self.norm(residual.to(dtype=self.norm.weight.dtype))
-        if self.residual_in_fp32:
-            residual = residual.to(torch.float32)
+        if self.residual_in_fp32 and _ln.supported(hidden_states, self.norm):
+            # add + LayerNorm in one kernel each way (csrc/layernorm.hip); same arithmetic as the three lines below
+            hidden_states, residual = _ln.add_layer_norm(hidden_states, residual, self.norm)
+        else:
+            residual = (hidden_states + residual) if residual is not None else hidden_states
+            hidden_states = self.norm(residual.to(dtype=self.norm.weight.dtype))
+            if self.residual_in_fp32:
+                residual = residual.to(torch.float32)
         hidden_states = self.mixer(hidden_states, inference_params=inference_params)
         return hidden_states, residual
 

@@ -29,6 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..mamba_ssm.models.mixer_seq_simple import _init_weights, create_block
+from ..mamba_ssm.ops import layernorm as _ln
 from ..mamba_ssm.utils.generation import InferenceParams
 from ..util.util import weight_scaling_init
 from . import convstack as cs
@@ -165,8 +166,11 @@ class CleanUMamba(nn.Module):
         residual = None
         for layer in self.tsfm_Mamba_layers:
             hidden_states, residual = layer(hidden_states, residual, inference_params=inference_params)
-        residual = (hidden_states + residual) if residual is not None else hidden_states
-        hidden_states = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
+        if _ln.supported(hidden_states, self.norm_f):
+            hidden_states, _ = _ln.add_layer_norm(hidden_states, residual, self.norm_f)
+        else:
+            residual = (hidden_states + residual) if residual is not None else hidden_states
+            hidden_states = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
         tsfm_out = hidden_states.permute(0, 2, 1)
         return self.tsfm_conv2(tsfm_out), tsfm_out
 
@@ -250,8 +254,11 @@ class CleanUMamba(nn.Module):
         residual = None
         for layer in self.tsfm_Mamba_layers:
             hidden_states, residual = layer(hidden_states, residual, inference_params=None)
-        residual = hidden_states + residual
-        hidden_states = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
+        if _ln.supported(hidden_states, self.norm_f):
+            hidden_states, _ = _ln.add_layer_norm(hidden_states, residual, self.norm_f)
+        else:
+            residual = hidden_states + residual
+            hidden_states = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
         tsfm_out = hidden_states.permute(0, 2, 1)
         tbuf = cs.to_rows(tsfm_out, g_t, dt)
         # tsfm_conv2 with the deepest skip added in its epilogue

@@ -261,6 +261,23 @@ int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n
 int cum_rfft(int32_t n, int64_t batch, float *in, float *out, void *stream);
 int cum_irfft(int32_t n, int64_t batch, float *in, float *out, void *stream);
 
+/* ---- residual add + LayerNorm of the Mamba blocks (mamba-ssm Block.forward with fused_add_norm=False as the reference
+ * runs it, src/network/CleanUMamba.py:156-189, 288-294, and the final add + norm_f, :292-294):
+ *   residual_out = x + residual (fp32);   y = (residual_out - mean) * rstd * weight + bias
+ * x: (batch, len, dim) of x_dtype with element strides (x_sb, x_sl, 1); residual: contiguous fp32 or NULL;
+ * y: contiguous, y_dtype; mean, rstd: fp32 [batch*len] (saved for the backward).  dim multiple of 8, <= 2048.
+ * Backward: dy (y_dtype) and dres_out (fp32 or NULL, the gradient arriving at residual_out) ->
+ *   dx = d(x) = d(residual) written as fp32 (dx32, may be NULL) and/or in h_dtype (dxh, may be NULL);
+ *   dweight, dbias (dbias may be NULL): fully overwritten.  workspace: cum_add_layernorm_bwd_workspace_elems(dim) fp32. */
+int cum_add_layernorm_fwd(int32_t x_dtype, int32_t y_dtype, int64_t batch, int32_t len, int32_t dim, const void *x,
+                          int64_t x_sb, int64_t x_sl, const float *residual, const float *weight, const float *bias,
+                          float eps, float *residual_out, void *y, float *mean, float *rstd, void *stream);
+int64_t cum_add_layernorm_bwd_workspace_elems(int32_t dim);
+int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t rows, int32_t dim, const void *dy,
+                          const float *dres_out, const float *residual_out, const float *mean, const float *rstd,
+                          const float *weight, float *dx32, void *dxh, float *dweight, float *dbias, float *workspace,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -206,3 +206,37 @@ def test_scan_and_dwconv_bf16_io_vs_oracle(cuda, shape):
     assert y.dtype == torch.bfloat16 and xg.grad.dtype == torch.bfloat16 and wg.grad.dtype == torch.float32
     for name, a, b in (("y", y, yr), ("dx", xg.grad, xr.grad), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad)):
         assert rel_l2(a.float(), b) < 4e-3, name
+
+
+@pytest.mark.parametrize("dim,dt", [(512, torch.float32), (512, torch.bfloat16), (72, torch.float32), (2048, torch.bfloat16)])
+def test_add_layernorm_vs_torch(cuda, dim, dt):
+    """Residual add + LayerNorm (csrc/layernorm.hip) against the separate torch ops the reference executes
+    (Block.forward, fused_add_norm=False), evaluated in float64: forward 1e-6 (f32 output) / bf16 rounding,
+    gradients 1e-5 (f32) / 5e-3 (bf16 hidden gradient)."""
+    from cleanumamba_amd.mamba_ssm.ops.layernorm import AddLayerNormFn
+    g = torch.Generator().manual_seed(dim)
+    bsz, L = 3, 37
+    wide = torch.randn(bsz, L + 2, dim + 8, generator=g)          # strided (batch, time) view like a row buffer
+    h0 = wide[:, :L, :dim].to(dt)
+    r0, w0, b0 = torch.randn(bsz, L, dim, generator=g), 1 + 0.1 * torch.randn(dim, generator=g), 0.1 * torch.randn(dim, generator=g)
+    gy, gr = torch.randn(bsz, L, dim, generator=g).to(dt).float(), torch.randn(bsz, L, dim, generator=g)
+
+    base = wide.to(dt).to(cuda).requires_grad_(True)
+    h = base[:, :L, :dim]
+    r, w, b = (t.to(cuda).requires_grad_(True) for t in (r0, w0, b0))
+    y, res = AddLayerNormFn.apply(h, r, w, b, 1e-5, dt)
+    assert y.dtype == dt and res.dtype == torch.float32
+    ((y.float() * gy.to(cuda)).sum() + (res * gr.to(cuda)).sum()).backward()
+
+    hd = h0.double().requires_grad_(True)
+    rd, wd, bd = (t.double().requires_grad_(True) for t in (r0, w0, b0))
+    res_d = hd + rd
+    y_d = torch.nn.functional.layer_norm(res_d, (dim,), wd, bd, 1e-5)
+    ((y_d * gy.double()).sum() + (res_d * gr.double()).sum()).backward()
+    lo = dt == torch.bfloat16
+    assert rel_l2(res, res_d) < 1e-6
+    assert rel_l2(y.float(), y_d) < (4e-3 if lo else 1e-6)
+    assert rel_l2(base.grad[:, :L, :dim].float(), hd.grad) < (5e-3 if lo else 1e-5)
+    assert float(base.grad[:, L:].abs().max()) == 0.0
+    for a, bb in ((r.grad, rd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
+        assert rel_l2(a, bb) < 1e-5

@@ -17,4 +17,6 @@ for n, c, s in rows:
     e = m.group(1) if m else "0/1"
     by[e] = by.get(e, 0) + s / 1e6 / 13
 sb = [s for n, c, s in rows if "scan_bwd_kernel" in n][0] / 1e6 / 13
-print(sys.argv[2], "NT %.2f" % sum(by.values()), {k: round(v, 2) for k, v in sorted(by.items())}, "scan_bwd %.2f" % sb)
+tot = sum(s for n, c, s in rows) / 1e6 / 13
+print(sys.argv[2], "total %.2f" % tot, "NT %.2f" % sum(by.values()), {k: round(v, 2) for k, v in sorted(by.items())},
+      "scan_bwd %.2f" % sb, "launches/step %.0f" % (sum(c for n, c, s in rows) / 13))

@@ -200,22 +200,32 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const LnBwdParam
   }
 }
 
+// 64 outputs per workgroup; its 4 waves each add every 4th slab (fixed order), partial sums meet in LDS
 __global__ __launch_bounds__(256) void add_layernorm_bwd_finalize_kernel(const float *slab, int nslab, int dim, float *dw,
                                                                          float *db) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 2 * dim) return;
-  const int k = e / dim, c = e % dim;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const bool live = e < 2 * dim;
+  const int k = live ? e / dim : 0, c = live ? e % dim : 0;
   float a0 = 0.f, a1 = 0.f;
-  int s = 0;
-  for (; s + 1 < nslab; s += 2) {
-    a0 += slab[((int64_t)s * 2 + k) * dim + c];
-    a1 += slab[((int64_t)(s + 1) * 2 + k) * dim + c];
+  if (live) {
+    int s = sl;
+    for (; s + 4 < nslab; s += 8) {
+      a0 += slab[((int64_t)s * 2 + k) * dim + c];
+      a1 += slab[((int64_t)(s + 4) * 2 + k) * dim + c];
+    }
+    if (s < nslab) a0 += slab[((int64_t)s * 2 + k) * dim + c];
   }
-  if (s < nslab) a0 += slab[((int64_t)s * 2 + k) * dim + c];
-  if (k == 0)
-    dw[c] = a0 + a1;
-  else if (db)
-    db[c] = a0 + a1;
+  red[sl][lane] = a0 + a1;
+  __syncthreads();
+  if (sl == 0 && live) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (k == 0)
+      dw[c] = v;
+    else if (db)
+      db[c] = v;
+  }
 }
 
 constexpr int kLnBwdGroups = 256;
@@ -289,7 +299,7 @@ extern "C" int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t r
   else
     hipLaunchKernelGGL((add_layernorm_bwd_kernel<float, float>), grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(add_layernorm_bwd_finalize_kernel, dim3((2 * dim + 255) / 256), dim3(256), 0, st, workspace, groups,
+  hipLaunchKernelGGL(add_layernorm_bwd_finalize_kernel, dim3((2 * dim + 63) / 64), dim3(256), 0, st, workspace, groups,
                      dim, dweight, dbias);
   CUM_CHECK_LAUNCH();
   return CUM_OK;

@@ -65,6 +65,19 @@ class _ProjFn(torch.autograd.Function):
         return dx, dw, None
 
 
+class _SplitXZ(torch.autograd.Function):
+    """xz (B, L, 2D) -> x, z as (B, D, L) views.  Plain slicing leaves autograd two zero-filled (B, L, 2D) buffers, two
+    slice copies and an add per block; the two gradients are simply concatenated here."""
+
+    @staticmethod
+    def forward(ctx, xz, d):
+        return xz[..., :d].transpose(1, 2), xz[..., d:].transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, dx, dz):
+        return torch.cat([dx.transpose(1, 2), dz.transpose(1, 2)], dim=-1), None
+
+
 _PROJ_TN = os.environ.get("CUM_PROJ_TN", "1") != "0"      # "0": plain F.linear everywhere (A/B timing)
 
 
@@ -140,8 +153,7 @@ class Mamba(nn.Module):
         d_conv = self.conv1d.weight.shape[-1]
 
         xz = _proj(hidden_states, self.in_proj.weight, self.in_proj.bias)         # (B, L, 2 d_inner)
-        x = xz[..., :d_inner].transpose(1, 2)                                     # (B, d_inner, L) views,
-        z = xz[..., d_inner:].transpose(1, 2)                                     # channel stride 1
+        x, z = _SplitXZ.apply(xz, d_inner)                                         # (B, d_inner, L) views, channel stride 1
         A = -torch.exp(self.A_log.float())
         if conv_state is not None:
             conv_state.copy_(F.pad(x, (d_conv - x.shape[-1], 0)))

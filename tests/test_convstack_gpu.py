@@ -102,3 +102,71 @@ def test_pointwise_with_residual(cuda):
     xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
     (torch.nn.functional.conv1d(xr, wr, b.double()) + s.double()).square().sum().backward()
     assert rel_l2(xd.grad, xr.grad) < 1e-4 and rel_l2(wd.grad, wr.grad) < 1e-4
+
+
+def _ref_gemm(A, W, bias):
+    return A.double() @ W.double().t() + (0 if bias is None else bias.double())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("M,N,K", [(300, 64, 64), (1000, 192, 512), (60001, 256, 256), (140003, 192, 256)])
+def test_gemm_backward_epilogues_against_torch(cuda, M, N, K, dtype, tol):
+    """The backward epilogues of cum_gemm_nt through the C ABI, ragged M (edge tiles); the four shapes make the
+    launcher pick the 128x128, 128x128, 256x256 and 256x128 tiles:
+    3 = ReLU gate from a full activation and from sign nibbles (+ ungated second output);
+    4 = GLU backward from the packed (a | b) pre-activation and from the gate-only form (+ residual)."""
+    from cleanumamba_amd import hip
+    from cleanumamba_amd.network import convstack as cs
+    g = torch.Generator().manual_seed(M + N + K)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    A = rn(M, K).to(cuda).to(dtype)
+    W = (rn(N, K) / K ** 0.5).to(cuda).to(dtype)
+    acc = _ref_gemm(A.cpu().float(), W.cpu().float(), None)            # what the MFMA accumulates (inputs already rounded)
+
+    # ---- epilogue 3
+    Y = rn(M, N).to(cuda).to(dtype)                                     # activation whose sign gates
+    out = torch.full((M, N), float("nan"), device=cuda, dtype=dtype)
+    ung = torch.full((M, N), float("nan"), device=cuda, dtype=dtype)
+    cs.gemm(A, 0, K, W, None, out, 0, N, M, 1 << 30, 1 << 30, hip.EPI_MASK, N, res=Y, r_off=0, ldr=N, aux=ung, x_off=0, ldz=N)
+    want = torch.where(Y.cpu().double() > 0, acc, torch.zeros_like(acc))
+    assert rel_l2(out.float(), want) < tol and rel_l2(ung.float(), acc) < tol
+    bits = torch.zeros(M * N // 4, dtype=torch.uint8, device=cuda)
+    yq = (Y.float().cpu() > 0).view(M, N // 4, 4).to(torch.uint8)
+    bits.copy_((yq[..., 0] | yq[..., 1] << 1 | yq[..., 2] << 2 | yq[..., 3] << 3).reshape(-1).to(cuda))
+    out2 = torch.full((M, N), float("nan"), device=cuda, dtype=dtype)
+    cs.gemm(A, 0, K, W, None, out2, 0, N, M, 1 << 30, 1 << 30, hip.EPI_MASK, N, res=bits, r_off=0, ldr=N, mask_bits=True)
+    assert torch.equal(out2, out)
+
+    # ---- producer of the sign nibbles: epilogue 1 with mask_bits
+    bias = rn(N).to(cuda)
+    relu_out = torch.empty(M, N, device=cuda, dtype=dtype)
+    nib = torch.full((M * N // 4,), 255, dtype=torch.uint8, device=cuda)
+    cs.gemm(A, 0, K, W, bias, relu_out, 0, N, M, 1 << 30, 1 << 30, hip.EPI_RELU, N, aux=nib, x_off=0, ldz=N, mask_bits=True)
+    rq = (relu_out.float().cpu() > 0).view(M, N // 4, 4).to(torch.uint8)
+    assert torch.equal(nib.cpu(), (rq[..., 0] | rq[..., 1] << 1 | rq[..., 2] << 2 | rq[..., 3] << 3).reshape(-1))
+
+    # ---- epilogue 4: d = acc + ext is the gradient of y = a * sig(b)
+    ext = rn(M, N).to(cuda).to(dtype)
+    a, b = rn(M, N), rn(M, N)
+    Z = torch.empty(M, 2 * N)
+    Zv = Z.view(M, N // 16, 2, 16)
+    Zv[:, :, 0], Zv[:, :, 1] = a.view(M, N // 16, 16), b.view(M, N // 16, 16)
+    Z = Z.to(cuda).to(dtype)
+    ar, br = Z.float().cpu().view(M, N // 16, 2, 16)[:, :, 0].reshape(M, N).double(), Z.float().cpu().view(M, N // 16, 2, 16)[:, :, 1].reshape(M, N).double()
+    d = acc + ext.float().cpu().double()
+    sg = torch.sigmoid(br)
+    want_dz = torch.empty(M, N // 16, 2, 16, dtype=torch.float64)
+    want_dz[:, :, 0], want_dz[:, :, 1] = (d * sg).view(M, N // 16, 16), (d * ar * sg * (1 - sg)).view(M, N // 16, 16)
+    dz = torch.full((M, 2 * N), float("nan"), device=cuda, dtype=dtype)
+    cs.gemm(A, 0, K, W, None, dz, 0, 2 * N, M, 1 << 30, 1 << 30, hip.EPI_GLU_BWD, N, res=ext, r_off=0, ldr=N, aux=Z, x_off=0, ldz=2 * N)
+    assert rel_l2(dz.float(), want_dz.view(M, 2 * N)) < tol
+    # gate-only form: b [M][N] and the saved output y
+    bg = br.to(dtype).to(cuda)
+    y = (ar * sg).to(dtype).to(cuda)
+    sgq = torch.sigmoid(bg.float().cpu().double())
+    want2 = torch.empty(M, N // 16, 2, 16, dtype=torch.float64)
+    want2[:, :, 0], want2[:, :, 1] = (d * sgq).view(M, N // 16, 16), (d * y.float().cpu().double() * (1 - sgq)).view(M, N // 16, 16)
+    dz2 = torch.full((M, 2 * N), float("nan"), device=cuda, dtype=dtype)
+    cs.gemm(A, 0, K, W, None, dz2, 0, 2 * N, M, 1 << 30, 1 << 30, hip.EPI_GLU_BWD, N, res=ext, r_off=0, ldr=N, aux=bg, x_off=0, ldz=N,
+            aux2=y, y_off=0, ldy=N, gate_only=True)
+    assert rel_l2(dz2.float(), want2.view(M, 2 * N)) < tol

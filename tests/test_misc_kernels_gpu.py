@@ -1,0 +1,39 @@
+"""Small C-ABI entry points against their torch equivalents (GPU): operand gather, hipFFT wrappers."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("src_dt,dst_dt", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32),
+                                           (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("n", [1, 7, 8, 1000, 100003])
+def test_gather_with_zero_padding(cuda, src_dt, dst_dt, n):
+    from cleanumamba_amd.network import convstack as cs
+    g = torch.Generator().manual_seed(n)
+    src = torch.randn(5000, generator=g).to(src_dt)
+    idx = torch.randint(-1, 5000, (n,), generator=g, dtype=torch.int32)
+    out = cs.gather(src.to(cuda), idx.to(cuda), dst_dt)
+    want = torch.where(idx >= 0, src[idx.clamp_min(0).long()].float(), torch.zeros(n)).to(dst_dt)
+    assert out.dtype == dst_dt and torch.equal(out.cpu(), want)      # pure data movement + one rounding: bit-exact
+
+
+@pytest.mark.parametrize("n_fft", [512, 1024, 2048])
+def test_rfft_irfft_match_torch_fft(cuda, n_fft):
+    """cum_rfft / cum_irfft (hipFFT, unnormalised, inputs may be overwritten) vs torch.fft on a copy."""
+    from cleanumamba_amd import hip
+    batch = 37
+    x = torch.randn(batch, n_fft, generator=torch.Generator().manual_seed(n_fft)).to(cuda)
+    want = torch.fft.rfft(x.clone(), dim=-1)
+    spec = torch.empty(batch, n_fft // 2 + 1, dtype=torch.complex64, device=cuda)
+    scratch = x.clone()
+    hip.check(hip.lib().cum_rfft(n_fft, batch, hip.ptr(scratch), hip.ptr(torch.view_as_real(spec)), hip.stream_ptr()))
+    assert rel_l2(torch.view_as_real(spec), torch.view_as_real(want)) < 1e-6
+    back_want = torch.fft.irfft(want.clone(), n=n_fft, dim=-1, norm="forward")
+    back = torch.empty(batch, n_fft, device=cuda)
+    z = want.clone()
+    hip.check(hip.lib().cum_irfft(n_fft, batch, hip.ptr(torch.view_as_real(z)), hip.ptr(back), hip.stream_ptr()))
+    assert rel_l2(back, back_want) < 1e-6
+    assert rel_l2(back / n_fft, x) < 1e-5                            # round trip

@@ -278,6 +278,16 @@ int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t rows, int32_
                           const float *weight, float *dx32, void *dxh, float *dweight, float *dbias, float *workspace,
                           void *stream);
 
+/* ---- streaming decoder glue (CleanUMamba._denoise_frame, src/network/CleanUMamba.py:476-488): overlap-add of a frame's
+ * transposed-conv output with the previous frame's tail, activation, skip add and tail update for S streams in
+ * lock-step, channels-last rows of Cp (C real channels):
+ *   out[s][t]  = act(y[s][t] + (t < 2 ? tail[s][t] : 0)) + skip[s][t]      t < L2
+ *   tail[s][t] = y[s][L2 + t] - bias                                          t < 2
+ * y, skip, out: stream s starts y_pitch / skip_pitch / out_pitch rows after stream s-1; tail: [S][2][Cp]. */
+int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t Cp, int32_t C, const void *y,
+                           int64_t y_pitch, void *tail, const float *bias, const void *skip, int64_t skip_pitch,
+                           void *out, int64_t out_pitch, int32_t relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

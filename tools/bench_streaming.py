@@ -19,6 +19,8 @@ with np.load("tests/golden/ckpt_pruned500k.npz") as f:
 net = CleanUMamba(**cfg)
 net.load_pruned_state_dict(sd)
 net = net.to(dev).eval()
+if len(sys.argv) > 3:
+    net.use_fused_stream = sys.argv[3] != "cached"      # third argument "cached": torch-module hop with encoder caches
 n = int(SECONDS * 16000)
 x = 0.05 * torch.randn(S, n, device=dev)
 hop = net.total_stride

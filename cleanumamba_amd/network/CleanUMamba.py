@@ -290,11 +290,18 @@ class CleanUMamba(nn.Module):
         conv_params = [p for m in (self.encoder, self.decoder, self.tsfm_conv1, self.tsfm_conv2) for p in m.parameters()]
         if plan is None or [p.data_ptr() for p in plan.params] != [p.data_ptr() for p in conv_params]:
             plan = plans[dt] = cs.PackPlan(conv_params)
+        # tensor version counters see optimizer steps, load_state_dict and every other in-place update, but not
+        # writes through ``param.data``: call invalidate_packed_weights() after those.  Training always re-packs.
         version = (sum(p._version for p in conv_params), len(plan.reqs))
-        if getattr(plan, "packed_version", None) != version or not plan.current:
+        if torch.is_grad_enabled() or getattr(plan, "packed_version", None) != version or not plan.current:
             plan.refresh()
             plan.packed_version = (version[0], len(plan.reqs))
         cs.set_active_plan(plan)
+
+    def invalidate_packed_weights(self):
+        """Drop the cached GEMM-layout copies of the conv weights (rebuilt on the next forward)."""
+        self.__dict__.pop("_pack_plans", None)
+        self.__dict__.pop("_hop_graph", None)
 
     # ----------------------------------------------------------------- streaming
     def reset_time_per_frame(self):

@@ -46,9 +46,62 @@ __global__ __launch_bounds__(256) void stream_tail_kernel(const T *__restrict__ 
   }
 }
 
+// Per-layer activation window of the streaming encoder: drop the n oldest rows of every stream, append the n newest
+// rows of `fresh` (the layer recomputed over the whole window).  Older rows keep the values they got in the hop that
+// first produced them, exactly like the reference's per-layer caches (src/network/CleanUMamba.py:425-447).
+// Out of place into `tmp`, then copied back by the second kernel (stream order makes the shift race-free).
+template <typename T>
+__global__ __launch_bounds__(256) void stream_window_shift_kernel(const T *__restrict__ window, const T *__restrict__ fresh,
+                                                                  T *__restrict__ tmp, int64_t pitch, int streams, int rows,
+                                                                  int n_new, int Cp) {
+  const int64_t total = (int64_t)streams * rows * Cp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = i % Cp;
+    const int64_t r = i / Cp;
+    const int t = r % rows;
+    const int64_t s = r / rows;
+    tmp[i] = t < rows - n_new ? window[(s * pitch + t + n_new) * Cp + c] : fresh[(s * pitch + t) * Cp + c];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stream_window_store_kernel(const T *__restrict__ tmp, T *__restrict__ window,
+                                                                  int64_t pitch, int streams, int rows, int Cp) {
+  const int64_t total = (int64_t)streams * rows * Cp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = i % Cp;
+    const int64_t r = i / Cp;
+    window[((r / rows) * pitch + r % rows) * Cp + c] = tmp[i];
+  }
+}
+
 }  // namespace cum
 
 using namespace cum;
+
+extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t rows, int32_t n_new, int32_t Cp,
+                                        void *window, const void *fresh, int64_t pitch, void *tmp, void *stream) {
+  CUM_REQUIRE(dtype == CUM_F32 || dtype == CUM_BF16, "stream_window_update: dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(streams >= 0 && rows > 0 && n_new > 0 && n_new <= rows && Cp > 0 && pitch >= rows,
+              "stream_window_update: bad shape");
+  if (streams == 0) return CUM_OK;
+  CUM_REQUIRE(window && fresh && tmp, "stream_window_update: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)streams * rows * Cp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == CUM_BF16) {
+    hipLaunchKernelGGL(stream_window_shift_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)window,
+                       (const __bf16 *)fresh, (__bf16 *)tmp, pitch, streams, rows, n_new, Cp);
+    hipLaunchKernelGGL(stream_window_store_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)tmp,
+                       (__bf16 *)window, pitch, streams, rows, Cp);
+  } else {
+    hipLaunchKernelGGL(stream_window_shift_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)window,
+                       (const float *)fresh, (float *)tmp, pitch, streams, rows, n_new, Cp);
+    hipLaunchKernelGGL(stream_window_store_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)tmp,
+                       (float *)window, pitch, streams, rows, Cp);
+  }
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
 
 extern "C" int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t Cp, int32_t C, const void *y,
                                       int64_t y_pitch, void *tail, const float *bias, const void *skip,

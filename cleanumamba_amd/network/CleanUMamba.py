@@ -128,6 +128,9 @@ class CleanUMamba(nn.Module):
         # True: streaming hops run on the fused GEMM kernels (_denoise_frame_fused); False: torch modules with
         # per-layer encoder caches (_denoise_frame, the reference's structure)
         self.use_fused_stream = True
+        # True: the fused streaming hop stores activations and runs its GEMMs in bf16 (f32 accumulate; the Mamba
+        # steps and all stream state stay f32).  Off by default: the hop then matches ``forward`` to 1e-4.
+        self.stream_bf16 = False
 
         # streaming state
         self.total_time = 0
@@ -440,33 +443,45 @@ class CleanUMamba(nn.Module):
         return hg["static_out"].clone()
 
     def _denoise_frame_fused(self, frame, inplace=True):
-        """One hop on the fused GEMM kernels.  The encoder runs on the S frames as S independent clips of
-        valid_length(1) samples (no per-layer caches: the window is recomputed, 16 GEMM launches in all); the decoder
-        layer is 1x1+GLU GEMM, transposed-conv GEMM and one overlap-add kernel (cum_stream_overlap_add) that also
-        applies ReLU, adds the skip and keeps the tail for the next hop.  Same arithmetic as _denoise_frame; the one
-        visible difference: with normalize_input=True the whole window is scaled by the running std of the CURRENT hop,
-        whereas the cached path keeps each cached activation scaled by the std of the hop that produced it (the
-        running std moves by O(1/frames), so the two agree ever more closely; use_fused_stream=False selects the
-        cached path)."""
-        S, E, dt, dev = frame.shape[0], self.encoder_n_layers, torch.float32, frame.device
+        """One hop on the fused GEMM kernels, same arithmetic as _denoise_frame.  Every encoder layer is recomputed
+        over the S windows (S independent clips of valid_length(1) samples, two GEMM launches) and only its newest
+        rows are appended to the layer's persistent window (cum_stream_window_update), so older activations keep the
+        input scaling of the hop that produced them, as with the reference's per-layer caches; a decoder layer is
+        1x1+GLU GEMM, transposed-conv GEMM and one overlap-add kernel (cum_stream_overlap_add) that also applies
+        ReLU, adds the skip and keeps the tail for the next hop."""
+        S, E, dev = frame.shape[0], self.encoder_n_layers, frame.device
+        dt = torch.bfloat16 if getattr(self, "stream_bf16", False) else torch.float32
         self._activate_pack_plan(dt)
         geo = cs.Geo(S, frame.shape[1], self.encoder[0][0].weight.shape[1])
         buf = cs.to_rows(frame.unsqueeze(1), geo, dt)
-        enc_geos, enc_params = [], []
-        for enc in self.encoder:
+        state, lib = self.encoder_decoder_state, hip.lib()
+        enc_geos, outs, n_new = [], [], self.total_stride
+        for i, enc in enumerate(self.encoder):
             T1 = (geo.T - self.kernel_size) // self.stride + 1
             g_mid = cs.Geo(S, T1, enc[0].weight.shape[0])
             g_out = cs.Geo(S, T1, enc[2].weight.shape[0] // 2)
+            n_new //= self.stride
+            y1 = cs._conv_relu_fwd(buf, enc[0].weight, enc[0].bias, geo, g_mid)
+            fresh, _ = cs._glu_fwd(y1, enc[2].weight, enc[2].bias, g_mid, g_out, False)
+            # the layer's window keeps older rows as the hop that produced them left them (per-layer caches of the
+            # reference, :425-447): only the n_new newest rows of the recomputed window are taken over
+            window = state.get(f"enc{i}")
+            if window is None:
+                window = state[f"enc{i}"] = fresh
+            else:
+                tmp = torch.empty(S * g_out.T * g_out.Cp, dtype=dt, device=dev)
+                with torch.cuda.device(dev):
+                    hip.check(lib.cum_stream_window_update(hip.dtype_code(dt), S, g_out.T, n_new, g_out.Cp,
+                                                           hip.ptr(window[1:]), hip.ptr(fresh[1:]), g_out.P, hip.ptr(tmp),
+                                                           hip.stream_ptr()))
             enc_geos.append((geo, g_mid, g_out))
-            enc_params += [enc[0].weight, enc[0].bias, enc[2].weight, enc[2].bias]
-            geo = g_out
-        outs = cs.EncoderStack.apply(buf, enc_geos, False, *enc_params)
-        x, _ = self._bottleneck(cs.from_rows(outs[-1], geo), inference_params=self.inference_params)   # (S, C, 1)
+            outs.append(window)
+            buf, geo = window, g_out
+        x, _ = self._bottleneck(cs.from_rows(outs[-1], geo).float(), inference_params=self.inference_params)   # (S, C, 1)
         L = x.shape[-1]
-        x = x + cs.from_rows(outs[-1], geo)[..., :L]
+        x = x + cs.from_rows(outs[-1], geo)[..., :L].float()
         g_in = cs.Geo(S, L, x.shape[1])
         ubuf = cs.to_rows(x, g_in, dt)
-        state, lib = self.encoder_decoder_state, hip.lib()
         for j, dec in enumerate(self.decoder):
             last = j == E - 1
             g_glu = cs.Geo(S, L, dec[0].weight.shape[0] // 2)
@@ -489,7 +504,7 @@ class CleanUMamba(nn.Module):
                     hip.ptr(dec[2].bias.float()), hip.ptr(skip), skip_pitch, hip.ptr(nbuf[1:]), g_next.P,
                     int(not last), hip.stream_ptr()))
             ubuf, g_in, L = nbuf, g_next, 2 * L
-        return cs.from_rows(ubuf, g_in)[:, 0]
+        return cs.from_rows(ubuf, g_in)[:, 0].float()
 
     def _denoise_frame(self, frame, inplace=False):
         """One hop: frame (S, frame_length) -> (S, >= total_stride) samples.  Encoder outputs that overlap

@@ -284,6 +284,11 @@ int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t rows, int32_
  *   out[s][t]  = act(y[s][t] + (t < 2 ? tail[s][t] : 0)) + skip[s][t]      t < L2
  *   tail[s][t] = y[s][L2 + t] - bias                                          t < 2
  * y, skip, out: stream s starts y_pitch / skip_pitch / out_pitch rows after stream s-1; tail: [S][2][Cp]. */
+/* Streaming encoder window of one layer (per-layer caches of _denoise_frame, :425-447): for every stream drop the n_new
+ * oldest of `rows` rows and append rows [rows - n_new, rows) of `fresh`.  window, fresh: stream s starts `pitch` rows
+ * after stream s-1; tmp: streams * rows * Cp elements of scratch. */
+int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t rows, int32_t n_new, int32_t Cp, void *window,
+                             const void *fresh, int64_t pitch, void *tmp, void *stream);
 int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t Cp, int32_t C, const void *y,
                            int64_t y_pitch, void *tail, const float *bias, const void *skip, int64_t skip_pitch,
                            void *out, int64_t out_pitch, int32_t relu, void *stream);

@@ -21,6 +21,7 @@ net.load_pruned_state_dict(sd)
 net = net.to(dev).eval()
 if len(sys.argv) > 3:
     net.use_fused_stream = sys.argv[3] != "cached"      # third argument "cached": torch-module hop with encoder caches
+    net.stream_bf16 = sys.argv[3] == "bf16"              # "bf16": fused hop with bf16 activations / GEMMs
 n = int(SECONDS * 16000)
 x = 0.05 * torch.randn(S, n, device=dev)
 hop = net.total_stride

@@ -20,9 +20,22 @@
 
 namespace cum {
 
-// Sum 8 per-lane values over the 64 lanes.  On return lanes of row q = lane>>4 hold in
-// r[0], r[1] the totals of v[2q], v[2q+1].
-__device__ __forceinline__ void wave_reduce_scatter8(const float (&v)[NS], float (&r)[2]) {
+// Two states of one lane side by side: the arithmetic below is written on pairs so that it maps onto the packed
+// f32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32: two results per lane per issue slot).
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int NP2 = NS / 2;
+__device__ __forceinline__ f2 exp2_2(f2 v) {
+  f2 r;
+  r.x = __builtin_amdgcn_exp2f(v.x);
+  r.y = __builtin_amdgcn_exp2f(v.y);
+  return r;
+}
+
+// Sum 8 per-lane values (4 pairs) over the 64 lanes.  On return lanes of row q = lane>>4 hold in
+// r[0], r[1] the totals of v[2q], v[2q+1].  (Kept on scalars: one asm block per exchange and scalar adds cost
+// fewer register copies than grouped exchanges with packed adds.)
+__device__ __forceinline__ void wave_reduce_scatter8(const f2 (&v2)[NP2], float (&r)[2]) {
+  const float v[NS] = {v2[0].x, v2[0].y, v2[1].x, v2[1].y, v2[2].x, v2[2].y, v2[3].x, v2[3].y};
   float h[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -48,7 +61,8 @@ __device__ __forceinline__ void wave_reduce_scatter8(const float (&v)[NS], float
 // 2: the chunk's B / C tiles staged in LDS by the whole workgroup (one coalesced load per chunk, broadcast
 // ds_read_b128 per step): no SGPR pressure -- the scalar variants keep 256 B/C values per chunk in flight and spend
 // ~20 % of their VALU instructions moving spilled SGPRs through VGPR lanes.
-template <int NW, int BC, typename TIO>
+// FULL: dstate == NW * NS known at compile time (every wave owns NS valid states, slab rows are 8-byte aligned pairs).
+template <int NW, int BC, typename TIO, bool FULL>
 __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   constexpr bool FAST = BC == 1;
   constexpr bool LDSBC = BC == 2;
@@ -71,21 +85,21 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   const int b = blockIdx.y;
   const int g = blockIdx.x;
   const int d = g * 64 + lane;
-  const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
+  const int N = FULL ? NW * NS : p.s.dstate, L = p.s.len, Dm = p.s.dim;
   const bool dok = d < Dm;
   const int dc = dok ? d : Dm - 1;
   const int n0 = w * NS;
-  const int nvalid = (N - n0) < NS ? (N - n0) : NS;
+  const int nvalid = FULL ? NS : ((N - n0) < NS ? (N - n0) : NS);
   const int nchunks = p.nchunks;
 
-  float Ap[NS], dAacc[NS], dxc[NS];
+  f2 Ap[NP2], dAacc[NP2], dxc[NP2];
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int jj = j < nvalid ? j : nvalid - 1;
     const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
-    Ap[j] = (j < nvalid) ? a : 0.f;
-    dAacc[j] = 0.f;
-    dxc[j] = 0.f;
+    Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
+    dAacc[j / 2][j % 2] = 0.f;
+    dxc[j / 2][j % 2] = 0.f;
   }
   const float Dd = p.D ? p.D[dc] : 0.f;
   const float bias = p.bias ? p.bias[dc] : 0.f;
@@ -106,6 +120,10 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   const int o_sl = (int)p.s.o_sl;
   const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
   const int softplus = p.s.delta_softplus;
+
+  // dB / dC slab stores: lanes 0, 16, 32, 48 own states 2q, 2q + 1 of the wave's slice (q = lane >> 4)
+  const unsigned qoff = 2u * (lane >> 4);
+  const bool st0 = (lane & 15) == 0 && (int)qoff < nvalid, st1 = (lane & 15) == 0 && (int)qoff + 1 < nvalid;
 
   float accD = 0.f, accBias = 0.f;
 
@@ -141,15 +159,16 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * TB;
     const int tlast = L - 1 - t0;  // last valid local step of this chunk (>= 0)
+    float *cB = wsB + (int64_t)t0 * N, *cC = wsC + (int64_t)t0 * N;
     // state entering the chunk: needed by both halves, requested now so that its latency hides behind phase A
-    float x0[NS];
+    f2 x0[NP2];
     {
       const float *ck = p.ckpt_in + (((int64_t)b * nchunks + c) * N + n0) * Dm + dc;
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
         const int jj = j < nvalid ? j : nvalid - 1;
         const float v = ck[(int64_t)jj * Dm];
-        x0[j] = (j < nvalid) ? v : 0.f;
+        x0[j / 2][j % 2] = (j < nvalid) ? v : 0.f;
       }
     }
     float eu[K], ez[K], edo[K], edt[K], esg[K];
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     // Operands of one time step: B_t / C_t slices (SGPRs via s_load) and the per-(t, d) values from LDS.  They are
     // fetched one step ahead of their use so that neither the scalar-load nor the LDS latency is exposed.
     struct StepOps {
-      float bv[NS], cv[NS];
+      f2 bv[NP2], cv[NP2];
       float dt, du, dy;
     };
     auto fetch = [&](int tl, StepOps &o) {
@@ -199,60 +218,73 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       if constexpr (LDSBC) {
         const float4 b0 = *reinterpret_cast<const float4 *>(&s_B[tc][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[tc][n0 + 4]);
         const float4 c0 = *reinterpret_cast<const float4 *>(&s_C[tc][n0]), c1 = *reinterpret_cast<const float4 *>(&s_C[tc][n0 + 4]);
-        o.bv[0] = b0.x; o.bv[1] = b0.y; o.bv[2] = b0.z; o.bv[3] = b0.w; o.bv[4] = b1.x; o.bv[5] = b1.y; o.bv[6] = b1.z; o.bv[7] = b1.w;
-        o.cv[0] = c0.x; o.cv[1] = c0.y; o.cv[2] = c0.z; o.cv[3] = c0.w; o.cv[4] = c1.x; o.cv[5] = c1.y; o.cv[6] = c1.z; o.cv[7] = c1.w;
+        o.bv[0] = f2{b0.x, b0.y}; o.bv[1] = f2{b0.z, b0.w}; o.bv[2] = f2{b1.x, b1.y}; o.bv[3] = f2{b1.z, b1.w};
+        o.cv[0] = f2{c0.x, c0.y}; o.cv[1] = f2{c0.z, c0.w}; o.cv[2] = f2{c1.x, c1.y}; o.cv[3] = f2{c1.z, c1.w};
       } else {
-        load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, o.bv);
-        load_bc<FAST>(opaque(Cw + (t0 + tc) * C_sl), C_sn, nvalid, o.cv);
+        float bs[NS], cs[NS];
+        load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, bs);
+        load_bc<FAST>(opaque(Cw + (t0 + tc) * C_sl), C_sn, nvalid, cs);
+#pragma unroll
+        for (int j = 0; j < NP2; ++j) {
+          o.bv[j] = f2{bs[2 * j], bs[2 * j + 1]};
+          o.cv[j] = f2{cs[2 * j], cs[2 * j + 1]};
+        }
       }
       o.dt = s_dt[tl][lane];
       o.du = s_du[tl][lane];
       o.dy = s_dy[tl][lane];
     };
     // one recomputed forward step (state only)
-    auto fwd_step = [&](float (&x)[NS], const StepOps &o) {
+    auto fwd_step = [&](f2 (&x)[NP2], const StepOps &o) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const float a = __builtin_amdgcn_exp2f(o.dt * Ap[j]);
-        x[j] = fmaf(a, x[j], o.du * o.bv[j]);
+      for (int j = 0; j < NP2; ++j) {
+        const f2 a = exp2_2(o.dt * Ap[j]);
+        x[j] = a * x[j] + o.du * o.bv[j];
       }
       __builtin_amdgcn_sched_barrier(0);
     };
     // one reverse step; xp = state before step tl; slot = tl % SUB
-    auto rev_step = [&](const float (&xp)[NS], int tl, int slot, const StepOps &o) {
+    auto rev_step = [&](const f2 (&xp)[NP2], int tl, int slot, const StepOps &o) {
       const float dt = o.dt, du = o.du, dy = o.dy;
-      float p1 = 0.f, p2 = 0.f, yp = 0.f;
-      float dBp[NS], dCp[NS];
+      f2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, yp = {0.f, 0.f};   // even / odd states summed apart, joined below
+      f2 dBp[NP2], dCp[NP2];
 #pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
-        const float xt = fmaf(a, xp[j], du * o.bv[j]);
-        const float dx = fmaf(o.cv[j], dy, dxc[j]);
-        yp = fmaf(o.cv[j], xt, yp);
+      for (int j = 0; j < NP2; ++j) {
+        const f2 a = exp2_2(dt * Ap[j]);
+        const f2 xt = a * xp[j] + du * o.bv[j];
+        const f2 dx = o.cv[j] * dy + dxc[j];
+        yp = o.cv[j] * xt + yp;
         dCp[j] = dy * xt;
         dBp[j] = dx * du;
-        const float gg = dx * xp[j] * a;
-        dAacc[j] = fmaf(gg, dt, dAacc[j]);
-        p1 = fmaf(gg, Ap[j], p1);
-        p2 = fmaf(dx, o.bv[j], p2);
+        const f2 gg = dx * xp[j] * a;
+        dAacc[j] = gg * dt + dAacc[j];
+        p1 = gg * Ap[j] + p1;
+        p2 = dx * o.bv[j] + p2;
         dxc[j] = a * dx;
       }
-      s_p1[w][slot][lane] = p1;
-      s_p2[w][slot][lane] = p2;
-      s_y[w][slot][lane] = yp;
+      s_p1[w][slot][lane] = p1.x + p1.y;
+      s_p2[w][slot][lane] = p2.x + p2.y;
+      s_y[w][slot][lane] = yp.x + yp.y;
       float rB[2], rC[2];
       wave_reduce_scatter8(dBp, rB);
       wave_reduce_scatter8(dCp, rC);
-      if ((lane & 15) == 0 && tl <= tlast) {
-        const int q = lane >> 4;
-        const int64_t row = (int64_t)(t0 + tl) * N;
-        if (2 * q < nvalid) {
-          wsB[row + 2 * q] = rB[0];
-          wsC[row + 2 * q] = rC[0];
-        }
-        if (2 * q + 1 < nvalid) {
-          wsB[row + 2 * q + 1] = rB[1];
-          wsC[row + 2 * q + 1] = rC[1];
+      if (tl <= tlast) {
+        // uniform row base + per-lane column: the four lanes with (lane & 15) == 0 write states 2q, 2q + 1
+        float *rowB = cB + tl * N, *rowC = cC + tl * N;
+        if constexpr (FULL) {
+          if (st0) {
+            *reinterpret_cast<f2 *>(rowB + qoff) = f2{rB[0], rB[1]};
+            *reinterpret_cast<f2 *>(rowC + qoff) = f2{rC[0], rC[1]};
+          }
+        } else {
+          if (st0) {
+            rowB[qoff] = rB[0];
+            rowC[qoff] = rC[0];
+          }
+          if (st1) {
+            rowB[qoff + 1] = rB[1];
+            rowC[qoff + 1] = rC[1];
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -289,13 +321,13 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       }
     };
 
-    float xs[SUB][NS];
+    f2 xs[SUB][NP2];
     StepOps cur, nxt;
     // ---- second half (local steps 8..15), only if the chunk reaches it
     if (tlast >= SUB) {
-      float x[NS];
+      f2 x[NP2];
 #pragma unroll
-      for (int j = 0; j < NS; ++j) x[j] = x0[j];
+      for (int j = 0; j < NP2; ++j) x[j] = x0[j];
       fetch(0, cur);
 #pragma unroll
       for (int tl = 0; tl < SUB; ++tl) {       // steps 0..7, state only
@@ -306,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
 #pragma unroll
       for (int s = 0; s < SUB; ++s) {          // steps 8..14, keeping the state before every step
 #pragma unroll
-        for (int j = 0; j < NS; ++j) xs[s][j] = x[j];
+        for (int j = 0; j < NP2; ++j) xs[s][j] = x[j];
         if (s + 1 < SUB) {
           fetch(SUB + s + 1, nxt);
           fwd_step(x, cur);
@@ -325,14 +357,14 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     }
     // ---- first half (local steps 0..7)
     {
-      float x[NS];
+      f2 x[NP2];
 #pragma unroll
-      for (int j = 0; j < NS; ++j) x[j] = x0[j];
+      for (int j = 0; j < NP2; ++j) x[j] = x0[j];
       fetch(0, cur);
 #pragma unroll
       for (int s = 0; s < SUB; ++s) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) xs[s][j] = x[j];
+        for (int j = 0; j < NP2; ++j) xs[s][j] = x[j];
         if (s + 1 < SUB) {
           fetch(s + 1, nxt);
           fwd_step(x, cur);
@@ -357,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     float *wa = p.ws_dA + ((int64_t)b * Dm + d) * N + n0;
 #pragma unroll
     for (int j = 0; j < NS; ++j)
-      if (j < nvalid) wa[j] = dAacc[j];
+      if (j < nvalid) wa[j] = dAacc[j / 2][j % 2];
   }
   __syncthreads();
   s_p1[w][0][lane] = accD;
@@ -422,12 +454,15 @@ template <int NW, typename TIO>
 static int launch_bwd_io(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
   const bool fast = p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW;
-  if (scan_bwd_variant() == 1)
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO>), grid, block, 0, st, p);
-  else if (fast)
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, 1, TIO>), grid, block, 0, st, p);
+  if (scan_bwd_variant() == 1) {
+    if (p.s.dstate == NS * NW)
+      hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO, true>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO, false>), grid, block, 0, st, p);
+  } else if (fast)
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, 1, TIO, false>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, 0, TIO>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, 0, TIO, false>), grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }

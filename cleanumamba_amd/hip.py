@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcleanumamba_hip.so")
+LIB_PATH = os.environ.get("CUM_LIB") or os.path.join(_HERE, "libcleanumamba_hip.so")   # CUM_LIB: another build (A/B)
 
 c_i32, c_i64, c_f32p, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
 

@@ -20,10 +20,7 @@
 
 namespace cum {
 
-// Two states of one lane side by side: the arithmetic below is written on pairs so that it maps onto the packed
-// f32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32: two results per lane per issue slot).
-typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int NP2 = NS / 2;
+constexpr int NP2 = NS / 2;   // state pairs per wave (f2: scan_common.h)
 __device__ __forceinline__ f2 exp2_2(f2 v) {
   f2 r;
   r.x = __builtin_amdgcn_exp2f(v.x);

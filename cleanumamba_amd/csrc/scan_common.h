@@ -20,6 +20,10 @@ constexpr int TB = 16;  // steps per chunk == checkpoint interval
 constexpr int SUB = 8;  // steps whose states are held in registers in backward
 constexpr int NS = 8;   // states per wave
 
+// Two states of one lane side by side: the scan arithmetic is written on pairs so that it maps onto the packed
+// f32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32: two results per lane per issue slot).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct ScanParams {
   cum_scan_shape s;
   cum_scan_grad_strides gs;

@@ -187,13 +187,13 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
   const int n0 = w * NS;
   const int nvalid = (N - n0) < NS ? (N - n0) : NS;
 
-  float Ap[NS], x[NS];
+  f2 Ap[NS / 2], x[NS / 2];
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int jj = j < nvalid ? j : nvalid - 1;
     const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
-    Ap[j] = (j < nvalid) ? a : 0.f;
-    x[j] = 0.f;
+    Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
+    x[j / 2][j % 2] = 0.f;
   }
   const float Dd = p.D ? p.D[dc] : 0.f;
   const float bias = p.bias ? p.bias[dc] : 0.f;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
       float *ck = p.ckpt + (((int64_t)b * nchunks + c) * N + n0) * Dm + d;
 #pragma unroll
       for (int j = 0; j < NS; ++j)
-        if (dok && j < nvalid) ck[(int64_t)j * Dm] = x[j];
+        if (dok && j < nvalid) ck[(int64_t)j * Dm] = x[j / 2][j % 2];
     }
     __syncthreads();
     float4 b0 = *reinterpret_cast<const float4 *>(&s_B[0][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[0][n0 + 4]);
@@ -281,16 +281,21 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
         ndt = s_dt[tl + 1][lane];
         ndu = s_du[tl + 1][lane];
       }
-      const float bv[NS] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      const float cv[NS] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-      float y = 0.f;
+      // pairs of states -> v_pk_mul_f32 / v_pk_fma_f32 (two state updates per issue slot); even and odd states
+      // are summed apart and joined once per step
+      const f2 bv[NS / 2] = {f2{b0.x, b0.y}, f2{b0.z, b0.w}, f2{b1.x, b1.y}, f2{b1.z, b1.w}};
+      const f2 cv[NS / 2] = {f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, f2{c1.z, c1.w}};
+      f2 y = {0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const float a = __builtin_amdgcn_exp2f(dt * Ap[j]);
-        x[j] = fmaf(a, x[j], du * bv[j]);
-        y = fmaf(cv[j], x[j], y);
+      for (int j = 0; j < NS / 2; ++j) {
+        const f2 e = dt * Ap[j];
+        f2 a;
+        a.x = __builtin_amdgcn_exp2f(e.x);
+        a.y = __builtin_amdgcn_exp2f(e.y);
+        x[j] = a * x[j] + du * bv[j];
+        y = cv[j] * x[j] + y;
       }
-      s_y[w][tl][lane] = y;
+      s_y[w][tl][lane] = y.x + y.y;
       __builtin_amdgcn_sched_barrier(0);
       b0 = nb0; b1 = nb1; c0 = nc0; c1 = nc1; dt = ndt; du = ndu;
     }
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
     float *ls = p.last_state + ((int64_t)b * Dm + d) * N + n0;
 #pragma unroll
     for (int j = 0; j < NS; ++j)
-      if (j < nvalid) ls[j] = x[j];
+      if (j < nvalid) ls[j] = x[j / 2][j % 2];
   }
 }
 

@@ -21,6 +21,8 @@
 namespace cum {
 
 constexpr int NP2 = NS / 2;   // state pairs per wave (f2: scan_common.h)
+constexpr int NA = 5;         // reverse steps per 8-step half that take their decay factors from LDS (80 KB at NW = 8)
+static_assert(NS == 8, "s_a holds the 8 states of a lane as two float4");
 __device__ __forceinline__ f2 exp2_2(f2 v) {
   f2 r;
   r.x = __builtin_amdgcn_exp2f(v.x);
@@ -75,6 +77,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   __shared__ float s_p1[NW][SUB][64];  // sum_n g * A'   (-> ddelta)
   __shared__ float s_p2[NW][SUB][64];  // sum_n dx * B   (-> ddelta, du)
   __shared__ float s_y[NW][SUB][64];   // sum_n C * x_t  (-> dz)
+  // decay factors a_t = exp2(dt * A') of the first NA steps of the half being processed: written by the recomputed
+  // forward steps, read back by the reverse steps instead of a second v_exp_f32 (each lane reads what it wrote)
+  __shared__ __attribute__((aligned(16))) float4 s_a[NA][2][NT];
 
   const int tid = threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -208,10 +213,15 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     // fetched one step ahead of their use so that neither the scalar-load nor the LDS latency is exposed.
     struct StepOps {
       f2 bv[NP2], cv[NP2];
+      f2 a[NP2];        // decay factors, only for steps whose slot is < NA
       float dt, du, dy;
     };
-    auto fetch = [&](int tl, StepOps &o) {
+    auto fetch = [&](int tl, StepOps &o, int aslot = -1) {
       const int tc = tl <= tlast ? tl : tlast;
+      if (aslot >= 0 && aslot < NA) {
+        const float4 a0 = s_a[aslot][0][tid], a1 = s_a[aslot][1][tid];
+        o.a[0] = f2{a0.x, a0.y}; o.a[1] = f2{a0.z, a0.w}; o.a[2] = f2{a1.x, a1.y}; o.a[3] = f2{a1.z, a1.w};
+      }
       if constexpr (LDSBC) {
         const float4 b0 = *reinterpret_cast<const float4 *>(&s_B[tc][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[tc][n0 + 4]);
         const float4 c0 = *reinterpret_cast<const float4 *>(&s_C[tc][n0]), c1 = *reinterpret_cast<const float4 *>(&s_C[tc][n0 + 4]);
@@ -232,11 +242,16 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       o.dy = s_dy[tl][lane];
     };
     // one recomputed forward step (state only)
-    auto fwd_step = [&](f2 (&x)[NP2], const StepOps &o) {
+    auto fwd_step = [&](f2 (&x)[NP2], const StepOps &o, int aslot = -1) {
+      f2 a[NP2];
 #pragma unroll
       for (int j = 0; j < NP2; ++j) {
-        const f2 a = exp2_2(o.dt * Ap[j]);
-        x[j] = a * x[j] + o.du * o.bv[j];
+        a[j] = exp2_2(o.dt * Ap[j]);
+        x[j] = a[j] * x[j] + o.du * o.bv[j];
+      }
+      if (aslot >= 0 && aslot < NA) {
+        s_a[aslot][0][tid] = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
+        s_a[aslot][1][tid] = make_float4(a[2].x, a[2].y, a[3].x, a[3].y);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       f2 dBp[NP2], dCp[NP2];
 #pragma unroll
       for (int j = 0; j < NP2; ++j) {
-        const f2 a = exp2_2(dt * Ap[j]);
+        const f2 a = slot < NA ? o.a[j] : exp2_2(dt * Ap[j]);
         const f2 xt = a * xp[j] + du * o.bv[j];
         const f2 dx = o.cv[j] * dy + dxc[j];
         yp = o.cv[j] * xt + yp;
@@ -338,13 +353,13 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         for (int j = 0; j < NP2; ++j) xs[s][j] = x[j];
         if (s + 1 < SUB) {
           fetch(SUB + s + 1, nxt);
-          fwd_step(x, cur);
+          fwd_step(x, cur, s);
           cur = nxt;
         }
       }
 #pragma unroll
       for (int s = SUB - 1; s >= 0; --s) {     // reverse 15..8 (cur holds step 15's operands)
-        if (s > 0) fetch(SUB + s - 1, nxt);
+        if (s > 0) fetch(SUB + s - 1, nxt, s - 1);
         rev_step(xs[s], SUB + s, s, cur);
         if (s > 0) cur = nxt;
       }
@@ -364,13 +379,13 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         for (int j = 0; j < NP2; ++j) xs[s][j] = x[j];
         if (s + 1 < SUB) {
           fetch(s + 1, nxt);
-          fwd_step(x, cur);
+          fwd_step(x, cur, s);
           cur = nxt;
         }
       }
 #pragma unroll
       for (int s = SUB - 1; s >= 0; --s) {
-        if (s > 0) fetch(s - 1, nxt);
+        if (s > 0) fetch(s - 1, nxt, s - 1);
         rev_step(xs[s], s, s, cur);
         if (s > 0) cur = nxt;
       }

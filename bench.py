@@ -167,7 +167,7 @@ def other_kernels(dev):
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "launch_ms": round(ms, 4), "algorithmic_bytes": byt,
                 "state_updates_per_s": round(upd / (ms * 1e-3) / 1e12, 3), "state_updates_unit": "T/s",
-                "note": "2.4 v_exp_f32 + ~20 VALU per state element: instruction-issue bound (DESIGN.md 3.2)"})
+                "note": "1.25 v_exp_f32 + ~9 packed VALU ops per state element: instruction-issue bound (DESIGN.md 3.2)"})
     return out
 
 

@@ -5,12 +5,11 @@
 // scaler.scale(loss).backward(), src/training/train.py:282-285).
 // Gradient formulas: SURVEY.md Appendix A.3.  Mapping: scan_common.h.
 //
-// The forward saved the state entering every 16-step chunk.  Chunks are walked in
-// reverse; inside a chunk each wave recomputes the states of one 8-step half into
-// VGPRs (8 x NS registers) and walks that half backwards:
-//     second half:  x0 -> 8 plain steps -> x8 ; 7 steps saving states ; reverse 15..8
-//     first half :  x0 -> 7 steps saving states ; reverse 7..0
-// i.e. 1.4 recomputed forward steps + 1 reverse step per time step (2.4 v_exp_f32 per
+// The forward saved the state entering every 8-step half of every 16-step chunk.  Chunks are
+// walked in reverse; inside a chunk each wave recomputes the states of one half into VGPRs
+// (8 x NS registers, 7 forward steps from the saved state) and walks that half backwards; the
+// decay factors of five of those steps come back from LDS, the other three are recomputed:
+// 7/8 recomputed forward steps + 1 reverse step per time step, 1.25 v_exp_f32 per
 // state element).  Sums over the channel axis (dB, dC) are reduced inside the wave with
 // v_permlane32_swap / v_permlane16_swap + DPP row adds; sums over workgroups (dB, dC)
 // and over the batch (dA, dD, dbias) go through fp32 slabs and a deterministic finalize
@@ -163,16 +162,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     const int tlast = L - 1 - t0;  // last valid local step of this chunk (>= 0)
     float *cB = wsB + (int64_t)t0 * N, *cC = wsC + (int64_t)t0 * N;
     // state entering the chunk: needed by both halves, requested now so that its latency hides behind phase A
-    f2 x0[NP2];
-    {
-      const float *ck = p.ckpt_in + (((int64_t)b * nchunks + c) * N + n0) * Dm + dc;
-#pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const int jj = j < nvalid ? j : nvalid - 1;
-        const float v = ck[(int64_t)jj * Dm];
-        x0[j / 2][j % 2] = (j < nvalid) ? v : 0.f;
-      }
-    }
+    f2 x0[NP2], x8[NP2];   // x8: state entering the second half (local step 8), read only if the chunk reaches it
+    ckpt_load(p.ckpt_in, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, dc), x0);
+    ckpt_load(p.ckpt_in, ckpt_slot(b, nchunks, c, tlast >= SUB ? 1 : 0, NW, w, Dm, dc), x8);
     float eu[K], ez[K], edo[K], edt[K], esg[K];
     // ---- phase A: per-(t, d) quantities, once, into LDS
 #pragma unroll
@@ -339,14 +331,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     if (tlast >= SUB) {
       f2 x[NP2];
 #pragma unroll
-      for (int j = 0; j < NP2; ++j) x[j] = x0[j];
-      fetch(0, cur);
-#pragma unroll
-      for (int tl = 0; tl < SUB; ++tl) {       // steps 0..7, state only
-        fetch(tl + 1, nxt);
-        fwd_step(x, cur);
-        cur = nxt;
-      }
+      for (int j = 0; j < NP2; ++j) x[j] = x8[j];
+      fetch(SUB, cur);
 #pragma unroll
       for (int s = 0; s < SUB; ++s) {          // steps 8..14, keeping the state before every step
 #pragma unroll

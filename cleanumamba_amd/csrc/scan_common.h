@@ -18,7 +18,7 @@ namespace cum {
 
 constexpr int TB = 16;  // steps per chunk == checkpoint interval
 constexpr int SUB = 8;  // steps whose states are held in registers in backward
-constexpr int NS = 8;   // states per wave
+constexpr int NS = 8;   // states per wave (ckpt_store / ckpt_load assume 8)
 
 // Two states of one lane side by side: the scan arithmetic is written on pairs so that it maps onto the packed
 // f32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32: two results per lane per issue slot).
@@ -38,6 +38,27 @@ struct ScanParams {
   float *ws_dA, *ws_dD, *ws_dbias, *ws_dB, *ws_dC;
   int nchunks, ngroups;
 };
+
+// Checkpoint buffer: the NS states a lane (channel d) of wave w holds, entering half h of chunk c of clip b, as
+// 32 contiguous bytes -- [(b, c, h, w, d)][NS]: two 16-byte accesses per lane, 2 KB contiguous per wave.
+__device__ __forceinline__ int64_t ckpt_slot(int b, int nchunks, int c, int h, int NW, int w, int Dm, int d) {
+  return (((((int64_t)b * nchunks + c) * 2 + h) * NW + w) * Dm + d) * NS;
+}
+__device__ __forceinline__ void ckpt_store(float *ck, int64_t slot, const float (&x)[NS]) {
+  float4 *q = reinterpret_cast<float4 *>(ck + slot);
+  q[0] = make_float4(x[0], x[1], x[2], x[3]);
+  q[1] = make_float4(x[4], x[5], x[6], x[7]);
+}
+__device__ __forceinline__ void ckpt_store(float *ck, int64_t slot, const f2 (&x)[NS / 2]) {
+  float4 *q = reinterpret_cast<float4 *>(ck + slot);
+  q[0] = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+  q[1] = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+}
+__device__ __forceinline__ void ckpt_load(const float *ck, int64_t slot, f2 (&x)[NS / 2]) {
+  const float4 *q = reinterpret_cast<const float4 *>(ck + slot);
+  const float4 a = q[0], c = q[1];
+  x[0] = f2{a.x, a.y}; x[1] = f2{a.z, a.w}; x[2] = f2{c.x, c.y}; x[3] = f2{c.z, c.w};
+}
 
 typedef const float __attribute__((address_space(4))) *cfp;
 

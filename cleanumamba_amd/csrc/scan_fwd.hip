@@ -85,12 +85,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
       ez[k] = rz[k];
     }
     if (c + 1 < nchunks) load_rows(t0 + TB);  // prefetch the next chunk's rows
-    if (p.ckpt) {
-      float *ck = p.ckpt + (((int64_t)b * nchunks + c) * N + n0) * Dm + d;
-#pragma unroll
-      for (int j = 0; j < NS; ++j)
-        if (dok && j < nvalid) ck[(int64_t)j * Dm] = x[j];
-    }
+    if (p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, d), x);
     __syncthreads();
     // ---- phase B: 16 sequential steps.  Operands (s_load for B/C, ds_read for delta'/du) are fetched TWO steps
     //      at a time, one pair ahead of their use: scalar loads return out of order, so any wait on them is a
@@ -128,6 +123,8 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
           y = fmaf(cur.cv[h][j], x[j], y);
         }
         s_y[w][tp + h][lane] = y;
+        if (tp + h == SUB - 1 && p.ckpt && dok)   // state entering the second half of the chunk
+          ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 1, NW, w, Dm, d), x);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (tp + 2 < TB) cur = nxt;
@@ -259,12 +256,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
       }
     }
     if (c + 1 < nchunks) load_rows(t0 + TB);
-    if (p.ckpt) {
-      float *ck = p.ckpt + (((int64_t)b * nchunks + c) * N + n0) * Dm + d;
-#pragma unroll
-      for (int j = 0; j < NS; ++j)
-        if (dok && j < nvalid) ck[(int64_t)j * Dm] = x[j / 2][j % 2];
-    }
+    if (p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, d), x);
     __syncthreads();
     float4 b0 = *reinterpret_cast<const float4 *>(&s_B[0][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[0][n0 + 4]);
     float4 c0 = *reinterpret_cast<const float4 *>(&s_C[0][n0]), c1 = *reinterpret_cast<const float4 *>(&s_C[0][n0 + 4]);
@@ -296,6 +288,8 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
         y = cv[j] * x[j] + y;
       }
       s_y[w][tl][lane] = y.x + y.y;
+      if (tl == SUB - 1 && p.ckpt && dok)   // state entering the second half of the chunk
+        ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 1, NW, w, Dm, d), x);
       __builtin_amdgcn_sched_barrier(0);
       b0 = nb0; b1 = nb1; c0 = nc0; c1 = nc1; dt = ndt; du = ndu;
     }
@@ -411,7 +405,8 @@ extern "C" int cum_scan_chunk(void) { return TB; }
 
 extern "C" int64_t cum_scan_ckpt_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len) {
   const int64_t nchunks = (len + TB - 1) / TB;
-  return (int64_t)batch * nchunks * dstate * dim;
+  const int64_t nw = (dstate + NS - 1) / NS;
+  return 2 * (int64_t)batch * nchunks * nw * dim * NS;   // the state entering each 8-step half of every chunk
 }
 
 extern "C" int cum_selective_scan_fwd(const cum_scan_shape *s, const void *u, const void *delta, const float *A,

@@ -56,8 +56,8 @@ int cum_scan_chunk(void);
  * y_t = <C_t, x_t> + D u_t, out = y * silu(z).   
  *
  * ckpt: NULL (inference) or fp32 buffer of cum_scan_ckpt_elems() elements that
- * receives the state entering every chunk of cum_scan_chunk() steps; the
- * backward consumes it.  last_state: NULL or (batch, dim, dstate) contiguous.
+ * receives the state entering every half of every chunk of cum_scan_chunk() steps
+ * (opaque layout, 16-byte aligned); the backward consumes it.  last_state: NULL or (batch, dim, dstate) contiguous.
  */
 typedef struct {
   int32_t batch, dim, dstate, len;

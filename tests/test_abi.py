@@ -28,7 +28,9 @@ def test_library_exports_every_declared_symbol():
 def test_size_queries_and_argument_errors():
     from cleanumamba_amd import hip
     lib = hip.lib()
-    assert lib.cum_scan_ckpt_elems(2, 8, 8, 33) == 2 * 3 * 8 * 8
+    # two saved states (one per 8-step half) per 16-step chunk, states padded to whole 8-state wave slices
+    assert lib.cum_scan_ckpt_elems(2, 8, 8, 33) == 2 * 2 * 3 * 8 * 8
+    assert lib.cum_scan_ckpt_elems(1, 5, 13, 16) == 2 * 1 * 1 * 2 * 5 * 8
     assert lib.cum_scan_bwd_workspace_elems(2, 100, 13, 7) == 2 * 100 * 13 + 2 * 2 * 100 + 2 * 2 * 2 * 7 * 13
     assert lib.cum_conv_bwd_workspace_elems(2, 10, 33, 4) == 2 * 3 * 5 * 10
     # bad arguments are rejected before any launch (works without a GPU)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Kernel trace of the default bench.py run + a short run for per-step sums (GPU box).  Outputs under gpurun_out/prof_round/.
+cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_round
+rm -rf $OUT && mkdir -p $OUT
+# (1) short run, no roofline / cpu legs: kernel-time sum per step against the wall-clock step time
+rocprofv3 --kernel-trace --stats -d /tmp/short -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-roofline --no-cpu-baseline > $OUT/short.json 2> $OUT/short.err
+python3 $GRAFT_REPO_ROOT/tools/ab_kernel_sums.py /tmp/short/step_results.db short > $OUT/short_sums.txt 2>&1
+python3 - /tmp/short/step_results.db <<'PY' > $OUT/short_gaps.txt
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select start, end, name from kernels order by start").fetchall()
+# the last 10 steps: split by the Adam kernel (FusedOptimizer multi_tensor_apply)
+idx = [i for i, r in enumerate(rows) if "FusedOptimizerTensorListMetadata" in r[2] or "fused_adam" in r[2].lower()]
+print("kernels", len(rows), "adam launches", len(idx))
+if len(idx) >= 12:
+    a, b = idx[-11*3], idx[-1*3] if False else idx[-1]
+    # step boundaries every 3 adam launches
+    ends = idx[2::3]
+    a, b = ends[-11], ends[-1]
+    seg = rows[a + 1:b + 1]
+    wall = (seg[-1][1] - seg[0][0]) / 1e6
+    busy = sum(e - s for s, e, _ in seg) / 1e6
+    gaps = sorted(((seg[i + 1][0] - seg[i][1]) / 1e3, seg[i][2][:60], seg[i + 1][2][:60]) for i in range(len(seg) - 1))
+    print("10 steps: wall %.2f ms, kernel busy %.2f ms, idle %.2f ms, launches %d" % (wall, busy, wall - busy, len(seg)))
+    print("largest gaps (us):")
+    for g in gaps[-15:]: print("  %.1f  %s -> %s" % g)
+    import collections
+    hist = collections.Counter(min(int(g[0] // 2) * 2, 40) for g in gaps)
+    print("gap histogram (us bucket: count):", sorted(hist.items()))
+PY
+# (2) the default run, csv stats for profiles/
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/full -o bench -- python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/full.err
+cp /tmp/full/bench_kernel_stats.csv $OUT/ 2>/dev/null || find /tmp/full -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;

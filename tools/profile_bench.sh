@@ -32,3 +32,22 @@ PY
 # (2) the default run, csv stats for profiles/
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/full -o bench -- python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/full.err
 cp /tmp/full/bench_kernel_stats.csv $OUT/ 2>/dev/null || find /tmp/full -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
+# (3) agreement of roofline.launch_ms with the trace: the roofline loop is the last thing bench.py runs at N = 1
+#     before the cpu baseline (16 shapes x (3 warm-up + 10 timed) cum_gemm_tn calls)
+python3 - /tmp/full $OUT/bench_under_rocprof.json <<'PY' > $OUT/tn_agreement.txt
+import csv, glob, json, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
+rows.sort()
+tn = [i for i, r in enumerate(rows) if "gemm_tn_kernel" in r[2]]
+n = 16 * 13
+first = tn[-n]
+seg = rows[first:]
+g = [e - s for s, e, k in seg if "gemm_tn_kernel" in k]
+red = [e - s for s, e, k in seg if "tn_reduce_kernel" in k]
+d = json.load(open(sys.argv[2]))
+print("last %d gemm_tn launches: mean %.1f us; tn_reduce launches in that span: %d, %.1f us per gemm_tn call" %
+      (len(g), sum(g) / len(g) / 1e3, len(red), sum(red) / len(g) / 1e3))
+print("kernel + reduce per call: %.1f us; roofline.launch_ms of the same run: %.1f us" %
+      ((sum(g) + sum(red)) / len(g) / 1e3, 1e3 * d["roofline"]["launch_ms"]))
+PY

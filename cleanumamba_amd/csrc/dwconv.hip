@@ -58,6 +58,58 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ConvParams p) {
   }
 }
 
+// bf16, channel-contiguous rows: one lane walks TWO adjacent channels (4-byte loads / stores: a wave instruction moves
+// 256 B instead of 128 B, half as many memory instructions) and the arithmetic runs on float2 pairs (v_pk_* ops).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 bf16x2_to_f2(uint32_t v) {
+  f2 r;
+  r.x = __builtin_bit_cast(float, v << 16);
+  r.y = __builtin_bit_cast(float, v & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ uint32_t f2_to_bf16x2(f2 v) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const bf16x2 o = {(__bf16)v.x, (__bf16)v.y};
+  return __builtin_bit_cast(uint32_t, o);
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const ConvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 128 + 2 * lane;
+  const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  const int L = p.s.len;
+  const int t0 = chunk * TC;
+  if (d >= p.s.dim || t0 >= L) return;
+  f2 wk[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) wk[k] = f2{p.w[d * W + k], p.w[(d + 1) * W + k]};
+  const f2 bs = p.bias ? f2{p.bias[d], p.bias[d + 1]} : f2{0.f, 0.f};
+  const __bf16 *xp = static_cast<const __bf16 *>(p.x) + b * p.s.x_sb + d;
+  __bf16 *yp = static_cast<__bf16 *>(p.y) + b * p.s.y_sb + d;
+  f2 xv[TC + W - 1];
+#pragma unroll
+  for (int i = 0; i < TC + W - 1; ++i) {
+    const int t = t0 - (W - 1) + i;
+    const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
+    const f2 v = bf16x2_to_f2(*reinterpret_cast<const uint32_t *>(xp + (int64_t)tc * p.s.x_sl));
+    xv[i] = (t >= 0 && t < L) ? v : f2{0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < TC; ++i) {
+    const int t = t0 + i;
+    f2 acc = bs;
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc = wk[k] * xv[i + k] + acc;
+    if (p.s.silu) {
+      acc.x = acc.x * sigmoidf_(acc.x);
+      acc.y = acc.y * sigmoidf_(acc.y);
+    }
+    if (t < L) *reinterpret_cast<uint32_t *>(yp + (int64_t)t * p.s.y_sl) = f2_to_bf16x2(acc);
+  }
+}
+
 template <int W, typename TIO>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ConvParams p) {
   const int lane = threadIdx.x & 63;
@@ -118,6 +170,67 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ConvParams p) {
 #pragma unroll
   for (int k = 0; k < W; ++k) ws[(int64_t)k * p.s.dim] = dwk[k];
   ws[(int64_t)MAXW * p.s.dim] = db;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void dwconv_bwd2_kernel(const ConvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 128 + 2 * lane;
+  const int chunk = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  const int L = p.s.len;
+  const int t0 = chunk * TC;
+  if (d >= p.s.dim || chunk >= p.nchunks) return;
+  f2 wk[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) wk[k] = f2{p.w[d * W + k], p.w[(d + 1) * W + k]};
+  const f2 bs = p.bias ? f2{p.bias[d], p.bias[d + 1]} : f2{0.f, 0.f};
+  const __bf16 *xp = static_cast<const __bf16 *>(p.x) + b * p.s.x_sb + d;
+  const __bf16 *dyp = static_cast<const __bf16 *>(p.dy) + b * p.s.y_sb + d;
+  __bf16 *dxp = static_cast<__bf16 *>(p.dx) + b * p.dx_sb + d;
+  f2 xv[TC + 2 * (W - 1)], g[TC + W - 1];
+#pragma unroll
+  for (int i = 0; i < TC + 2 * (W - 1); ++i) {
+    const int t = t0 - (W - 1) + i;
+    const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
+    const f2 v = bf16x2_to_f2(*reinterpret_cast<const uint32_t *>(xp + (int64_t)tc * p.s.x_sl));
+    xv[i] = (t >= 0 && t < L) ? v : f2{0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < TC + W - 1; ++i) {
+    const int s = t0 + i;
+    const int sc = s < L ? s : L - 1;
+    const f2 v = bf16x2_to_f2(*reinterpret_cast<const uint32_t *>(dyp + (int64_t)sc * p.s.y_sl));
+    f2 gi = s < L ? v : f2{0.f, 0.f};
+    if (p.s.silu) {
+      f2 pre = bs;
+#pragma unroll
+      for (int k = 0; k < W; ++k) pre = wk[k] * xv[i + k] + pre;
+      f2 sg;
+      sg.x = sigmoidf_(pre.x);
+      sg.y = sigmoidf_(pre.y);
+      gi *= sg * (1.f + pre * (1.f - sg));
+    }
+    g[i] = gi;
+  }
+  f2 dwk[W], db = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < W; ++k) dwk[k] = f2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TC; ++i) {
+    const int t = t0 + i;
+    f2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc = wk[k] * g[i + (W - 1) - k] + acc;
+    if (t < L) *reinterpret_cast<uint32_t *>(dxp + (int64_t)t * p.dx_sl) = f2_to_bf16x2(acc);
+#pragma unroll
+    for (int k = 0; k < W; ++k) dwk[k] = g[i] * xv[i + k] + dwk[k];
+    db += g[i];
+  }
+  float *ws = p.ws + ((int64_t)(b * p.nchunks + chunk) * (MAXW + 1)) * p.s.dim + d;
+#pragma unroll
+  for (int k = 0; k < W; ++k) *reinterpret_cast<f2 *>(ws + (int64_t)k * p.s.dim) = dwk[k];
+  *reinterpret_cast<f2 *>(ws + (int64_t)MAXW * p.s.dim) = db;
 }
 
 // dweight[d][k] = sum over (batch, chunk) slabs; dbias likewise.  A workgroup owns 64 consecutive (k, d) outputs;
@@ -194,6 +307,17 @@ extern "C" int cum_causal_conv1d_fwd(const cum_conv_shape *s, const void *x, con
   dim3 grid((s->dim + 63) / 64, (p.nchunks + 3) / 4, s->batch), block(256);
   hipStream_t st = (hipStream_t)stream;
   const bool h = s->io_dtype == CUM_BF16;
+  const bool pair = h && s->dim % 2 == 0 && s->x_sd == 1 && s->y_sd == 1 && s->x_sl % 2 == 0 && s->y_sl % 2 == 0 &&
+                    s->x_sb % 2 == 0 && s->y_sb % 2 == 0 && ((uintptr_t)x & 3) == 0 && ((uintptr_t)y & 3) == 0;
+  if (pair) {
+    dim3 grid2((s->dim / 2 + 63) / 64, grid.y, grid.z);
+    switch (s->width) {
+      case 1: hipLaunchKernelGGL(dwconv_fwd2_kernel<1>, grid2, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL(dwconv_fwd2_kernel<2>, grid2, block, 0, st, p); break;
+      case 3: hipLaunchKernelGGL(dwconv_fwd2_kernel<3>, grid2, block, 0, st, p); break;
+      default: hipLaunchKernelGGL(dwconv_fwd2_kernel<4>, grid2, block, 0, st, p); break;
+    }
+  } else
   switch (s->width) {
     case 1: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<1, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<1, float>), grid, block, 0, st, p); break;
     case 2: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<2, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<2, float>), grid, block, 0, st, p); break;
@@ -228,6 +352,19 @@ extern "C" int cum_causal_conv1d_bwd(const cum_conv_shape *s, const void *x, con
   p.nchunks = (s->len + TC - 1) / TC;
   dim3 grid((s->dim + 63) / 64, (p.nchunks + 3) / 4, s->batch), block(256);
   const bool h = s->io_dtype == CUM_BF16;
+  // two channels per lane when every row of x, dy and dx starts 4-byte aligned with unit channel stride
+  const bool pair = h && s->dim % 2 == 0 && s->x_sd == 1 && s->y_sd == 1 && dx_sd == 1 && s->x_sl % 2 == 0 &&
+                    s->y_sl % 2 == 0 && dx_sl % 2 == 0 && s->x_sb % 2 == 0 && s->y_sb % 2 == 0 && dx_sb % 2 == 0 &&
+                    ((uintptr_t)x & 3) == 0 && ((uintptr_t)dy & 3) == 0 && ((uintptr_t)dx & 3) == 0;
+  if (pair) {
+    dim3 grid2((s->dim / 2 + 63) / 64, (p.nchunks + 3) / 4, s->batch);
+    switch (s->width) {
+      case 1: hipLaunchKernelGGL(dwconv_bwd2_kernel<1>, grid2, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL(dwconv_bwd2_kernel<2>, grid2, block, 0, st, p); break;
+      case 3: hipLaunchKernelGGL(dwconv_bwd2_kernel<3>, grid2, block, 0, st, p); break;
+      default: hipLaunchKernelGGL(dwconv_bwd2_kernel<4>, grid2, block, 0, st, p); break;
+    }
+  } else
   switch (s->width) {
     case 1: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<1, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<1, float>), grid, block, 0, st, p); break;
     case 2: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<2, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<2, float>), grid, block, 0, st, p); break;

@@ -159,7 +159,7 @@ def test_streaming_step_kernels_vs_golden(cuda):
     assert rel_l2(cs, g["conv_state64"]) < 1e-6
 
 
-@pytest.mark.parametrize("shape", [(2, 192, 64, 150), (1, 70, 20, 33)])
+@pytest.mark.parametrize("shape", [(2, 192, 64, 150), (1, 70, 20, 33), (2, 53, 8, 40)])   # 53: odd dim, one channel per lane
 def test_scan_and_dwconv_bf16_io_vs_oracle(cuda, shape):
     """bf16 element type for u / delta / z / out (what autocast hands over; cum_scan_shape.io_dtype): against the
     f64 oracle on the SAME bf16-rounded inputs the only differences are the kernels' f32 arithmetic and the final

@@ -87,13 +87,19 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
                                         P(out, o_off), P(aux, x_off), P(aux2, y_off), hip.stream_ptr()))
 
 
-def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True):
-    """dW [N, K] f32 = dZ^T X (X rows may overlap), db [N] f32 = column sums of dZ.  csrc/gemm_tn.hip."""
+def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True, out=None):
+    """dW [N, K] f32 = dZ^T X (X rows may overlap), db [N] f32 = column sums of dZ.  csrc/gemm_tn.hip.
+    ``out = (flat f32 buffer, offset)`` places dW then db at that offset (N*K + N elements) instead of allocating."""
     lib = hip.lib()
     dc = hip.dtype_code(dZ.dtype)
     dev = dZ.device
-    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
-    db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
+    if out is not None:
+        arena, off = out
+        dW = arena[off:off + N * K].view(N, K)
+        db = arena[off + N * K:off + N * K + N] if want_bias else None
+    else:
+        dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+        db = torch.empty(N, dtype=torch.float32, device=dev) if want_bias else None
     ws = torch.empty(max(lib.cum_gemm_tn_workspace_elems(dc, M, N, K), 1), dtype=torch.float32, device=dev)
     esz = dZ.element_size()
     with torch.cuda.device(dev):
@@ -238,6 +244,52 @@ def _invert(packed_ids, param_shape):
 
 def _zeros(rows, cols):
     return torch.zeros(rows, cols, dtype=torch.int64)
+
+
+# Weight gradients of a whole stack: every cum_gemm_tn of the stack's backward writes (dW, db) in GEMM layout into one
+# flat f32 arena, and ONE gather (index built once per stack signature) brings all of them into the parameters'
+# layouts -- instead of two or three gathers per layer (~50 launches per step).
+_ARENA_BATCH = os.environ.get("CUM_WGRAD_ARENA", "1") != "0"      # "0": one gather per parameter (A/B timing)
+_ARENA_INDEX = {}
+
+
+class _WgradArena:
+    def __init__(self, sizes, dev):
+        """sizes: [(N, K)] per weight-gradient GEMM, in slot order."""
+        self.sizes, self.offs, off = sizes, [], 0
+        for N, K in sizes:
+            self.offs.append(off)
+            off += (N * K + N + 3) // 4 * 4           # 16-byte aligned slots (the GEMM stores float4)
+        self.buf = torch.empty(max(off, 4), dtype=torch.float32, device=dev)
+
+    def out(self, slot):
+        return (self.buf, self.offs[slot])
+
+    def dw_index(self, slot, inv_ids):
+        """inv_ids: _invert(...) layout of a parameter (1-based position in the slot's dW, 0 = no source)."""
+        ids = inv_ids.reshape(-1)
+        return torch.where(ids > 0, ids - 1 + self.offs[slot], torch.full_like(ids, -1))
+
+    def db_index(self, slot, inv_ids):
+        N, K = self.sizes[slot]
+        ids = inv_ids.reshape(-1)
+        return torch.where(ids > 0, ids - 1 + self.offs[slot] + N * K, torch.full_like(ids, -1))
+
+    def unpack(self, key, build_parts, shapes):
+        """One gather for all parameters; build_parts() -> [index tensor per parameter]; returns views per shape."""
+        ent = _ARENA_INDEX.get((key, self.buf.device))
+        if ent is None:
+            ent = torch.cat([p.reshape(-1) for p in build_parts()]).to(torch.int32).to(self.buf.device)
+            _ARENA_INDEX[(key, self.buf.device)] = ent
+        flat = gather(self.buf, ent, torch.float32)
+        outs, off = [], 0
+        for sh in shapes:
+            n = 1
+            for d in sh:
+                n *= d
+            outs.append(flat[off:off + n].view(sh))
+            off += n
+        return outs
 
 
 def lay_conv_fwd(wshape, cp_in, rows, cols):
@@ -623,12 +675,15 @@ def _glu_bwd(z, ybuf, dy, go):
     return dz
 
 
-def _glu_wgrad(dz, xbuf, w, gi, M):
-    """Weight / bias gradient of a 1x1+GLU layer from dZ [M, G*32] and its input row buffer."""
+def _glu_wgrad(dz, xbuf, w, gi, M, out=None):
+    """Weight / bias gradient of a 1x1+GLU layer from dZ [M, G*32] and its input row buffer.  With ``out`` (an arena
+    slot) the GEMM-layout results stay there for the stack's batched un-pack and nothing is returned."""
     G32 = dz.shape[1]
     H2 = w.shape[0]
     sh = tuple(w.shape)
-    dwp, dbp = wgrad(dz, 0, G32, G32, xbuf, gi.Cp, gi.Cp, gi.Cp, M)
+    dwp, dbp = wgrad(dz, 0, G32, G32, xbuf, gi.Cp, gi.Cp, gi.Cp, M, out=out)
+    if out is not None:
+        return None, None
     db = take(dbp, ("glu_vec_unpack", H2), lambda: _invert(lay_glu_vec(H2), (H2,)))
     dw = take(dwp, ("glu_unpack", sh, G32, gi.Cp), lambda: _invert(lay_glu_fwd(sh, G32, gi.Cp), sh))
     return dw.to(w.dtype), db.to(w.dtype)
@@ -671,6 +726,11 @@ class EncoderStack(torch.autograd.Function):
         dt, dev = bufs[0].dtype, bufs[0].device
         grads = [None] * (4 * E)
         dz, dx0 = None, None
+        # arena slots: 2 i = conv of layer i (N = Cp_mid, K = 4 Cp_in), 2 i + 1 = its 1x1+GLU (N = G*32, K = Cp_mid)
+        arena = None
+        if _ARENA_BATCH:
+            arena = _WgradArena([nk for i in range(E) for nk in ((geos[i][1].Cp, 4 * geos[i][0].Cp),
+                                                                 (2 * zs[i].shape[1], geos[i][1].Cp))], dev)
         for i in reversed(range(E)):
             gi, gm, go = geos[i]
             w1, b1, w2, b2 = params[4 * i:4 * i + 4]
@@ -679,7 +739,8 @@ class EncoderStack(torch.autograd.Function):
                     raise RuntimeError("EncoderStack: the deepest output must be used")
                 dz = _glu_bwd(zs[i], bufs[i + 1], dys[i].contiguous(), go)
             G32 = dz.shape[1]
-            grads[4 * i + 2], grads[4 * i + 3] = _glu_wgrad(dz, y1s[i], w2, gm, go.M)
+            grads[4 * i + 2], grads[4 * i + 3] = _glu_wgrad(dz, y1s[i], w2, gm, go.M,
+                                                            out=arena.out(2 * i + 1) if arena else None)
             # 1x1 data gradient, gated by the ReLU below it in the epilogue
             wt = _glu_dgrad_weights(w2, gm, G32, dt)
             dzc = gm.new(dt, dev)
@@ -687,10 +748,12 @@ class EncoderStack(torch.autograd.Function):
                  res=y1s[i], r_off=gm.Cp, ldr=gm.Cp, geo=gm)
             # conv weight gradient: X row m = the 4*Cp contiguous inputs of output row m
             sh = tuple(w1.shape)
-            dwp, dbp = wgrad(dzc, gm.Cp, gm.Cp, gm.Cp, bufs[i], gi.Cp, 2 * gi.Cp, 4 * gi.Cp, gm.M)
-            grads[4 * i] = take(dwp, ("conv_unpack", sh, gi.Cp, gm.Cp),
-                                lambda: _invert(lay_conv_fwd(sh, gi.Cp, gm.Cp, 4 * gi.Cp), sh)).to(w1.dtype)
-            grads[4 * i + 1] = dbp[:sh[0]].to(w1.dtype)
+            dwp, dbp = wgrad(dzc, gm.Cp, gm.Cp, gm.Cp, bufs[i], gi.Cp, 2 * gi.Cp, 4 * gi.Cp, gm.M,
+                             out=arena.out(2 * i) if arena else None)
+            if arena is None:
+                grads[4 * i] = take(dwp, ("conv_unpack", sh, gi.Cp, gm.Cp),
+                                    lambda: _invert(lay_conv_fwd(sh, gi.Cp, gm.Cp, 4 * gi.Cp), sh)).to(w1.dtype)
+                grads[4 * i + 1] = dbp[:sh[0]].to(w1.dtype)
             dz = None
             if i == 0 and not ctx.needs_input_grad[0]:
                 break
@@ -711,6 +774,22 @@ class EncoderStack(torch.autograd.Function):
                 dx0 = dx
             else:
                 dz = _glu_bwd(zs[i - 1], bufs[i], dx if ext is None else dx + ext, gi)
+        if arena is not None:
+            shapes = [tuple(p.shape) for p in params]
+
+            def parts():
+                out = []
+                for i in range(E):
+                    gi, gm, _ = geos[i]
+                    sh1, sh2 = shapes[4 * i], shapes[4 * i + 2]
+                    G32 = 2 * zs[i].shape[1]
+                    out.append(arena.dw_index(2 * i, _invert(lay_conv_fwd(sh1, gi.Cp, gm.Cp, 4 * gi.Cp), sh1)))
+                    out.append(arena.db_index(2 * i, torch.arange(1, sh1[0] + 1, dtype=torch.int64)))
+                    out.append(arena.dw_index(2 * i + 1, _invert(lay_glu_fwd(sh2, G32, gm.Cp), sh2)))
+                    out.append(arena.db_index(2 * i + 1, _invert(lay_glu_vec(sh2[0]), (sh2[0],))))
+                return out
+            key = ("enc", tuple(shapes), tuple((g[0].Cp, g[1].Cp) for g in geos), tuple(z.shape[1] for z in zs))
+            grads = [g.to(p.dtype) for g, p in zip(arena.unpack(key, parts, shapes), params)]
         return (dx0, None, None, *grads)
 
 
@@ -763,15 +842,23 @@ class DecoderStack(torch.autograd.Function):
                                                  hip.stream_ptr()))
             dpre = gated
         du = None
+        # arena slots: 2 j = 1x1+GLU of layer j (N = G*32, K = Cp_in), 2 j + 1 = its transposed conv (N = 2 Cp_out,
+        # K = 2 Cp_glu)
+        arena = None
+        if _ARENA_BATCH:
+            arena = _WgradArena([nk for j in range(E) for nk in ((2 * zs[j].shape[1], geos[j][0].Cp),
+                                                                 (2 * geos[j][2].Cp, 2 * geos[j][1].Cp))], dev)
         for j in reversed(range(E)):
             gi, gg, go = geos[j]
             w1, b1, wt, bt = params[4 * j:4 * j + 4]
             sht = tuple(wt.shape)
             # transposed-conv weight gradient: pair rows of dpre against the 2*Cp contiguous inputs (rows m-1, m)
-            dwp, dbp = wgrad(dpre, go.Cp, 2 * go.Cp, 2 * go.Cp, gs[j], 0, gg.Cp, 2 * gg.Cp, gg.M)
+            dwp, dbp = wgrad(dpre, go.Cp, 2 * go.Cp, 2 * go.Cp, gs[j], 0, gg.Cp, 2 * gg.Cp, gg.M,
+                             out=arena.out(2 * j + 1) if arena else None)
             grads[4 * j + 3] = (dbp[:go.Cp] + dbp[go.Cp:])[:sht[1]].to(wt.dtype)
-            grads[4 * j + 2] = take(dwp, ("convt_unpack", sht, gg.Cp, go.Cp),
-                                    lambda: _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)).to(wt.dtype)
+            if arena is None:
+                grads[4 * j + 2] = take(dwp, ("convt_unpack", sht, gg.Cp, go.Cp),
+                                        lambda: _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)).to(wt.dtype)
             # its data gradient = strided conv of dpre (row t reads rows 2t..2t+3), through the GLU in the epilogue
             Nd, Kd = rup(gg.Cp, 16), rup(4 * go.Cp, bk_of(dt))
             wc = take(wt, ("convt_dgrad", sht, go.Cp, Nd, Kd), lambda: lay_convt_dgrad(sht, go.Cp, Nd, Kd), dt)
@@ -785,7 +872,7 @@ class DecoderStack(torch.autograd.Function):
                 dg = gg.new(dt, dev)
                 gemm(dpre, go.Cp, 2 * go.Cp, wc, None, dg, gg.Cp, gg.Cp, gg.M, gg.P, gg.T, hip.EPI_BIAS, gg.Cp, geo=gg)
                 dz = _glu_bwd(z, gs[j], dg, gg)
-            grads[4 * j], grads[4 * j + 1] = _glu_wgrad(dz, us[j], w1, gi, gg.M)
+            grads[4 * j], grads[4 * j + 1] = _glu_wgrad(dz, us[j], w1, gi, gg.M, out=arena.out(2 * j) if arena else None)
             # 1x1 data gradient: ungated it is the gradient of u_j (and of the skip added into it); gated by the ReLU
             # of layer j-1 it is that layer's dpre -- both written by one epilogue
             w1t = _glu_dgrad_weights(w1, gi, G32, dt)
@@ -801,4 +888,23 @@ class DecoderStack(torch.autograd.Function):
                 dpre = du
             if j > 0 and j - 1 < ctx.n_skips:
                 dskips[j - 1] = du
+        if arena is not None:
+            # w1, b1, wt per layer from one gather (bt is the sum of two halves of its slab: set above)
+            shapes = [tuple(params[4 * j + k].shape) for j in range(E) for k in range(3)]
+
+            def parts():
+                out = []
+                for j in range(E):
+                    gi, gg, go = geos[j]
+                    sh1, sht = shapes[3 * j], shapes[3 * j + 2]
+                    G32 = 2 * zs[j].shape[1]
+                    out.append(arena.dw_index(2 * j, _invert(lay_glu_fwd(sh1, G32, gi.Cp), sh1)))
+                    out.append(arena.db_index(2 * j, _invert(lay_glu_vec(sh1[0]), (sh1[0],))))
+                    out.append(arena.dw_index(2 * j + 1, _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)))
+                return out
+            key = ("dec", tuple(shapes), tuple((g[0].Cp, g[1].Cp, g[2].Cp) for g in geos), tuple(z.shape[1] for z in zs))
+            un = arena.unpack(key, parts, shapes)
+            for j in range(E):
+                for k in range(3):
+                    grads[4 * j + k] = un[3 * j + k].to(params[4 * j + k].dtype)
         return (du, None, None, None, *dskips, *grads)

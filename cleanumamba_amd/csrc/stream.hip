@@ -52,15 +52,15 @@ __global__ __launch_bounds__(256) void stream_tail_kernel(const T *__restrict__ 
 // Out of place into `tmp`, then copied back by the second kernel (stream order makes the shift race-free).
 template <typename T>
 __global__ __launch_bounds__(256) void stream_window_shift_kernel(const T *__restrict__ window, const T *__restrict__ fresh,
-                                                                  T *__restrict__ tmp, int64_t pitch, int streams, int rows,
-                                                                  int n_new, int Cp) {
+                                                                  T *__restrict__ tmp, int64_t pitch, int64_t fresh_pitch,
+                                                                  int fresh_row0, int streams, int rows, int n_new, int Cp) {
   const int64_t total = (int64_t)streams * rows * Cp;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = i % Cp;
     const int64_t r = i / Cp;
     const int t = r % rows;
     const int64_t s = r / rows;
-    tmp[i] = t < rows - n_new ? window[(s * pitch + t + n_new) * Cp + c] : fresh[(s * pitch + t) * Cp + c];
+    tmp[i] = t < rows - n_new ? window[(s * pitch + t + n_new) * Cp + c] : fresh[(s * fresh_pitch + t - fresh_row0) * Cp + c];
   }
 }
 template <typename T>
@@ -74,15 +74,33 @@ __global__ __launch_bounds__(256) void stream_window_store_kernel(const T *__res
   }
 }
 
+// newest rows of a window -> compact input of the next layer's incremental step
+template <typename T>
+__global__ __launch_bounds__(256) void stream_tail_rows_kernel(const T *__restrict__ src, int64_t src_pitch, int src_row0,
+                                                               T *__restrict__ dst, int64_t dst_pitch, int streams,
+                                                               int rows, int Cp) {
+  const int64_t total = (int64_t)streams * rows * Cp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = i % Cp;
+    const int64_t r = i / Cp;
+    const int t = r % rows;
+    const int64_t s = r / rows;
+    dst[(s * dst_pitch + t) * Cp + c] = src[(s * src_pitch + src_row0 + t) * Cp + c];
+  }
+}
+
 }  // namespace cum
 
 using namespace cum;
 
 extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t rows, int32_t n_new, int32_t Cp,
-                                        void *window, const void *fresh, int64_t pitch, void *tmp, void *stream) {
+                                        void *window, const void *fresh, int64_t pitch, int64_t fresh_pitch,
+                                        int32_t fresh_row0, void *tmp, void *stream) {
   CUM_REQUIRE(dtype == CUM_F32 || dtype == CUM_BF16, "stream_window_update: dtype must be CUM_F32 or CUM_BF16");
   CUM_REQUIRE(streams >= 0 && rows > 0 && n_new > 0 && n_new <= rows && Cp > 0 && pitch >= rows,
               "stream_window_update: bad shape");
+  CUM_REQUIRE(fresh_row0 >= 0 && fresh_row0 <= rows - n_new && fresh_pitch >= rows - fresh_row0,
+              "stream_window_update: fresh rows out of range");
   if (streams == 0) return CUM_OK;
   CUM_REQUIRE(window && fresh && tmp, "stream_window_update: null pointer");
   hipStream_t st = (hipStream_t)stream;
@@ -90,15 +108,35 @@ extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t 
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (dtype == CUM_BF16) {
     hipLaunchKernelGGL(stream_window_shift_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)window,
-                       (const __bf16 *)fresh, (__bf16 *)tmp, pitch, streams, rows, n_new, Cp);
+                       (const __bf16 *)fresh, (__bf16 *)tmp, pitch, fresh_pitch, fresh_row0, streams, rows, n_new, Cp);
     hipLaunchKernelGGL(stream_window_store_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)tmp,
                        (__bf16 *)window, pitch, streams, rows, Cp);
   } else {
     hipLaunchKernelGGL(stream_window_shift_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)window,
-                       (const float *)fresh, (float *)tmp, pitch, streams, rows, n_new, Cp);
+                       (const float *)fresh, (float *)tmp, pitch, fresh_pitch, fresh_row0, streams, rows, n_new, Cp);
     hipLaunchKernelGGL(stream_window_store_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)tmp,
                        (float *)window, pitch, streams, rows, Cp);
   }
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+extern "C" int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows, int32_t Cp, const void *src,
+                                    int64_t src_pitch, int32_t src_row0, void *dst, int64_t dst_pitch, void *stream) {
+  CUM_REQUIRE(dtype == CUM_F32 || dtype == CUM_BF16, "stream_tail_rows: dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(streams >= 0 && rows > 0 && Cp > 0 && src_row0 >= 0 && src_pitch >= src_row0 + rows && dst_pitch >= rows,
+              "stream_tail_rows: bad shape");
+  if (streams == 0) return CUM_OK;
+  CUM_REQUIRE(src && dst, "stream_tail_rows: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)streams * rows * Cp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == CUM_BF16)
+    hipLaunchKernelGGL(stream_tail_rows_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)src, src_pitch,
+                       src_row0, (__bf16 *)dst, dst_pitch, streams, rows, Cp);
+  else
+    hipLaunchKernelGGL(stream_tail_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)src, src_pitch,
+                       src_row0, (float *)dst, dst_pitch, streams, rows, Cp);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }

@@ -84,7 +84,8 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P]),
     "cum_add_layernorm_bwd_workspace_elems": (c_i64, [c_i32]),
     "cum_add_layernorm_bwd": (c_i32, [c_i32, c_i32, c_i64, c_i32] + [_P] * 12),
-    "cum_stream_window_update": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, c_i64, _P, _P]),
+    "cum_stream_window_update": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, c_i64, c_i64, c_i32, _P, _P]),
+    "cum_stream_tail_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, _P, c_i64, c_i32, _P, c_i64, _P]),
     "cum_stream_overlap_add": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i64, _P, c_i64, c_i32, _P]),
     "cum_rfft": (c_i32, [c_i32, c_i64, _P, _P, _P]),
     "cum_irfft": (c_i32, [c_i32, c_i64, _P, _P, _P]),
@@ -105,7 +106,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 4:
+        if L.cum_abi_version() != 5:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -443,37 +443,67 @@ class CleanUMamba(nn.Module):
         return hg["static_out"].clone()
 
     def _denoise_frame_fused(self, frame, inplace=True):
-        """One hop on the fused GEMM kernels, same arithmetic as _denoise_frame.  Every encoder layer is recomputed
-        over the S windows (S independent clips of valid_length(1) samples, two GEMM launches) and only its newest
-        rows are appended to the layer's persistent window (cum_stream_window_update), so older activations keep the
-        input scaling of the hop that produced them, as with the reference's per-layer caches; a decoder layer is
+        """One hop on the fused GEMM kernels, same arithmetic as _denoise_frame.  Every encoder layer keeps a persistent
+        window of its output (the decoder's skips read its oldest rows); the first hop of a stream computes the
+        windows whole (S independent clips of valid_length(1) samples), later hops compute only the hop's new rows
+        from the newest rows of the window below (cum_stream_tail_rows) and append them (cum_stream_window_update),
+        so older activations keep the input scaling of the hop that produced them, as with the reference's per-layer
+        caches (``stream_incremental = False`` recomputes the windows every hop); a decoder layer is
         1x1+GLU GEMM, transposed-conv GEMM and one overlap-add kernel (cum_stream_overlap_add) that also applies
         ReLU, adds the skip and keeps the tail for the next hop."""
         S, E, dev = frame.shape[0], self.encoder_n_layers, frame.device
         dt = torch.bfloat16 if getattr(self, "stream_bf16", False) else torch.float32
         self._activate_pack_plan(dt)
         geo = cs.Geo(S, frame.shape[1], self.encoder[0][0].weight.shape[1])
-        buf = cs.to_rows(frame.unsqueeze(1), geo, dt)
         state, lib = self.encoder_decoder_state, hip.lib()
+        # After the first hop of a stream only the hop's new rows of every layer are computed: layer i emits
+        # n = total_stride >> (i + 1) rows from the 2 n + 2 newest rows of its input (2 carried + 2 n new ones).
+        incremental = state.get("enc0") is not None and getattr(self, "stream_incremental", True)
+        buf = None if incremental else cs.to_rows(frame.unsqueeze(1), geo, dt)
+        dc = hip.dtype_code(dt)
         enc_geos, outs, n_new = [], [], self.total_stride
         for i, enc in enumerate(self.encoder):
             T1 = (geo.T - self.kernel_size) // self.stride + 1
             g_mid = cs.Geo(S, T1, enc[0].weight.shape[0])
             g_out = cs.Geo(S, T1, enc[2].weight.shape[0] // 2)
             n_new //= self.stride
-            y1 = cs._conv_relu_fwd(buf, enc[0].weight, enc[0].bias, geo, g_mid)
-            fresh, _ = cs._glu_fwd(y1, enc[2].weight, enc[2].bias, g_mid, g_out, False)
-            # the layer's window keeps older rows as the hop that produced them left them (per-layer caches of the
-            # reference, :425-447): only the n_new newest rows of the recomputed window are taken over
             window = state.get(f"enc{i}")
-            if window is None:
-                window = state[f"enc{i}"] = fresh
-            else:
+            if incremental:
+                t_in = self.stride * n_new + self.kernel_size - self.stride
+                g_cin = cs.Geo(S, t_in, geo.C)
+                xin = state.get(f"encin{i}")
+                if xin is None:                   # persistent: its framing rows are zeroed once
+                    xin = state[f"encin{i}"] = g_cin.new(dt, dev, zero=True)
+                if i == 0:
+                    g_cin.rows(xin)[:, :t_in, :1] = frame[:, frame.shape[1] - t_in:].unsqueeze(-1).to(dt)
+                else:
+                    with torch.cuda.device(dev):
+                        hip.check(lib.cum_stream_tail_rows(dc, S, t_in, geo.Cp, hip.ptr(buf[1:]), geo.P, geo.T - t_in,
+                                                           hip.ptr(xin[1:]), g_cin.P, hip.stream_ptr()))
+                g_cm, g_co = cs.Geo(S, n_new, g_mid.C), cs.Geo(S, n_new, g_out.C)
+                y1 = cs._conv_relu_fwd(xin, enc[0].weight, enc[0].bias, g_cin, g_cm)
+                fresh, _ = cs._glu_fwd(y1, enc[2].weight, enc[2].bias, g_cm, g_co, False)
                 tmp = torch.empty(S * g_out.T * g_out.Cp, dtype=dt, device=dev)
                 with torch.cuda.device(dev):
-                    hip.check(lib.cum_stream_window_update(hip.dtype_code(dt), S, g_out.T, n_new, g_out.Cp,
-                                                           hip.ptr(window[1:]), hip.ptr(fresh[1:]), g_out.P, hip.ptr(tmp),
-                                                           hip.stream_ptr()))
+                    hip.check(lib.cum_stream_window_update(dc, S, g_out.T, n_new, g_out.Cp, hip.ptr(window[1:]),
+                                                           hip.ptr(fresh[1:]), g_out.P, g_co.P, g_out.T - n_new,
+                                                           hip.ptr(tmp), hip.stream_ptr()))
+            else:
+                y1 = cs._conv_relu_fwd(buf, enc[0].weight, enc[0].bias, geo, g_mid)
+                fresh, _ = cs._glu_fwd(y1, enc[2].weight, enc[2].bias, g_mid, g_out, False)
+                # the layer's window keeps older rows as the hop that produced them left them (per-layer caches of
+                # the reference, :425-447): only the n_new newest rows of the recomputed window are taken over
+                if window is None:
+                    window = state[f"enc{i}"] = fresh
+                    # compact input of the incremental hops; allocated here so that the captured hop allocates nothing
+                    t_in = self.stride * n_new + self.kernel_size - self.stride
+                    state[f"encin{i}"] = cs.Geo(S, t_in, geo.C).new(dt, dev, zero=True)
+                else:
+                    tmp = torch.empty(S * g_out.T * g_out.Cp, dtype=dt, device=dev)
+                    with torch.cuda.device(dev):
+                        hip.check(lib.cum_stream_window_update(dc, S, g_out.T, n_new, g_out.Cp, hip.ptr(window[1:]),
+                                                               hip.ptr(fresh[1:]), g_out.P, g_out.P, 0, hip.ptr(tmp),
+                                                               hip.stream_ptr()))
             enc_geos.append((geo, g_mid, g_out))
             outs.append(window)
             buf, geo = window, g_out

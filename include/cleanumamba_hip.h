@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 4
+#define CUM_ABI_VERSION 5
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -285,10 +285,16 @@ int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t rows, int32_
  *   tail[s][t] = y[s][L2 + t] - bias                                          t < 2
  * y, skip, out: stream s starts y_pitch / skip_pitch / out_pitch rows after stream s-1; tail: [S][2][Cp]. */
 /* Streaming encoder window of one layer (per-layer caches of _denoise_frame, :425-447): for every stream drop the n_new
- * oldest of `rows` rows and append rows [rows - n_new, rows) of `fresh`.  window, fresh: stream s starts `pitch` rows
- * after stream s-1; tmp: streams * rows * Cp elements of scratch. */
+ * oldest of `rows` rows and append n_new rows of `fresh`: window row t >= rows - n_new takes fresh row t - fresh_row0
+ * (fresh_row0 = 0: `fresh` is a whole recomputed window; fresh_row0 = rows - n_new: `fresh` holds only the new rows).
+ * window / fresh: stream s starts `pitch` / `fresh_pitch` rows after stream s-1; tmp: streams * rows * Cp elements. */
 int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t rows, int32_t n_new, int32_t Cp, void *window,
-                             const void *fresh, int64_t pitch, void *tmp, void *stream);
+                             const void *fresh, int64_t pitch, int64_t fresh_pitch, int32_t fresh_row0, void *tmp,
+                             void *stream);
+/* Input of the next layer's incremental step: dst[s][t] = src[s][src_row0 + t] for t < rows (the newest rows of a
+ * window: 2 carried rows + the hop's new rows); rows of dst beyond `rows` are not touched (they stay zero). */
+int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows, int32_t Cp, const void *src, int64_t src_pitch,
+                         int32_t src_row0, void *dst, int64_t dst_pitch, void *stream);
 int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t Cp, int32_t C, const void *y,
                            int64_t y_pitch, void *tail, const float *bias, const void *skip, int64_t skip_pitch,
                            void *out, int64_t out_pitch, int32_t relu, void *stream);

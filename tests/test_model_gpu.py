@@ -160,23 +160,26 @@ def test_batched_streams_equal_single_streams(cuda):
 
 def test_streaming_paths_agree_and_bf16_hop(cuda):
     """The fused hop (GEMM kernels, S >= 2), the cached torch-module hop and the optional bf16 hop on the same streams,
-    with input normalisation on (running std).  Fused and cached keep the same per-layer windows -> f32 rounding only
+    with input normalisation on (running std).  Fused (incremental or recomputing the windows) and cached keep the same
+    per-layer windows -> f32 rounding only
     (8e-6 measured; 1e-4).  The bf16 hop is held to the error bf16 itself costs on this checkpoint and input: the
     autocast parallel forward against the f32 one (0.112 measured, white noise in -> small output), x1.5."""
     net = _net("pruned500k", cuda, pruned=True)
     x = (0.1 * torch.randn(4, 9000, generator=torch.Generator().manual_seed(5))).to(cuda)
     outs = {}
     with torch.no_grad():
-        for name, fused, bf16 in (("fused", True, False), ("cached", False, False), ("bf16", True, True)):
+        for name, fused, bf16, incr in (("fused", True, False, True), ("cached", False, False, True),
+                                        ("bf16", True, True, True), ("fused_full", True, False, False)):
             net.reset_stream()
-            net.use_fused_stream, net.stream_bf16 = fused, bf16
+            net.use_fused_stream, net.stream_bf16, net.stream_incremental = fused, bf16, incr
             outs[name] = torch.cat([net.feed_batch(x), net.flush_batch()], 1)
-        net.stream_bf16 = False
+        net.stream_bf16, net.stream_incremental = False, True
         y32 = net(x.unsqueeze(1))
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y16 = net(x.unsqueeze(1)).float()
     assert outs["fused"].shape == (4, 9000) and outs["fused"].dtype == torch.float32
     assert rel_l2(outs["fused"], outs["cached"]) < 1e-4
+    assert rel_l2(outs["fused_full"], outs["cached"]) < 1e-4      # windows recomputed whole every hop
     bf16_cost = rel_l2(y16, y32)
     assert rel_l2(outs["bf16"], outs["fused"]) < 1.5 * bf16_cost + 1e-3
 

@@ -67,3 +67,20 @@ extern "C" int cum_irfft(int32_t n, int64_t batch, float *in, float *out, void *
   }
   return CUM_OK;
 }
+
+// in, out: [batch][n] interleaved complex (in == out allowed).  Unnormalised in both directions.
+extern "C" int cum_cfft(int32_t n, int64_t batch, float *in, float *out, int32_t inverse, void *stream) {
+  CUM_REQUIRE(n >= 2 && batch >= 0 && batch < 2147483647LL, "cfft: bad length or batch");
+  if (batch == 0) return CUM_OK;
+  CUM_REQUIRE(in && out, "cfft: null pointer");
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipfftHandle h;
+  if (int rc = get_plan(n, batch, HIPFFT_C2C, &h)) return rc;
+  if (hipfftSetStream(h, (hipStream_t)stream) != HIPFFT_SUCCESS ||
+      hipfftExecC2C(h, reinterpret_cast<hipfftComplex *>(in), reinterpret_cast<hipfftComplex *>(out),
+                    inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+    cum_set_error("cfft: hipfftExecC2C failed");
+    return CUM_ELAUNCH;
+  }
+  return CUM_OK;
+}

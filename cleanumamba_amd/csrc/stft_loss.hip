@@ -159,6 +159,110 @@ __global__ __launch_bounds__(256) void stft_loss_grad_kernel(const float2 *__res
   }
 }
 
+// ---- packed real FFT: the N real samples of a frame are transformed as H = N/2 complex numbers
+// z[m] = x[2m] + i x[2m+1] by ONE complex FFT (Z), and the real-input spectrum is recovered where it is consumed:
+//   X[k] = c1_k Z[k mod H] + c2_k conj(Z[(H-k) mod H]),  c1_k = (1 - i w_k)/2, c2_k = (1 + i w_k)/2, w_k = e^{-2 pi i k/N}
+// for k = 0..H.  rocFFT's own r2c / c2r do the same with a separate pass over the spectrum before / after the
+// complex FFT (r2c_even_post / c2r_even_pre: 0.4 ms per step); here that pass rides in the loss kernels.
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 conjf2(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 packed_bin(float2 za, float2 zb, float2 w) {
+  // c1 = (1 - i w)/2 = ((1 + w.y) - i w.x)/2 ; c2 = (1 + i w)/2 = ((1 - w.y) + i w.x)/2
+  const float2 c1 = make_float2(0.5f * (1.f + w.y), -0.5f * w.x), c2 = make_float2(0.5f * (1.f - w.y), 0.5f * w.x);
+  const float2 p = cmul(c1, za), q = cmul(c2, conjf2(zb));
+  return make_float2(p.x + q.x, p.y + q.y);
+}
+
+__global__ __launch_bounds__(256) void stft_loss_partials_packed_kernel(const float2 *__restrict__ zx,
+                                                                        const float2 *__restrict__ zy, int64_t rows,
+                                                                        int64_t n_frames, int H, int64_t frame0,
+                                                                        const float2 *__restrict__ tw,
+                                                                        float *__restrict__ partials) {
+  __shared__ float red[4];
+  const int64_t r0 = (int64_t)blockIdx.x * kLossRows;
+  const int nrow = (int)min((int64_t)kLossRows, rows - r0);
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int r = 0; r < nrow; ++r) {
+    if ((r0 + r) % n_frames < frame0) continue;
+    const int64_t base = (r0 + r) * H;
+    for (int k = threadIdx.x; k <= H; k += 256) {
+      const int a = k == H ? 0 : k, b = k == 0 ? 0 : H - k;
+      const float2 w = tw[k];
+      const LossTerms t = loss_terms(packed_bin(zx[base + a], zx[base + b], w), packed_bin(zy[base + a], zy[base + b], w));
+      const float d = t.my - t.mx;
+      s1 += d * d;
+      s2 += t.my * t.my;
+      s3 += fabsf(logf(t.my) - logf(t.mx));
+    }
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  s3 = block_sum_256(s3, red);
+  if (threadIdx.x == 0) {
+    partials[3 * (int64_t)blockIdx.x + 0] = s1;
+    partials[3 * (int64_t)blockIdx.x + 1] = s2;
+    partials[3 * (int64_t)blockIdx.x + 2] = s3;
+  }
+}
+
+// g_k = dL/dRe X[k] + i dL/dIm X[k] of one bin (no hermitian halving: every bin 0..H enters the loss once)
+__device__ __forceinline__ float2 bin_grad(float2 vx, float2 vy, float c_sc, float c_mag) {
+  const LossTerms t = loss_terms(vx, vy);
+  if (!t.live) return make_float2(0.f, 0.f);
+  const float inv_mx = 1.f / t.mx;
+  const float lg = logf(t.mx) - logf(t.my);
+  const float sgn = lg > 0.f ? 1.f : (lg < 0.f ? -1.f : 0.f);
+  const float dm = (c_sc * (t.mx - t.my) + c_mag * sgn * inv_mx) * inv_mx;
+  return make_float2(dm * vx.x, dm * vx.y);
+}
+
+// gz[j] = dL/dRe Z[j] + i dL/dIm Z[j]:  conj(c1_j) g_j + c2_{H-j} conj(g_{H-j})  (j = 1..H-1);
+// gz[0] = (1 + i) Re g_0 + (1 - i) Re g_H.  An unnormalised inverse complex FFT of gz is the gradient wrt the
+// frame's samples (even samples in the real parts, odd ones in the imaginary parts).
+__global__ __launch_bounds__(256) void stft_loss_grad_packed_kernel(const float2 *__restrict__ zx,
+                                                                    const float2 *__restrict__ zy, int64_t rows,
+                                                                    int64_t n_frames, int H, int64_t frame0,
+                                                                    const float *__restrict__ stats,
+                                                                    const float *__restrict__ g_sc,
+                                                                    const float *__restrict__ g_mag, float inv_count,
+                                                                    const float2 *__restrict__ tw,
+                                                                    float2 *__restrict__ gz) {
+  const int64_t r0 = (int64_t)blockIdx.x * kLossRows;
+  const int nrow = (int)min((int64_t)kLossRows, rows - r0);
+  const float c_sc = g_sc[0] / (stats[2] * stats[3]);
+  const float c_mag = g_mag[0] * inv_count;
+  for (int r = 0; r < nrow; ++r) {
+    const bool in_band = (r0 + r) % n_frames >= frame0;
+    const int64_t base = (r0 + r) * H;
+    for (int j = threadIdx.x; j <= H / 2; j += 256) {
+      const int m = j == 0 ? 0 : H - j;                 // mirror index
+      float2 oj = make_float2(0.f, 0.f), om = oj;
+      if (in_band) {
+        const float2 xj = zx[base + j], xm = zx[base + m], yj = zy[base + j], ym = zy[base + m];
+        if (j == 0) {
+          // X[0] = Re z + Im z, X[H] = Re z - Im z (both real)
+          const float2 g0 = bin_grad(make_float2(xj.x + xj.y, 0.f), make_float2(yj.x + yj.y, 0.f), c_sc, c_mag);
+          const float2 gh = bin_grad(make_float2(xj.x - xj.y, 0.f), make_float2(yj.x - yj.y, 0.f), c_sc, c_mag);
+          oj = make_float2(g0.x + gh.x, g0.x - gh.x);
+        } else {
+          const float2 wj = tw[j], wm = tw[H - j];
+          const float2 gj = bin_grad(packed_bin(xj, xm, wj), packed_bin(yj, ym, wj), c_sc, c_mag);
+          const float2 gm = bin_grad(packed_bin(xm, xj, wm), packed_bin(ym, yj, wm), c_sc, c_mag);
+          // conj(c1_k) = ((1 + w.y) + i w.x)/2 ; c2_k = ((1 - w.y) + i w.x)/2
+          const float2 c1j = make_float2(0.5f * (1.f + wj.y), 0.5f * wj.x), c2j = make_float2(0.5f * (1.f - wj.y), 0.5f * wj.x);
+          const float2 c1m = make_float2(0.5f * (1.f + wm.y), 0.5f * wm.x), c2m = make_float2(0.5f * (1.f - wm.y), 0.5f * wm.x);
+          const float2 a = cmul(c1j, gj), b = cmul(c2m, conjf2(gm));
+          oj = make_float2(a.x + b.x, a.y + b.y);
+          const float2 c = cmul(c1m, gm), d = cmul(c2j, conjf2(gj));
+          om = make_float2(c.x + d.x, c.y + d.y);
+        }
+      }
+      gz[base + j] = oj;
+      if (m != j) gz[base + m] = om;
+    }
+  }
+}
+
 // One thread per signal sample: sums win[n] * dframes[f][n] over every (f, n) whose padded position lands on it --
 // the direct position and, near the ends, its mirror images in the reflect padding.
 __global__ __launch_bounds__(256) void stft_fold_kernel(const float *__restrict__ dframes, int64_t len, int n_fft,
@@ -258,6 +362,40 @@ extern "C" int cum_stft_fold(const float *dframes, int64_t batch, int64_t len, i
   hipLaunchKernelGGL(stft_fold_kernel, dim3((unsigned)cdiv64(len, 256), (unsigned)batch), dim3(256), 0,
                      (hipStream_t)stream, dframes, len, n_fft, hop, win_length, window, n_frames, dx, dx_stride_b,
                      accumulate);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+extern "C" int cum_stft_loss_fwd_packed(const float *zx, const float *zy, int64_t batch, int64_t n_frames, int32_t n_fft,
+                                        int64_t frame0, const float *twiddle, float *workspace, float *stats,
+                                        void *stream) {
+  CUM_REQUIRE(batch > 0 && n_frames > 0 && n_fft >= 8 && n_fft % 4 == 0 && frame0 >= 0 && frame0 < n_frames,
+              "stft_loss_fwd_packed: bad shape");
+  CUM_REQUIRE(zx && zy && twiddle && workspace && stats, "stft_loss_fwd_packed: null pointer");
+  const int64_t rows = batch * n_frames, parts = cdiv64(rows, kLossRows);
+  const int H = n_fft / 2;
+  hipLaunchKernelGGL(stft_loss_partials_packed_kernel, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream,
+                     (const float2 *)zx, (const float2 *)zy, rows, n_frames, H, frame0, (const float2 *)twiddle,
+                     workspace);
+  const double count = (double)batch * (double)(n_frames - frame0) * (double)(H + 1);
+  hipLaunchKernelGGL(stft_loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, workspace, parts, count,
+                     stats);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+extern "C" int cum_stft_loss_bwd_packed(const float *zx, const float *zy, int64_t batch, int64_t n_frames, int32_t n_fft,
+                                        int64_t frame0, const float *stats, const float *g_sc, const float *g_mag,
+                                        const float *twiddle, float *gz, void *stream) {
+  CUM_REQUIRE(batch > 0 && n_frames > 0 && n_fft >= 8 && n_fft % 4 == 0 && frame0 >= 0 && frame0 < n_frames,
+              "stft_loss_bwd_packed: bad shape");
+  CUM_REQUIRE(zx && zy && stats && g_sc && g_mag && twiddle && gz, "stft_loss_bwd_packed: null pointer");
+  const int64_t rows = batch * n_frames, parts = cdiv64(rows, kLossRows);
+  const int H = n_fft / 2;
+  const double count = (double)batch * (double)(n_frames - frame0) * (double)(H + 1);
+  hipLaunchKernelGGL(stft_loss_grad_packed_kernel, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream,
+                     (const float2 *)zx, (const float2 *)zy, rows, n_frames, H, frame0, stats, g_sc, g_mag,
+                     (float)(1.0 / count), (const float2 *)twiddle, (float2 *)gz);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }

@@ -89,6 +89,9 @@ SIGNATURES = {
     "cum_stream_overlap_add": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i64, _P, c_i64, c_i32, _P]),
     "cum_rfft": (c_i32, [c_i32, c_i64, _P, _P, _P]),
     "cum_irfft": (c_i32, [c_i32, c_i64, _P, _P, _P]),
+    "cum_cfft": (c_i32, [c_i32, c_i64, _P, _P, c_i32, _P]),
+    "cum_stft_loss_fwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P]),
+    "cum_stft_loss_bwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

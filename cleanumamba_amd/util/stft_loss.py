@@ -6,15 +6,34 @@ ParallelWaveGAN): per resolution a spectral-convergence term
 averaged over resolutions and weighted by sc_lambda / mag_lambda.
 
 On the GPU one resolution is: cum_stft_frames (window + reflect padding, both signals) -> one batched
-rocFFT r2c (cum_rfft) -> cum_stft_loss_fwd (both terms, deterministic tree sums); backward is cum_stft_loss_bwd ->
-one unnormalised c2r (cum_irfft) -> cum_stft_fold (overlap-add gather).  The reference's ~25 elementwise passes per
+rocFFT complex FFT of n_fft/2 points over the frames read as packed complex numbers (cum_cfft) ->
+cum_stft_loss_fwd_packed (recovers the real-input spectrum, both terms, deterministic tree sums); backward is
+cum_stft_loss_bwd_packed -> one unnormalised inverse complex FFT -> cum_stft_fold (overlap-add gather).  The reference's ~25 elementwise passes per
 resolution and direction never touch HBM.  CPU tensors take the plain torch.stft route below (host-side
 checks only; the train step never does).
 """
+import math
+import os
+
 import torch
 import torch.nn.functional as F
 
 from .. import hip
+
+# Packed path (default): one complex FFT of n_fft/2 points per frame, the real-input spectrum recovered inside the
+# loss kernels (cum_stft_loss_*_packed) -- rocFFT's separate r2c post- / c2r pre-processing passes disappear.
+# CUM_STFT_PACKED=0 keeps the r2c / c2r route (A/B timing).
+_PACKED = os.environ.get("CUM_STFT_PACKED", "1") != "0"
+_TWIDDLE = {}
+
+
+def _twiddle(n_fft, device):
+    key = (n_fft, device)
+    if key not in _TWIDDLE:
+        k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)
+        ang = -2.0 * math.pi * k / n_fft
+        _TWIDDLE[key] = torch.stack([torch.cos(ang), torch.sin(ang)], 1).float().contiguous().to(device)
+    return _TWIDDLE[key]
 
 
 class STFTLossFn(torch.autograd.Function):
@@ -43,13 +62,21 @@ class STFTLossFn(torch.autograd.Function):
             for i, sig in enumerate((x, y)):
                 hip.check(lib.cum_stft_frames(hip.ptr(sig), bsz, L, sig.stride(0), n_fft, hop, win_length,
                                               hip.ptr(window), hip.ptr(frames[i]), n_frames, st))
-            # rocFFT, one batched r2c for both signals; `frames` is scratch and may be overwritten
-            spec = torch.empty(2, bsz, n_frames, bins, dtype=torch.complex64, device=x.device)
-            sr = torch.view_as_real(spec)
-            hip.check(lib.cum_rfft(n_fft, 2 * bsz * n_frames, hip.ptr(frames), hip.ptr(sr), st))
-            del frames
-            hip.check(lib.cum_stft_loss_fwd(hip.ptr(sr[0]), hip.ptr(sr[1]), bsz, n_frames, bins, frame0, hip.ptr(ws),
-                                            hip.ptr(stats), st))
+            if _PACKED:
+                # frames read as (n_fft / 2) complex numbers, transformed in place by one batched complex FFT
+                tw = _twiddle(n_fft, x.device)
+                hip.check(lib.cum_cfft(n_fft // 2, 2 * bsz * n_frames, hip.ptr(frames), hip.ptr(frames), 0, st))
+                hip.check(lib.cum_stft_loss_fwd_packed(hip.ptr(frames[0]), hip.ptr(frames[1]), bsz, n_frames, n_fft,
+                                                       frame0, hip.ptr(tw), hip.ptr(ws), hip.ptr(stats), st))
+                spec = frames
+            else:
+                # rocFFT, one batched r2c for both signals; `frames` is scratch and may be overwritten
+                spec = torch.empty(2, bsz, n_frames, bins, dtype=torch.complex64, device=x.device)
+                sr = torch.view_as_real(spec)
+                hip.check(lib.cum_rfft(n_fft, 2 * bsz * n_frames, hip.ptr(frames), hip.ptr(sr), st))
+                del frames
+                hip.check(lib.cum_stft_loss_fwd(hip.ptr(sr[0]), hip.ptr(sr[1]), bsz, n_frames, bins, frame0,
+                                                hip.ptr(ws), hip.ptr(stats), st))
         ctx.save_for_backward(spec, stats, window)
         ctx.cfg = (bsz, L, n_fft, hop, win_length, n_frames, bins, frame0)
         return stats[0], stats[1]
@@ -67,15 +94,23 @@ class STFTLossFn(torch.autograd.Function):
             zero = torch.zeros((), dtype=torch.float32, device=spec.device)
         g_sc = zero if g_sc is None else g_sc.float().contiguous()
         g_mag = zero if g_mag is None else g_mag.float().contiguous()
-        sr = torch.view_as_real(spec)
-        z = torch.empty(bsz, n_frames, bins, dtype=torch.complex64, device=spec.device)
         dx = torch.empty(bsz, L, dtype=torch.float32, device=spec.device)
         with torch.cuda.device(spec.device):
             st = hip.stream_ptr()
-            hip.check(lib.cum_stft_loss_bwd(hip.ptr(sr[0]), hip.ptr(sr[1]), bsz, n_frames, bins, frame0, hip.ptr(stats),
-                                            hip.ptr(g_sc), hip.ptr(g_mag), hip.ptr(torch.view_as_real(z)), st))
             dframes = torch.empty(bsz, n_frames, n_fft, dtype=torch.float32, device=spec.device)
-            hip.check(lib.cum_irfft(n_fft, bsz * n_frames, hip.ptr(torch.view_as_real(z)), hip.ptr(dframes), st))
+            if spec.dtype == torch.float32:          # packed transforms (2, B, frames, n_fft) saved by the forward
+                tw = _twiddle(n_fft, spec.device)
+                hip.check(lib.cum_stft_loss_bwd_packed(hip.ptr(spec[0]), hip.ptr(spec[1]), bsz, n_frames, n_fft, frame0,
+                                                       hip.ptr(stats), hip.ptr(g_sc), hip.ptr(g_mag), hip.ptr(tw),
+                                                       hip.ptr(dframes), st))
+                hip.check(lib.cum_cfft(n_fft // 2, bsz * n_frames, hip.ptr(dframes), hip.ptr(dframes), 1, st))
+            else:
+                sr = torch.view_as_real(spec)
+                z = torch.empty(bsz, n_frames, bins, dtype=torch.complex64, device=spec.device)
+                hip.check(lib.cum_stft_loss_bwd(hip.ptr(sr[0]), hip.ptr(sr[1]), bsz, n_frames, bins, frame0,
+                                                hip.ptr(stats), hip.ptr(g_sc), hip.ptr(g_mag),
+                                                hip.ptr(torch.view_as_real(z)), st))
+                hip.check(lib.cum_irfft(n_fft, bsz * n_frames, hip.ptr(torch.view_as_real(z)), hip.ptr(dframes), st))
             hip.check(lib.cum_stft_fold(hip.ptr(dframes), bsz, L, n_fft, hop, win_length, hip.ptr(window), n_frames,
                                         hip.ptr(dx), dx.stride(0), 0, st))
         return dx, None, None, None, None, None, None

@@ -261,6 +261,22 @@ int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n
 int cum_rfft(int32_t n, int64_t batch, float *in, float *out, void *stream);
 int cum_irfft(int32_t n, int64_t batch, float *in, float *out, void *stream);
 
+/* Complex FFT of length n, batch transforms, unnormalised in both directions; in == out allowed. */
+int cum_cfft(int32_t n, int64_t batch, float *in, float *out, int32_t inverse, void *stream);
+
+/* The same loss on PACKED transforms: a frame's n_fft real samples are read as n_fft/2 complex numbers
+ * (even samples real, odd imaginary) and transformed by cum_cfft; zx / zy: [batch * n_frames][n_fft / 2] complex.  The
+ * real-input spectrum X[k], k = 0..n_fft/2, is recovered inside the kernels (twiddle: [n_fft/2 + 1] complex,
+ * e^{-2 pi i k / n_fft}).  cum_stft_loss_bwd_packed writes gz = dL/dRe(Z) + i dL/dIm(Z); an unnormalised inverse
+ * cum_cfft of gz is the gradient wrt the frames (what cum_stft_fold takes).  Replaces rocFFT's r2c post- / c2r
+ * pre-processing passes. */
+int cum_stft_loss_fwd_packed(const float *zx, const float *zy, int64_t batch, int64_t n_frames, int32_t n_fft,
+                             int64_t frame0, const float *twiddle, float *workspace, float *stats, void *stream);
+int cum_stft_loss_bwd_packed(const float *zx, const float *zy, int64_t batch, int64_t n_frames, int32_t n_fft,
+                             int64_t frame0, const float *stats, const float *g_sc, const float *g_mag,
+                             const float *twiddle, float *gz, void *stream);
+
+
 /* ---- residual add + LayerNorm of the Mamba blocks (mamba-ssm Block.forward with fused_add_norm=False as the reference
  * runs it, src/network/CleanUMamba.py:156-189, 288-294, and the final add + norm_f, :292-294):
  *   residual_out = x + residual (fp32);   y = (residual_out - mean) * rstd * weight + bias

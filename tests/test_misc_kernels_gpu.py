@@ -37,3 +37,21 @@ def test_rfft_irfft_match_torch_fft(cuda, n_fft):
     hip.check(hip.lib().cum_irfft(n_fft, batch, hip.ptr(torch.view_as_real(z)), hip.ptr(back), hip.stream_ptr()))
     assert rel_l2(back, back_want) < 1e-6
     assert rel_l2(back / n_fft, x) < 1e-5                            # round trip
+
+
+@pytest.mark.parametrize("n", [256, 1024])
+def test_cfft_matches_torch_fft(cuda, n):
+    """cum_cfft (hipFFT c2c, in place, unnormalised both ways) against torch.fft in float64."""
+    from cleanumamba_amd import hip
+    g = torch.Generator().manual_seed(n)
+    z = torch.randn(37, n, 2, generator=g)
+    ref = torch.fft.fft(torch.view_as_complex(z.double()))
+    buf = z.to(cuda).contiguous()
+    with torch.cuda.device(cuda):
+        hip.check(hip.lib().cum_cfft(n, 37, hip.ptr(buf), hip.ptr(buf), 0, hip.stream_ptr()))
+    got = torch.view_as_complex(buf.double().cpu())
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+    with torch.cuda.device(cuda):
+        hip.check(hip.lib().cum_cfft(n, 37, hip.ptr(buf), hip.ptr(buf), 1, hip.stream_ptr()))
+    back = buf.cpu() / n
+    assert float((back - z).abs().max()) < 1e-5

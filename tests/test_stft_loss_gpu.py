@@ -80,3 +80,24 @@ def test_mrstft_loss_is_reproducible_and_rejects_cpu_mix(cuda):
     assert torch.equal(outs[0][2], outs[1][2])                     # fixed-order sums: bit-reproducible
     with pytest.raises(RuntimeError):
         STFTLossFn.apply(den.to(cuda), clean, mr.stft_losses[0].window, 1024, 120, 600, False)
+
+
+@pytest.mark.parametrize("band", ["full", "high"])
+def test_packed_and_r2c_paths_agree(cuda, band, monkeypatch):
+    """The default path (one complex FFT of n_fft/2 points per frame, spectrum recovered inside the loss kernels) and
+    the r2c / c2r path compute the same loss: values to 1e-6, the spectral-convergence gradient to 1e-5."""
+    from cleanumamba_amd.util import stft_loss as S
+    clean, den = _pair(2, 20000, seed=11)
+    cfg = dict(sc_lambda=0.5, mag_lambda=0.5, band=band, hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200],
+               fft_sizes=[512, 1024, 2048])
+    mr = S.MultiResolutionSTFTLoss(**cfg).to(cuda)
+    res = {}
+    for packed in (True, False):
+        monkeypatch.setattr(S, "_PACKED", packed)
+        xg = den.to(cuda).requires_grad_(True)
+        sc, mag = mr(xg, clean.to(cuda))
+        sc.backward()
+        res[packed] = (float(sc), float(mag), xg.grad.clone())
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    assert abs(res[True][1] - res[False][1]) <= 1e-6 * abs(res[False][1])
+    assert rel_l2(res[True][2], res[False][2]) < 1e-5

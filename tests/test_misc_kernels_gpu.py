@@ -55,3 +55,34 @@ def test_cfft_matches_torch_fft(cuda, n):
         hip.check(hip.lib().cum_cfft(n, 37, hip.ptr(buf), hip.ptr(buf), 1, hip.stream_ptr()))
     back = buf.cpu() / n
     assert float((back - z).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_stream_window_update_and_tail_rows(cuda, dt):
+    """The streaming encoder glue against plain slicing: window <- cat(window[n_new:], new rows) with `fresh` either a
+    whole recomputed window or only the new rows; tail_rows copies the newest rows into a compact clip buffer."""
+    from cleanumamba_amd import hip
+    S, rows, n_new, Cp, pitch = 5, 22, 8, 24, 24
+    g = torch.Generator().manual_seed(3)
+    window = torch.randn(S, pitch, Cp, generator=g).to(dt).to(cuda)
+    full = torch.randn(S, pitch, Cp, generator=g).to(dt).to(cuda)
+    want = torch.cat([window[:, n_new:rows], full[:, rows - n_new:rows]], 1)
+    lib, dc = hip.lib(), hip.dtype_code(dt)
+    for compact in (False, True):
+        w = window.clone()
+        fresh = full[:, rows - n_new:rows].contiguous() if compact else full
+        tmp = torch.empty(S * rows * Cp, dtype=dt, device=cuda)
+        with torch.cuda.device(cuda):
+            hip.check(lib.cum_stream_window_update(dc, S, rows, n_new, Cp, hip.ptr(w), hip.ptr(fresh), pitch,
+                                                   n_new if compact else pitch, rows - n_new if compact else 0,
+                                                   hip.ptr(tmp), hip.stream_ptr()))
+        assert torch.equal(w[:, :rows], want)
+        assert torch.equal(w[:, rows:], window[:, rows:])                 # rows beyond the window are untouched
+    dst = torch.zeros(S, 12, Cp, dtype=dt, device=cuda)
+    with torch.cuda.device(cuda):
+        hip.check(lib.cum_stream_tail_rows(dc, S, 10, Cp, hip.ptr(window), pitch, rows - 10, hip.ptr(dst), 12,
+                                           hip.stream_ptr()))
+    assert torch.equal(dst[:, :10], window[:, rows - 10:rows]) and float(dst[:, 10:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        hip.check(lib.cum_stream_tail_rows(dc, S, 10, Cp, hip.ptr(window), pitch, rows, hip.ptr(dst), 12,
+                                           hip.stream_ptr()))                # source rows out of range

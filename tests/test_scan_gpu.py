@@ -122,6 +122,54 @@ def test_scan_linearity_and_determinism_at_e8_size(cuda):
     assert rel_l2(a[0][3:4, sel], yr) < FWD_TOL
 
 
+def test_scan_properties_at_e6_size_bf16_io(cuda):
+    """BASELINE config 2 bottleneck shape (E6: B=32, D=2048, N=64, L=2499), bf16 I/O as under autocast: the
+    mid-chunk checkpoints and the LDS-parked decay factors of the backward at a length that is not a multiple of the
+    16-step chunk.  Size-independent checks: bit-reproducible forward and gradients, causality (a prefix of the input
+    gives the prefix of the output), and three channels of one clip against the float64 oracle, forward and dA."""
+    from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    g = torch.Generator(device="cuda").manual_seed(1)
+    bsz, dim, N, L = 32, 2048, 64, 2499
+    rn = lambda *s: torch.randn(*s, generator=g, device=cuda)
+    u, z = (rn(bsz, L, dim).bfloat16().transpose(1, 2) for _ in range(2))
+    delta = (0.3 * rn(bsz, L, dim)).bfloat16().transpose(1, 2)
+    A = -torch.exp(torch.log(torch.arange(1, N + 1, device=cuda).float())[None].repeat(dim, 1))
+    xd = rn(bsz, L, 2 * N)
+    Bm, Cm = xd[..., :N].transpose(1, 2), xd[..., N:].transpose(1, 2)
+    bias = 0.3 * rn(dim)
+    dout = rn(bsz, L, dim).bfloat16().transpose(1, 2)
+
+    def run():
+        leaves = [t.detach().clone().requires_grad_(True) for t in (u, delta, A)]
+        y = selective_scan_fn(leaves[0], leaves[1], leaves[2], Bm, Cm, None, z=z, delta_bias=bias, delta_softplus=True)
+        y.backward(dout)
+        return [y.detach()] + [t.grad for t in leaves]
+    a, b = run(), run()
+    for ta, tb in zip(a, b):
+        assert torch.equal(ta, tb), "scan is not bit-reproducible at the E6 size"
+    with torch.no_grad():
+        yp = selective_scan_fn(u[..., :1000], delta[..., :1000], A, Bm[..., :1000], Cm[..., :1000], None,
+                               z=z[..., :1000], delta_bias=bias, delta_softplus=True)
+    assert torch.equal(yp, a[0][..., :1000])
+    sel, clip = [5, 1024, 2040], 7
+    ur, dr = u[clip:clip + 1, sel].double().cpu(), delta[clip:clip + 1, sel].double().cpu()
+    Ar = A[sel].double().cpu().requires_grad_(True)
+    yr = M.selective_scan_ref(ur, dr, Ar, Bm[clip:clip + 1].double().cpu(), Cm[clip:clip + 1].double().cpu(), None,
+                              z=z[clip:clip + 1, sel].double().cpu(), delta_bias=bias[sel].double().cpu(),
+                              delta_softplus=True)
+    assert rel_l2(a[0][clip:clip + 1, sel].float(), yr) < 4e-3          # bf16 output rounding
+    # dA of those channels from this clip alone: run the kernel on the one-clip, three-channel problem
+    leaves = [t.detach().clone().requires_grad_(True) for t in (u[clip:clip + 1, sel].contiguous(),
+                                                                 delta[clip:clip + 1, sel].contiguous(), A[sel].clone())]
+    y1 = selective_scan_fn(leaves[0].transpose(1, 2).contiguous().transpose(1, 2), leaves[1].transpose(1, 2).contiguous().transpose(1, 2),
+                           leaves[2], Bm[clip:clip + 1], Cm[clip:clip + 1], None,
+                           z=z[clip:clip + 1, sel].transpose(1, 2).contiguous().transpose(1, 2), delta_bias=bias[sel],
+                           delta_softplus=True)
+    y1.backward(dout[clip:clip + 1, sel].transpose(1, 2).contiguous().transpose(1, 2))
+    yr.backward(dout[clip:clip + 1, sel].double().cpu())
+    assert rel_l2(leaves[2].grad, Ar.grad) < 4e-3
+
+
 @pytest.mark.parametrize("idx", range(4))
 @pytest.mark.parametrize("layout", ["bld", "bdl"])
 def test_dwconv_fwd_bwd_vs_golden(cuda, idx, layout):

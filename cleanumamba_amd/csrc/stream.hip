@@ -74,6 +74,39 @@ __global__ __launch_bounds__(256) void stream_window_store_kernel(const T *__res
   }
 }
 
+// The same update in ONE launch and in place: a workgroup owns (stream, chunk of CC channels), pulls the rows it keeps
+// into registers (<= 32 values per thread), and only after its barrier writes them back n_new rows earlier and appends
+// the fresh rows -- no other workgroup touches those addresses.
+constexpr int kShiftRegs = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void stream_window_inplace_kernel(T *__restrict__ window, const T *__restrict__ fresh,
+                                                                    int64_t pitch, int64_t fresh_pitch, int fresh_row0,
+                                                                    int rows, int n_new, int Cp, int CC) {
+  const int nchunk = (Cp + CC - 1) / CC;
+  const int64_t s = blockIdx.x / nchunk;
+  const int c0 = (blockIdx.x % nchunk) * CC;
+  const int cc = min(CC, Cp - c0);
+  const int keep = rows - n_new, total = keep * cc;
+  T *w = window + s * pitch * Cp + c0;
+  T v[kShiftRegs];
+#pragma unroll
+  for (int k = 0; k < kShiftRegs; ++k) {
+    const int e = threadIdx.x + k * 256;
+    if (e < total) v[k] = w[(int64_t)(e / cc + n_new) * Cp + e % cc];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kShiftRegs; ++k) {
+    const int e = threadIdx.x + k * 256;
+    if (e < total) w[(int64_t)(e / cc) * Cp + e % cc] = v[k];
+  }
+  const T *f = fresh + s * fresh_pitch * Cp + c0;
+  for (int e = threadIdx.x; e < n_new * cc; e += 256) {
+    const int t = keep + e / cc;
+    w[(int64_t)t * Cp + e % cc] = f[(int64_t)(t - fresh_row0) * Cp + e % cc];
+  }
+}
+
 // newest rows of a window -> compact input of the next layer's incremental step
 template <typename T>
 __global__ __launch_bounds__(256) void stream_tail_rows_kernel(const T *__restrict__ src, int64_t src_pitch, int src_row0,
@@ -102,8 +135,23 @@ extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t 
   CUM_REQUIRE(fresh_row0 >= 0 && fresh_row0 <= rows - n_new && fresh_pitch >= rows - fresh_row0,
               "stream_window_update: fresh rows out of range");
   if (streams == 0) return CUM_OK;
-  CUM_REQUIRE(window && fresh && tmp, "stream_window_update: null pointer");
+  CUM_REQUIRE(window && fresh, "stream_window_update: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  const int keep = rows - n_new;
+  if (keep <= kShiftRegs * 256) {       // in place, one launch: every workgroup's kept rows fit its registers
+    int CC = keep > 0 ? (kShiftRegs * 256) / keep : Cp;
+    CC = CC < Cp ? CC : Cp;
+    const int nchunk = (Cp + CC - 1) / CC;
+    if (dtype == CUM_BF16)
+      hipLaunchKernelGGL(stream_window_inplace_kernel<__bf16>, dim3(streams * nchunk), dim3(256), 0, st, (__bf16 *)window,
+                         (const __bf16 *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cp, CC);
+    else
+      hipLaunchKernelGGL(stream_window_inplace_kernel<float>, dim3(streams * nchunk), dim3(256), 0, st, (float *)window,
+                         (const float *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cp, CC);
+    CUM_CHECK_LAUNCH();
+    return CUM_OK;
+  }
+  CUM_REQUIRE(tmp, "stream_window_update: windows of more than 8192 kept rows need the scratch buffer");
   const int64_t total = (int64_t)streams * rows * Cp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (dtype == CUM_BF16) {

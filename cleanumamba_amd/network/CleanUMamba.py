@@ -166,9 +166,18 @@ class CleanUMamba(nn.Module):
         return self.stride ** self.encoder_n_layers
 
     # ------------------------------------------------------------------- forward
-    def _bottleneck(self, x, inference_params=None):
+    @staticmethod
+    def _pointwise_linear(conv, x):
+        """A 1x1 Conv1d as a matmul over (B*T, C): for the one-column inputs of a streaming hop MIOpen falls back
+        to a naive kernel (23 us against 6 us).  Module hooks on ``conv`` do not fire on this route."""
+        return F.linear(x.transpose(1, 2), conv.weight.squeeze(-1), conv.bias).transpose(1, 2)
+
+    def _bottleneck(self, x, inference_params=None, pointwise_as_linear=False):
         """tsfm_conv1 -> Mamba blocks -> add + norm_f -> tsfm_conv2.  x: (B, C, T)."""
-        x = self.tsfm_conv1(x)
+        if pointwise_as_linear:
+            x = self._pointwise_linear(self.tsfm_conv1, x)
+        else:
+            x = self.tsfm_conv1(x)
         hidden_states = x.permute(0, 2, 1)
         residual = None
         for layer in self.tsfm_Mamba_layers:
@@ -179,6 +188,8 @@ class CleanUMamba(nn.Module):
             residual = (hidden_states + residual) if residual is not None else hidden_states
             hidden_states = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
         tsfm_out = hidden_states.permute(0, 2, 1)
+        if pointwise_as_linear:
+            return self._pointwise_linear(self.tsfm_conv2, tsfm_out), tsfm_out
         return self.tsfm_conv2(tsfm_out), tsfm_out
 
     def forward(self, noisy_audio, return_skip_connections=False):
@@ -483,11 +494,10 @@ class CleanUMamba(nn.Module):
                 g_cm, g_co = cs.Geo(S, n_new, g_mid.C), cs.Geo(S, n_new, g_out.C)
                 y1 = cs._conv_relu_fwd(xin, enc[0].weight, enc[0].bias, g_cin, g_cm)
                 fresh, _ = cs._glu_fwd(y1, enc[2].weight, enc[2].bias, g_cm, g_co, False)
-                tmp = torch.empty(S * g_out.T * g_out.Cp, dtype=dt, device=dev)
-                with torch.cuda.device(dev):
+                with torch.cuda.device(dev):        # in place, one launch (windows are far below 8192 kept rows)
                     hip.check(lib.cum_stream_window_update(dc, S, g_out.T, n_new, g_out.Cp, hip.ptr(window[1:]),
                                                            hip.ptr(fresh[1:]), g_out.P, g_co.P, g_out.T - n_new,
-                                                           hip.ptr(tmp), hip.stream_ptr()))
+                                                           None, hip.stream_ptr()))
             else:
                 y1 = cs._conv_relu_fwd(buf, enc[0].weight, enc[0].bias, geo, g_mid)
                 fresh, _ = cs._glu_fwd(y1, enc[2].weight, enc[2].bias, g_mid, g_out, False)
@@ -499,15 +509,15 @@ class CleanUMamba(nn.Module):
                     t_in = self.stride * n_new + self.kernel_size - self.stride
                     state[f"encin{i}"] = cs.Geo(S, t_in, geo.C).new(dt, dev, zero=True)
                 else:
-                    tmp = torch.empty(S * g_out.T * g_out.Cp, dtype=dt, device=dev)
                     with torch.cuda.device(dev):
                         hip.check(lib.cum_stream_window_update(dc, S, g_out.T, n_new, g_out.Cp, hip.ptr(window[1:]),
-                                                               hip.ptr(fresh[1:]), g_out.P, g_out.P, 0, hip.ptr(tmp),
+                                                               hip.ptr(fresh[1:]), g_out.P, g_out.P, 0, None,
                                                                hip.stream_ptr()))
             enc_geos.append((geo, g_mid, g_out))
             outs.append(window)
             buf, geo = window, g_out
-        x, _ = self._bottleneck(cs.from_rows(outs[-1], geo).float(), inference_params=self.inference_params)   # (S, C, 1)
+        x, _ = self._bottleneck(cs.from_rows(outs[-1], geo).float(), inference_params=self.inference_params,
+                                pointwise_as_linear=True)                                                     # (S, C, 1)
         L = x.shape[-1]
         x = x + cs.from_rows(outs[-1], geo)[..., :L].float()
         g_in = cs.Geo(S, L, x.shape[1])

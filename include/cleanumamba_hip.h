@@ -303,7 +303,9 @@ int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t rows, int32_
 /* Streaming encoder window of one layer (per-layer caches of _denoise_frame, :425-447): for every stream drop the n_new
  * oldest of `rows` rows and append n_new rows of `fresh`: window row t >= rows - n_new takes fresh row t - fresh_row0
  * (fresh_row0 = 0: `fresh` is a whole recomputed window; fresh_row0 = rows - n_new: `fresh` holds only the new rows).
- * window / fresh: stream s starts `pitch` / `fresh_pitch` rows after stream s-1; tmp: streams * rows * Cp elements. */
+ * window / fresh: stream s starts `pitch` / `fresh_pitch` rows after stream s-1 (fresh must not alias window).  One
+ * in-place launch when rows - n_new <= 8192; longer windows go through tmp (streams * rows * Cp elements, else
+ * it may be NULL). */
 int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t rows, int32_t n_new, int32_t Cp, void *window,
                              const void *fresh, int64_t pitch, int64_t fresh_pitch, int32_t fresh_row0, void *tmp,
                              void *stream);

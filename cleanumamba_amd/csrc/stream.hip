@@ -1,7 +1,7 @@
 // Streaming decoder glue (reference: CleanUMamba._denoise_frame, src/network/CleanUMamba.py:476-488, with the skip
 // order fixed as SURVEY fact 9 describes).  Per hop and decoder layer the transposed conv of a frame yields 2L + 2
 // time steps per stream; the first `stride` = 2 overlap the previous frame's tail, the last 2 are this frame's tail
-// for the next hop.  One kernel does what the reference spells as slice / add / cat / clone / relu / add-skip:
+// for the next hop.  One kernel (one launch) does what the reference spells as slice / add / cat / clone / relu / add-skip:
 //   out[s][t]  = act( y[s][t] + (t < 2 ? tail[s][t] : 0) ) + skip[s][t]          t < 2L
 //   tail[s][t] = y[s][2L + t] - bias                                               t < 2   (bias re-added next hop)
 // on channels-last row buffers (csrc/gemm.hip layout), S streams in lock-step.
@@ -23,26 +23,18 @@ __global__ __launch_bounds__(256) void stream_overlap_add_kernel(const T *__rest
     const int64_t s = r / (L2 + 2);
     const float v = (float)y[(s * y_pitch + t) * Cp + c];
     if (t < L2) {
-      float o = v + (t < 2 ? (float)tail[(s * 2 + t) * Cp + c] : 0.f);
+      float o = v;
+      if (t < 2) {
+        // the thread that consumes the old tail element also replaces it (rows L2, L2 + 1 of this frame, bias taken
+        // out because the next frame's transposed conv adds it again): no other thread touches tail[s][t][c]
+        o += (float)tail[(s * 2 + t) * Cp + c];
+        const float b = (bias && c < C) ? bias[c] : 0.f;
+        tail[(s * 2 + t) * Cp + c] = (T)(c < C ? (float)y[(s * y_pitch + L2 + t) * Cp + c] - b : 0.f);
+      }
       if (relu) o = fmaxf(o, 0.f);
       if (skip) o += (float)skip[(s * skip_pitch + t) * Cp + c];
       out[(s * out_pitch + t) * Cp + c] = (T)(c < C ? o : 0.f);
     }
-  }
-}
-
-// new tails from rows L2, L2 + 1; launched after the kernel above (stream order), which read the old tails
-template <typename T>
-__global__ __launch_bounds__(256) void stream_tail_kernel(const T *__restrict__ y, int64_t y_pitch, T *__restrict__ tail,
-                                                          const float *__restrict__ bias, int streams, int L2, int Cp,
-                                                          int C) {
-  const int64_t total = (int64_t)streams * 2 * Cp;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = i % Cp;
-    const int t = (i / Cp) % 2;
-    const int64_t s = i / (2 * Cp);
-    const float b = (bias && c < C) ? bias[c] : 0.f;
-    tail[i] = (T)(c < C ? (float)y[(s * y_pitch + L2 + t) * Cp + c] - b : 0.f);
   }
 }
 
@@ -199,20 +191,14 @@ extern "C" int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)streams * (L2 + 2) * Cp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  const int64_t ttotal = (int64_t)streams * 2 * Cp;
-  const int tblocks = (int)((ttotal + 255) / 256 < 1024 ? (ttotal + 255) / 256 : 1024);
   if (dtype == CUM_BF16) {
     hipLaunchKernelGGL(stream_overlap_add_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)y, y_pitch,
                        (__bf16 *)tail, bias, (const __bf16 *)skip, skip_pitch, (__bf16 *)out, out_pitch, streams, L2, Cp, C,
                        relu);
-    hipLaunchKernelGGL(stream_tail_kernel<__bf16>, dim3(tblocks), dim3(256), 0, st, (const __bf16 *)y, y_pitch,
-                       (__bf16 *)tail, bias, streams, L2, Cp, C);
   } else {
     hipLaunchKernelGGL(stream_overlap_add_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)y, y_pitch,
                        (float *)tail, bias, (const float *)skip, skip_pitch, (float *)out, out_pitch, streams, L2, Cp, C,
                        relu);
-    hipLaunchKernelGGL(stream_tail_kernel<float>, dim3(tblocks), dim3(256), 0, st, (const float *)y, y_pitch,
-                       (float *)tail, bias, streams, L2, Cp, C);
   }
   CUM_CHECK_LAUNCH();
   return CUM_OK;

@@ -173,6 +173,19 @@ class Mamba(nn.Module):
             ssm_state.copy_(last_state)
         return _proj(y.transpose(1, 2), self.out_proj.weight, self.out_proj.bias)
 
+    def _neg_exp_A_log(self):
+        """A = -exp(A_log); in inference (no grad) it is computed once per value of A_log instead of once per token
+        (two tiny kernels per block and hop of the streaming path)."""
+        if torch.is_grad_enabled() and self.A_log.requires_grad:
+            return -torch.exp(self.A_log.float())
+        key = (self.A_log._version, self.A_log.data_ptr(), self.A_log.device)
+        hit = self.__dict__.get("_A_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, -torch.exp(self.A_log.float()))
+            self.__dict__["_A_cache"] = hit
+        return hit[1]
+
     def step(self, hidden_states, conv_state, ssm_state):
         """One token for every stream.  hidden_states: (B, 1, d_model); states updated in place."""
         assert hidden_states.shape[1] == 1, "step() decodes one token at a time"
@@ -185,7 +198,7 @@ class Mamba(nn.Module):
         x_db = F.linear(x, self.x_proj.weight)
         dt, Bv, Cv = torch.split(x_db, [dt_rank, d_state, d_state], dim=-1)
         dt = F.linear(dt, self.dt_proj.weight)
-        A = -torch.exp(self.A_log.float())
+        A = self._neg_exp_A_log()
         y = selective_state_update(ssm_state, x, dt.float(), A, Bv, Cv, self.D.float(), z=z.float(),
                                    dt_bias=self.dt_proj.bias.float(), dt_softplus=True)
         out = F.linear(y.to(hidden_states.dtype), self.out_proj.weight, self.out_proj.bias)

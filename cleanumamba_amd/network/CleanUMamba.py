@@ -532,9 +532,13 @@ class CleanUMamba(nn.Module):
             if tail is None:                       # first hop of the stream: nothing to overlap with
                 tail = state[f"dec{j}"] = torch.zeros(S, 2, g_ct.Cp, dtype=dt, device=dev)
             g_next = cs.Geo(S, 2 * L, g_ct.C)
-            nbuf = state.get(f"decbuf{j}")       # persistent: the kernel rewrites every data row, the framing rows stay zero
+            # persistent between hops (the kernel rewrites every data row, the framing rows stay zero) -- except the
+            # last layer's, which is handed to the caller
+            nbuf = None if last else state.get(f"decbuf{j}")
             if nbuf is None or nbuf.dtype != dt:
-                nbuf = state[f"decbuf{j}"] = g_next.new(dt, dev, zero=True)
+                nbuf = g_next.new(dt, dev, zero=True)
+                if not last:
+                    state[f"decbuf{j}"] = nbuf
             skip, skip_pitch = None, 0
             if not last:
                 sbuf, g_skip = outs[E - 2 - j], enc_geos[E - 2 - j][2]

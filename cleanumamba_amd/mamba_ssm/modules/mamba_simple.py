@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import hip
 from ..ops import layernorm as _ln
 from ..ops.selective_scan_interface import selective_scan_fn, selective_state_update
 
@@ -79,6 +80,7 @@ class _SplitXZ(torch.autograd.Function):
 
 
 _PROJ_TN = os.environ.get("CUM_PROJ_TN", "1") != "0"      # "0": plain F.linear everywhere (A/B timing)
+_FUSED_STEP = os.environ.get("CUM_FUSED_STEP", "1") != "0"  # "0": Block + Mamba.step as separate small kernels
 
 
 def _proj(x, w, bias=None):
@@ -237,7 +239,45 @@ class Block(nn.Module):
         self.mixer = mixer_cls(dim)
         self.norm = norm_cls(dim)
 
+    def _fused_step_ok(self, hidden_states, residual, inference_params):
+        m = self.mixer
+        if not (_FUSED_STEP and inference_params is not None and inference_params.seqlen_offset > 0
+                and hidden_states.is_cuda and hidden_states.shape[1] == 1 and hidden_states.dtype == torch.float32
+                and not torch.is_grad_enabled() and isinstance(m, Mamba) and isinstance(self.norm, nn.LayerNorm)
+                and self.norm.elementwise_affine and m.in_proj.weight.dtype == torch.float32
+                and m.activation in ("silu", "swish") and (residual is None or residual.dtype == torch.float32)):
+            return False
+        d_inner, dt_rank = m.in_proj.weight.shape[0] // 2, m.dt_proj.weight.shape[1]
+        d_state = (m.x_proj.weight.shape[0] - dt_rank) // 2
+        return bool(hip.lib().cum_mamba_step_supported(hidden_states.shape[-1], d_inner, d_state, dt_rank,
+                                                       m.conv1d.weight.shape[-1]))
+
+    def _fused_step(self, hidden_states, residual, inference_params):
+        """Block.forward + Mamba.step for one token of every stream in one launch (csrc/mamba_step.hip)."""
+        m = self.mixer
+        bsz, _, dm = hidden_states.shape
+        conv_state, ssm_state = m._get_states_from_cache(inference_params, bsz)
+        d_inner, dt_rank = m.in_proj.weight.shape[0] // 2, m.dt_proj.weight.shape[1]
+        d_state = (m.x_proj.weight.shape[0] - dt_rank) // 2
+        d_conv = m.conv1d.weight.shape[-1]
+        h = hidden_states.reshape(bsz, dm).contiguous()
+        r = None if residual is None else residual.reshape(bsz, dm).contiguous()
+        out, res_out = torch.empty_like(h), torch.empty_like(h)
+        c = lambda t: None if t is None else t.detach().contiguous()
+        with torch.cuda.device(h.device):
+            hip.check(hip.lib().cum_mamba_step(
+                bsz, dm, d_inner, d_state, dt_rank, d_conv, float(self.norm.eps), hip.ptr(h), hip.ptr(r),
+                hip.ptr(c(self.norm.weight)), hip.ptr(c(self.norm.bias)), hip.ptr(c(m.in_proj.weight)),
+                hip.ptr(c(m.in_proj.bias)), hip.ptr(conv_state), hip.ptr(c(m.conv1d.weight).view(d_inner, d_conv)),
+                hip.ptr(c(m.conv1d.bias)), hip.ptr(c(m.x_proj.weight)), hip.ptr(c(m.dt_proj.weight)),
+                hip.ptr(c(m.dt_proj.bias)), hip.ptr(m._neg_exp_A_log()), hip.ptr(c(m.D)), hip.ptr(ssm_state),
+                hip.ptr(c(m.out_proj.weight)), hip.ptr(c(m.out_proj.bias)), hip.ptr(out), hip.ptr(res_out),
+                hip.stream_ptr()))
+        return out.view(bsz, 1, dm), res_out.view(bsz, 1, dm)
+
     def forward(self, hidden_states, residual=None, inference_params=None):
+        if self._fused_step_ok(hidden_states, residual, inference_params):
+            return self._fused_step(hidden_states, residual, inference_params)
         if self.residual_in_fp32 and _ln.supported(hidden_states, self.norm):
             # add + LayerNorm in one kernel each way (csrc/layernorm.hip); same arithmetic as the three lines below
             hidden_states, residual = _ln.add_layer_norm(hidden_states, residual, self.norm)

@@ -294,6 +294,22 @@ int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t rows, int32_
                           const float *weight, float *dx32, void *dxh, float *dweight, float *dbias, float *workspace,
                           void *stream);
 
+/* ---- one Mamba block for one token of every stream in ONE launch (Block.forward + Mamba.step of the streaming path,
+ * src/network/CleanUMamba.py:451-454): residual_out = hidden_in (+ residual_in); h = LayerNorm(residual_out);
+ * xz = in_proj h; x = silu(conv_update(x)); (dt, B, C) = x_proj x; dt = softplus(dt_proj dt + dt_bias);
+ * state = exp(dt A) state + dt B x; y = (C . state + D x) silu(z); hidden_out = out_proj y.  All tensors f32 and
+ * contiguous: hidden / residual [streams][d_model], conv_state [streams][d_inner][d_conv] and ssm_state
+ * [streams][d_inner][d_state] updated in place, A = -exp(A_log) [d_inner][d_state].  Optional (NULL): residual_in,
+ * norm_b, in_proj_b, conv_b, dt_proj_b, D, out_proj_b.  For small (pruned) models: every stream's workgroup re-reads
+ * the projection matrices from L2 -- cum_mamba_step_supported() tells whether the sizes qualify. */
+int cum_mamba_step_supported(int32_t d_model, int32_t d_inner, int32_t d_state, int32_t dt_rank, int32_t d_conv);
+int cum_mamba_step(int32_t streams, int32_t d_model, int32_t d_inner, int32_t d_state, int32_t dt_rank, int32_t d_conv,
+                   float eps, const float *hidden_in, const float *residual_in, const float *norm_w,
+                   const float *norm_b, const float *in_proj_w, const float *in_proj_b, float *conv_state,
+                   const float *conv_w, const float *conv_b, const float *x_proj_w, const float *dt_proj_w,
+                   const float *dt_proj_b, const float *A, const float *D, float *ssm_state, const float *out_proj_w,
+                   const float *out_proj_b, float *hidden_out, float *residual_out, void *stream);
+
 /* ---- streaming decoder glue (CleanUMamba._denoise_frame, src/network/CleanUMamba.py:476-488): overlap-add of a frame's
  * transposed-conv output with the previous frame's tail, activation, skip add and tail update for S streams in
  * lock-step, channels-last rows of Cp (C real channels):

@@ -249,3 +249,50 @@ def test_backward_paths_agree(cuda, name, pruned):
         assert rel_l2(grads[0][k], grads[1][k]) < 1e-4, k
     flat = lambda g: torch.cat([g[k].reshape(-1) for k in conv_keys])
     assert rel_l2(flat(grads[0]), flat(grads[2])) < 3e-2
+
+
+@pytest.mark.parametrize("dims", [(114, 8, 8, 32), (114, 48, 8, 32), (96, 40, 13, 5)])
+def test_fused_mamba_step_equals_separate_kernels(cuda, dims, monkeypatch):
+    """cum_mamba_step (Block.forward + Mamba.step in one launch, pruned-model sizes) against the same block run as
+    separate kernels: outputs, residual stream, conv and SSM states after three tokens (f32, 1e-5)."""
+    from cleanumamba_amd.mamba_ssm.models.mixer_seq_simple import create_block
+    from cleanumamba_amd.mamba_ssm.modules import mamba_simple as MS
+    from cleanumamba_amd.mamba_ssm.utils.generation import InferenceParams
+    d_model, d_inner, d_state, dt_rank = dims
+    torch.manual_seed(d_inner)
+    blk = create_block(d_model, ssm_cfg={"d_state": d_state, "expand": 1, "dt_rank": dt_rank}, norm_epsilon=1e-5,
+                       rms_norm=False, residual_in_fp32=True, fused_add_norm=False, layer_idx=0, device=cuda,
+                       dtype=torch.float32).eval()
+    m = blk.mixer
+    # resize the inner width the way pruning does (expand = 1 gives d_inner = d_model)
+    with torch.no_grad():
+        m.in_proj.weight = torch.nn.Parameter(torch.randn(2 * d_inner, d_model, device=cuda) / d_model ** 0.5)
+        m.conv1d.weight = torch.nn.Parameter(torch.randn(d_inner, 1, 4, device=cuda) * 0.5)
+        m.conv1d.bias = torch.nn.Parameter(torch.randn(d_inner, device=cuda) * 0.1)
+        m.x_proj.weight = torch.nn.Parameter(torch.randn(dt_rank + 2 * d_state, d_inner, device=cuda) / d_inner ** 0.5)
+        m.dt_proj.weight = torch.nn.Parameter(torch.randn(d_inner, dt_rank, device=cuda) / dt_rank ** 0.5)
+        m.dt_proj.bias = torch.nn.Parameter(torch.randn(d_inner, device=cuda) * 0.5)
+        m.A_log = torch.nn.Parameter(torch.randn(d_inner, d_state, device=cuda) * 0.5)
+        m.D = torch.nn.Parameter(torch.randn(d_inner, device=cuda))
+        m.out_proj.weight = torch.nn.Parameter(torch.randn(d_model, d_inner, device=cuda) / d_inner ** 0.5)
+        blk.norm.weight.normal_(1.0, 0.2)
+        blk.norm.bias.normal_(0.0, 0.2)
+    S = 37
+    toks = [torch.randn(S, 1, d_model, device=cuda) for _ in range(3)]
+    res0 = torch.randn(S, 1, d_model, device=cuda)
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(MS, "_FUSED_STEP", fused)
+        ip = InferenceParams(max_seqlen=8, max_batch_size=S)
+        conv_state, ssm_state = m._get_states_from_cache(ip, S, initialize_states=True)
+        conv_state.copy_(torch.randn(conv_state.shape, generator=torch.Generator().manual_seed(1)).to(cuda))
+        ssm_state.copy_(torch.randn(ssm_state.shape, generator=torch.Generator().manual_seed(2)).to(cuda))
+        ip.seqlen_offset = 1
+        outs, res = [], res0
+        with torch.no_grad():
+            for t in toks:
+                h, res = blk(t, res, inference_params=ip)
+                outs.append(h)
+        got[fused] = (torch.cat(outs, 1), res, conv_state.clone(), ssm_state.clone())
+    for a, b, name in zip(got[True], got[False], ("hidden", "residual", "conv_state", "ssm_state")):
+        assert a.shape == b.shape and rel_l2(a, b) < 1e-5, name

@@ -73,7 +73,8 @@ constexpr int kShiftRegs = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void stream_window_inplace_kernel(T *__restrict__ window, const T *__restrict__ fresh,
                                                                     int64_t pitch, int64_t fresh_pitch, int fresh_row0,
-                                                                    int rows, int n_new, int Cp, int CC) {
+                                                                    int rows, int n_new, int Cp, int CC,
+                                                                    T *__restrict__ tail_dst, int64_t tail_pitch) {
   const int nchunk = (Cp + CC - 1) / CC;
   const int64_t s = blockIdx.x / nchunk;
   const int c0 = (blockIdx.x % nchunk) * CC;
@@ -93,9 +94,22 @@ __global__ __launch_bounds__(256) void stream_window_inplace_kernel(T *__restric
     if (e < total) w[(int64_t)(e / cc) * Cp + e % cc] = v[k];
   }
   const T *f = fresh + s * fresh_pitch * Cp + c0;
+  // tail_dst: the n_new + 2 newest rows of the updated window as a compact clip buffer = the next layer's input of an
+  // incremental hop (two carried rows + the new ones), written here instead of by a separate launch
+  T *td = tail_dst ? tail_dst + s * tail_pitch * Cp + c0 : nullptr;
   for (int e = threadIdx.x; e < n_new * cc; e += 256) {
     const int t = keep + e / cc;
-    w[(int64_t)t * Cp + e % cc] = f[(int64_t)(t - fresh_row0) * Cp + e % cc];
+    const T v_new = f[(int64_t)(t - fresh_row0) * Cp + e % cc];
+    w[(int64_t)t * Cp + e % cc] = v_new;
+    if (td) td[(int64_t)(t - keep + 2) * Cp + e % cc] = v_new;
+  }
+  if (td) {
+    // carried rows = rows keep - 2, keep - 1 of the updated window = old rows rows - 2, rows - 1 (still in registers)
+#pragma unroll
+    for (int k = 0; k < kShiftRegs; ++k) {
+      const int e = threadIdx.x + k * 256;
+      if (e < total && e / cc >= keep - 2) td[(int64_t)(e / cc - (keep - 2)) * Cp + e % cc] = v[k];
+    }
   }
 }
 
@@ -120,7 +134,8 @@ using namespace cum;
 
 extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t rows, int32_t n_new, int32_t Cp,
                                         void *window, const void *fresh, int64_t pitch, int64_t fresh_pitch,
-                                        int32_t fresh_row0, void *tmp, void *stream) {
+                                        int32_t fresh_row0, void *tmp, void *tail_dst, int64_t tail_pitch,
+                                        void *stream) {
   CUM_REQUIRE(dtype == CUM_F32 || dtype == CUM_BF16, "stream_window_update: dtype must be CUM_F32 or CUM_BF16");
   CUM_REQUIRE(streams >= 0 && rows > 0 && n_new > 0 && n_new <= rows && Cp > 0 && pitch >= rows,
               "stream_window_update: bad shape");
@@ -130,16 +145,20 @@ extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t 
   CUM_REQUIRE(window && fresh, "stream_window_update: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int keep = rows - n_new;
+  CUM_REQUIRE(!tail_dst || (keep >= 2 && keep <= kShiftRegs * 256 && tail_pitch >= n_new + 2),
+              "stream_window_update: tail_dst needs the in-place path and two carried rows");
   if (keep <= kShiftRegs * 256) {       // in place, one launch: every workgroup's kept rows fit its registers
     int CC = keep > 0 ? (kShiftRegs * 256) / keep : Cp;
     CC = CC < Cp ? CC : Cp;
     const int nchunk = (Cp + CC - 1) / CC;
     if (dtype == CUM_BF16)
       hipLaunchKernelGGL(stream_window_inplace_kernel<__bf16>, dim3(streams * nchunk), dim3(256), 0, st, (__bf16 *)window,
-                         (const __bf16 *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cp, CC);
+                         (const __bf16 *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cp, CC, (__bf16 *)tail_dst,
+                         tail_pitch);
     else
       hipLaunchKernelGGL(stream_window_inplace_kernel<float>, dim3(streams * nchunk), dim3(256), 0, st, (float *)window,
-                         (const float *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cp, CC);
+                         (const float *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cp, CC, (float *)tail_dst,
+                         tail_pitch);
     CUM_CHECK_LAUNCH();
     return CUM_OK;
   }

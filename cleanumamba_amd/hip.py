@@ -86,7 +86,7 @@ SIGNATURES = {
     "cum_add_layernorm_bwd": (c_i32, [c_i32, c_i32, c_i64, c_i32] + [_P] * 12),
     "cum_mamba_step_supported": (c_i32, [c_i32] * 5),
     "cum_mamba_step": (c_i32, [c_i32] * 6 + [ctypes.c_float] + [_P] * 20),
-    "cum_stream_window_update": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, c_i64, c_i64, c_i32, _P, _P]),
+    "cum_stream_window_update": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, c_i64, c_i64, c_i32, _P, _P, c_i64, _P]),
     "cum_stream_tail_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, _P, c_i64, c_i32, _P, c_i64, _P]),
     "cum_stream_overlap_add": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i64, _P, c_i64, c_i32, _P]),
     "cum_rfft": (c_i32, [c_i32, c_i64, _P, _P, _P]),

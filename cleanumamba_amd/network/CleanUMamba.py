@@ -487,17 +487,16 @@ class CleanUMamba(nn.Module):
                     xin = state[f"encin{i}"] = g_cin.new(dt, dev, zero=True)
                 if i == 0:
                     g_cin.rows(xin)[:, :t_in, :1] = frame[:, frame.shape[1] - t_in:].unsqueeze(-1).to(dt)
-                else:
-                    with torch.cuda.device(dev):
-                        hip.check(lib.cum_stream_tail_rows(dc, S, t_in, geo.Cp, hip.ptr(buf[1:]), geo.P, geo.T - t_in,
-                                                           hip.ptr(xin[1:]), g_cin.P, hip.stream_ptr()))
+                # (deeper layers: the window update of the layer below has already written xin)
                 g_cm, g_co = cs.Geo(S, n_new, g_mid.C), cs.Geo(S, n_new, g_out.C)
                 y1 = cs._conv_relu_fwd(xin, enc[0].weight, enc[0].bias, g_cin, g_cm)
                 fresh, _ = cs._glu_fwd(y1, enc[2].weight, enc[2].bias, g_cm, g_co, False)
+                nxt = state.get(f"encin{i + 1}")   # the next layer's compact input: 2 carried rows + the new ones
                 with torch.cuda.device(dev):        # in place, one launch (windows are far below 8192 kept rows)
                     hip.check(lib.cum_stream_window_update(dc, S, g_out.T, n_new, g_out.Cp, hip.ptr(window[1:]),
                                                            hip.ptr(fresh[1:]), g_out.P, g_co.P, g_out.T - n_new,
-                                                           None, hip.stream_ptr()))
+                                                           None, None if nxt is None else hip.ptr(nxt[1:]),
+                                                           n_new + 4, hip.stream_ptr()))
             else:
                 y1 = cs._conv_relu_fwd(buf, enc[0].weight, enc[0].bias, geo, g_mid)
                 fresh, _ = cs._glu_fwd(y1, enc[2].weight, enc[2].bias, g_mid, g_out, False)
@@ -511,7 +510,7 @@ class CleanUMamba(nn.Module):
                 else:
                     with torch.cuda.device(dev):
                         hip.check(lib.cum_stream_window_update(dc, S, g_out.T, n_new, g_out.Cp, hip.ptr(window[1:]),
-                                                               hip.ptr(fresh[1:]), g_out.P, g_out.P, 0, None,
+                                                               hip.ptr(fresh[1:]), g_out.P, g_out.P, 0, None, None, 0,
                                                                hip.stream_ptr()))
             enc_geos.append((geo, g_mid, g_out))
             outs.append(window)

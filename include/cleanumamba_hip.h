@@ -321,10 +321,11 @@ int cum_mamba_step(int32_t streams, int32_t d_model, int32_t d_inner, int32_t d_
  * (fresh_row0 = 0: `fresh` is a whole recomputed window; fresh_row0 = rows - n_new: `fresh` holds only the new rows).
  * window / fresh: stream s starts `pitch` / `fresh_pitch` rows after stream s-1 (fresh must not alias window).  One
  * in-place launch when rows - n_new <= 8192; longer windows go through tmp (streams * rows * Cp elements, else
- * it may be NULL). */
+ * it may be NULL).  tail_dst (optional, in-place path only): also receives the n_new + 2 newest rows of the updated
+ * window, stream s at row s * tail_pitch -- what cum_stream_tail_rows would copy for the next layer. */
 int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t rows, int32_t n_new, int32_t Cp, void *window,
                              const void *fresh, int64_t pitch, int64_t fresh_pitch, int32_t fresh_row0, void *tmp,
-                             void *stream);
+                             void *tail_dst, int64_t tail_pitch, void *stream);
 /* Input of the next layer's incremental step: dst[s][t] = src[s][src_row0 + t] for t < rows (the newest rows of a
  * window: 2 carried rows + the hop's new rows); rows of dst beyond `rows` are not touched (they stay zero). */
 int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows, int32_t Cp, const void *src, int64_t src_pitch,

@@ -73,11 +73,15 @@ def test_stream_window_update_and_tail_rows(cuda, dt):
         fresh = full[:, rows - n_new:rows].contiguous() if compact else full
         tmp = torch.empty(S * rows * Cp, dtype=dt, device=cuda)
         with torch.cuda.device(cuda):
+            nxt = torch.zeros(S, n_new + 4, Cp, dtype=dt, device=cuda)
             hip.check(lib.cum_stream_window_update(dc, S, rows, n_new, Cp, hip.ptr(w), hip.ptr(fresh), pitch,
                                                    n_new if compact else pitch, rows - n_new if compact else 0,
-                                                   hip.ptr(tmp), hip.stream_ptr()))
+                                                   hip.ptr(tmp), hip.ptr(nxt) if compact else None, n_new + 4,
+                                                   hip.stream_ptr()))
         assert torch.equal(w[:, :rows], want)
         assert torch.equal(w[:, rows:], window[:, rows:])                 # rows beyond the window are untouched
+        if compact:       # the next layer's compact input: the n_new + 2 newest rows of the updated window
+            assert torch.equal(nxt[:, :n_new + 2], want[:, rows - n_new - 2:]) and float(nxt[:, n_new + 2:].abs().max()) == 0
     dst = torch.zeros(S, 12, Cp, dtype=dt, device=cuda)
     with torch.cuda.device(cuda):
         hip.check(lib.cum_stream_tail_rows(dc, S, 10, Cp, hip.ptr(window), pitch, rows - 10, hip.ptr(dst), 12,

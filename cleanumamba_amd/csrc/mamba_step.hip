@@ -45,7 +45,35 @@ __device__ __forceinline__ void matvec(const float *__restrict__ W, const float 
   }
 }
 
+// Small matrices (rows * (cols + 1) <= kStepStage floats): stage W into LDS with coalesced reads (row pitch cols + 1:
+// conflict-free column walks), then one thread per output row -- two barriers instead of rows / 4 dependent
+// load -> shuffle-reduce rounds per wave.  Larger ones keep the wave-per-row form.  Ends with a barrier either way.
+constexpr int kStepStage = 12288;
+__device__ __forceinline__ void matvec_small(const float *__restrict__ W, const float *__restrict__ bias, const float *vec,
+                                             float *out, int rows, int cols, float *s_w, int tid, int wave, int lane) {
+  if (rows * (cols + 1) <= kStepStage) {
+    const int total = rows * cols;
+    for (int e = tid; e < total; e += 256) s_w[(e / cols) * (cols + 1) + e % cols] = W[e];
+    __syncthreads();
+    for (int j = tid; j < rows; j += 256) {
+      const float *w = s_w + j * (cols + 1);
+      float a0 = bias ? bias[j] : 0.f, a1 = 0.f;
+      int k = 0;
+      for (; k + 1 < cols; k += 2) {
+        a0 = fmaf(w[k], vec[k], a0);
+        a1 = fmaf(w[k + 1], vec[k + 1], a1);
+      }
+      if (k < cols) a0 = fmaf(w[k], vec[k], a0);
+      out[j] = a0 + a1;
+    }
+  } else {
+    matvec(W, bias, vec, out, rows, cols, wave, lane, 4);
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void mamba_step_kernel(const StepParams p) {
+  __shared__ float s_w[kStepStage];
   __shared__ float s_h[kStepMaxModel];            // normed hidden, later reused for nothing else
   __shared__ float s_xz[2 * kStepMaxInner];
   __shared__ float s_x[kStepMaxInner];
@@ -85,8 +113,7 @@ __global__ __launch_bounds__(256) void mamba_step_kernel(const StepParams p) {
   __syncthreads();
 
   // ---- in_proj: xz = W_in h
-  matvec(p.in_w, p.in_b, s_h, s_xz, 2 * di, dm, wave, lane, 4);
-  __syncthreads();
+  matvec_small(p.in_w, p.in_b, s_h, s_xz, 2 * di, dm, s_w, tid, wave, lane);
 
   // ---- causal conv update + SiLU (state shifted in place)
   for (int d = tid; d < di; d += 256) {
@@ -102,8 +129,7 @@ __global__ __launch_bounds__(256) void mamba_step_kernel(const StepParams p) {
   __syncthreads();
 
   // ---- x_proj -> (dt_low, B, C); dt = softplus(W_dt dt_low + b_dt)
-  matvec(p.xproj_w, nullptr, s_x, s_xdb, R + 2 * N, di, wave, lane, 4);
-  __syncthreads();
+  matvec_small(p.xproj_w, nullptr, s_x, s_xdb, R + 2 * N, di, s_w, tid, wave, lane);
   for (int d = tid; d < di; d += 256) {
     const float *w = p.dtproj_w + (int64_t)d * R;
     float acc = p.dtproj_b ? p.dtproj_b[d] : 0.f;
@@ -133,7 +159,7 @@ __global__ __launch_bounds__(256) void mamba_step_kernel(const StepParams p) {
   __syncthreads();
 
   // ---- out_proj
-  matvec(p.out_w, p.out_b, s_y, p.hidden_out + s * dm, dm, di, wave, lane, 4);
+  matvec_small(p.out_w, p.out_b, s_y, p.hidden_out + s * dm, dm, di, s_w, tid, wave, lane);
 }
 
 }  // namespace cum

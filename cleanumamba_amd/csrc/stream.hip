@@ -66,49 +66,49 @@ __global__ __launch_bounds__(256) void stream_window_store_kernel(const T *__res
   }
 }
 
-// The same update in ONE launch and in place: a workgroup owns (stream, chunk of CC channels), pulls the rows it keeps
-// into registers (<= 32 values per thread), and only after its barrier writes them back n_new rows earlier and appends
-// the fresh rows -- no other workgroup touches those addresses.
-constexpr int kShiftRegs = 32;
-template <typename T>
-__global__ __launch_bounds__(256) void stream_window_inplace_kernel(T *__restrict__ window, const T *__restrict__ fresh,
+// The same update in ONE launch and in place: a workgroup owns (stream, chunk of CC 16-byte channel vectors), pulls the
+// rows it keeps into registers (<= 8 vectors per thread), and only after its barrier writes them back n_new rows
+// earlier and appends the fresh rows -- no other workgroup touches those addresses.  Everything moves as 16-byte
+// vectors (Cp is a multiple of 8 elements).
+constexpr int kShiftRegs = 8;
+__global__ __launch_bounds__(256) void stream_window_inplace_kernel(uint4 *__restrict__ window, const uint4 *__restrict__ fresh,
                                                                     int64_t pitch, int64_t fresh_pitch, int fresh_row0,
-                                                                    int rows, int n_new, int Cp, int CC,
-                                                                    T *__restrict__ tail_dst, int64_t tail_pitch) {
-  const int nchunk = (Cp + CC - 1) / CC;
+                                                                    int rows, int n_new, int Cv, int CC,
+                                                                    uint4 *__restrict__ tail_dst, int64_t tail_pitch) {
+  const int nchunk = (Cv + CC - 1) / CC;
   const int64_t s = blockIdx.x / nchunk;
   const int c0 = (blockIdx.x % nchunk) * CC;
-  const int cc = min(CC, Cp - c0);
+  const int cc = min(CC, Cv - c0);
   const int keep = rows - n_new, total = keep * cc;
-  T *w = window + s * pitch * Cp + c0;
-  T v[kShiftRegs];
+  uint4 *w = window + s * pitch * Cv + c0;
+  uint4 v[kShiftRegs];
 #pragma unroll
   for (int k = 0; k < kShiftRegs; ++k) {
     const int e = threadIdx.x + k * 256;
-    if (e < total) v[k] = w[(int64_t)(e / cc + n_new) * Cp + e % cc];
+    if (e < total) v[k] = w[(int64_t)(e / cc + n_new) * Cv + e % cc];
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kShiftRegs; ++k) {
     const int e = threadIdx.x + k * 256;
-    if (e < total) w[(int64_t)(e / cc) * Cp + e % cc] = v[k];
+    if (e < total) w[(int64_t)(e / cc) * Cv + e % cc] = v[k];
   }
-  const T *f = fresh + s * fresh_pitch * Cp + c0;
+  const uint4 *f = fresh + s * fresh_pitch * Cv + c0;
   // tail_dst: the n_new + 2 newest rows of the updated window as a compact clip buffer = the next layer's input of an
   // incremental hop (two carried rows + the new ones), written here instead of by a separate launch
-  T *td = tail_dst ? tail_dst + s * tail_pitch * Cp + c0 : nullptr;
+  uint4 *td = tail_dst ? tail_dst + s * tail_pitch * Cv + c0 : nullptr;
   for (int e = threadIdx.x; e < n_new * cc; e += 256) {
     const int t = keep + e / cc;
-    const T v_new = f[(int64_t)(t - fresh_row0) * Cp + e % cc];
-    w[(int64_t)t * Cp + e % cc] = v_new;
-    if (td) td[(int64_t)(t - keep + 2) * Cp + e % cc] = v_new;
+    const uint4 v_new = f[(int64_t)(t - fresh_row0) * Cv + e % cc];
+    w[(int64_t)t * Cv + e % cc] = v_new;
+    if (td) td[(int64_t)(t - keep + 2) * Cv + e % cc] = v_new;
   }
   if (td) {
     // carried rows = rows keep - 2, keep - 1 of the updated window = old rows rows - 2, rows - 1 (still in registers)
 #pragma unroll
     for (int k = 0; k < kShiftRegs; ++k) {
       const int e = threadIdx.x + k * 256;
-      if (e < total && e / cc >= keep - 2) td[(int64_t)(e / cc - (keep - 2)) * Cp + e % cc] = v[k];
+      if (e < total && e / cc >= keep - 2) td[(int64_t)(e / cc - (keep - 2)) * Cv + e % cc] = v[k];
     }
   }
 }
@@ -145,24 +145,23 @@ extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t 
   CUM_REQUIRE(window && fresh, "stream_window_update: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int keep = rows - n_new;
-  CUM_REQUIRE(!tail_dst || (keep >= 2 && keep <= kShiftRegs * 256 && tail_pitch >= n_new + 2),
-              "stream_window_update: tail_dst needs the in-place path and two carried rows");
-  if (keep <= kShiftRegs * 256) {       // in place, one launch: every workgroup's kept rows fit its registers
-    int CC = keep > 0 ? (kShiftRegs * 256) / keep : Cp;
-    CC = CC < Cp ? CC : Cp;
-    const int nchunk = (Cp + CC - 1) / CC;
-    if (dtype == CUM_BF16)
-      hipLaunchKernelGGL(stream_window_inplace_kernel<__bf16>, dim3(streams * nchunk), dim3(256), 0, st, (__bf16 *)window,
-                         (const __bf16 *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cp, CC, (__bf16 *)tail_dst,
-                         tail_pitch);
-    else
-      hipLaunchKernelGGL(stream_window_inplace_kernel<float>, dim3(streams * nchunk), dim3(256), 0, st, (float *)window,
-                         (const float *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cp, CC, (float *)tail_dst,
-                         tail_pitch);
+  CUM_REQUIRE(!tail_dst || (keep >= 2 && tail_pitch >= n_new + 2), "stream_window_update: tail_dst needs two carried rows");
+  const int esz = dtype == CUM_BF16 ? 2 : 4;
+  const bool vec_ok = (Cp * esz) % 16 == 0 && ((uintptr_t)window & 15) == 0 && ((uintptr_t)fresh & 15) == 0 &&
+                      ((uintptr_t)tail_dst & 15) == 0;
+  if (keep <= kShiftRegs * 256 && vec_ok) {   // in place, one launch: every workgroup's kept rows fit its registers
+    const int Cv = Cp * esz / 16;
+    int CC = keep > 0 ? (kShiftRegs * 256) / keep : Cv;
+    CC = CC < Cv ? CC : Cv;
+    const int nchunk = (Cv + CC - 1) / CC;
+    hipLaunchKernelGGL(stream_window_inplace_kernel, dim3(streams * nchunk), dim3(256), 0, st, (uint4 *)window,
+                       (const uint4 *)fresh, pitch, fresh_pitch, fresh_row0, rows, n_new, Cv, CC, (uint4 *)tail_dst,
+                       tail_pitch);
     CUM_CHECK_LAUNCH();
     return CUM_OK;
   }
-  CUM_REQUIRE(tmp, "stream_window_update: windows of more than 8192 kept rows need the scratch buffer");
+  CUM_REQUIRE(!tail_dst, "stream_window_update: tail_dst needs the in-place path (16-byte aligned rows, <= 2048 kept rows)");
+  CUM_REQUIRE(tmp, "stream_window_update: this window needs the scratch buffer (tmp)");
   const int64_t total = (int64_t)streams * rows * Cp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (dtype == CUM_BF16) {

@@ -320,7 +320,7 @@ int cum_mamba_step(int32_t streams, int32_t d_model, int32_t d_inner, int32_t d_
  * oldest of `rows` rows and append n_new rows of `fresh`: window row t >= rows - n_new takes fresh row t - fresh_row0
  * (fresh_row0 = 0: `fresh` is a whole recomputed window; fresh_row0 = rows - n_new: `fresh` holds only the new rows).
  * window / fresh: stream s starts `pitch` / `fresh_pitch` rows after stream s-1 (fresh must not alias window).  One
- * in-place launch when rows - n_new <= 8192; longer windows go through tmp (streams * rows * Cp elements, else
+ * in-place launch when rows - n_new <= 2048 and rows are 16-byte aligned; other windows go through tmp (streams * rows * Cp elements, else
  * it may be NULL).  tail_dst (optional, in-place path only): also receives the n_new + 2 newest rows of the updated
  * window, stream s at row s * tail_pitch -- what cum_stream_tail_rows would copy for the next layer. */
 int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t rows, int32_t n_new, int32_t Cp, void *window,

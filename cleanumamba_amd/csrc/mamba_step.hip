@@ -162,9 +162,37 @@ __global__ __launch_bounds__(256) void mamba_step_kernel(const StepParams p) {
   matvec_small(p.out_w, p.out_b, s_y, p.hidden_out + s * dm, dm, di, s_w, tid, wave, lane);
 }
 
+// out[s][j] = bias[j] + sum_k W[j][k] x[s][k]: the 1x1 bottleneck convolutions of a hop on one-column inputs (a
+// library GEMM takes 25 us for a 256 x 85 x 114 problem); one workgroup per stream, W staged in LDS.
+__global__ __launch_bounds__(256) void small_linear_kernel(const float *__restrict__ x, int64_t x_stride,
+                                                           const float *__restrict__ W, const float *__restrict__ bias,
+                                                           float *__restrict__ out, int64_t out_stride, int rows,
+                                                           int cols) {
+  __shared__ float s_w[kStepStage];
+  __shared__ float s_v[kStepMaxModel];
+  const int tid = threadIdx.x;
+  const float *xv = x + blockIdx.x * x_stride;
+  for (int k = tid; k < cols; k += 256) s_v[k] = xv[k];
+  __syncthreads();
+  matvec_small(W, bias, s_v, out + blockIdx.x * out_stride, rows, cols, s_w, tid, tid >> 6, tid & 63);
+}
+
 }  // namespace cum
 
 using namespace cum;
+
+extern "C" int cum_small_linear(int32_t streams, int32_t rows, int32_t cols, const float *x, int64_t x_stride,
+                                const float *W, const float *bias, float *out, int64_t out_stride, void *stream) {
+  CUM_REQUIRE(streams >= 0 && rows >= 1 && cols >= 1 && cols <= kStepMaxModel && x_stride >= cols && out_stride >= rows,
+              "small_linear: bad shape (cols <= 1024)");
+  if (streams == 0) return CUM_OK;
+  CUM_REQUIRE(x && W && out, "small_linear: null pointer");
+  hipLaunchKernelGGL(small_linear_kernel, dim3(streams), dim3(256), 0, (hipStream_t)stream, x, x_stride, W, bias, out,
+                     out_stride, rows, cols);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
 
 extern "C" int cum_mamba_step_supported(int32_t d_model, int32_t d_inner, int32_t d_state, int32_t dt_rank,
                                         int32_t d_conv) {

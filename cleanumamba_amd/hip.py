@@ -84,6 +84,7 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P]),
     "cum_add_layernorm_bwd_workspace_elems": (c_i64, [c_i32]),
     "cum_add_layernorm_bwd": (c_i32, [c_i32, c_i32, c_i64, c_i32] + [_P] * 12),
+    "cum_small_linear": (c_i32, [c_i32, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i64, _P]),
     "cum_mamba_step_supported": (c_i32, [c_i32] * 5),
     "cum_mamba_step": (c_i32, [c_i32] * 6 + [ctypes.c_float] + [_P] * 20),
     "cum_stream_window_update": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, c_i64, c_i64, c_i32, _P, _P, c_i64, _P]),

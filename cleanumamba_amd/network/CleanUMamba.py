@@ -170,7 +170,19 @@ class CleanUMamba(nn.Module):
     def _pointwise_linear(conv, x):
         """A 1x1 Conv1d as a matmul over (B*T, C): for the one-column inputs of a streaming hop MIOpen falls back
         to a naive kernel (23 us against 6 us).  Module hooks on ``conv`` do not fire on this route."""
-        return F.linear(x.transpose(1, 2), conv.weight.squeeze(-1), conv.bias).transpose(1, 2)
+        w = conv.weight.squeeze(-1)
+        if x.is_cuda and x.shape[-1] == 1 and x.dtype == torch.float32 and w.dtype == torch.float32 \
+                and w.shape[1] <= 1024 and not torch.is_grad_enabled():
+            # one-column input: a workgroup per stream with the matrix staged in LDS (csrc/mamba_step.hip)
+            xin = x.reshape(x.shape[0], x.shape[1]).contiguous()
+            out = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                hip.check(hip.lib().cum_small_linear(x.shape[0], w.shape[0], w.shape[1], hip.ptr(xin), w.shape[1],
+                                                     hip.ptr(w.detach().contiguous()),
+                                                     hip.ptr(None if conv.bias is None else conv.bias.detach()),
+                                                     hip.ptr(out), w.shape[0], hip.stream_ptr()))
+            return out.unsqueeze(-1)
+        return F.linear(x.transpose(1, 2), w, conv.bias).transpose(1, 2)
 
     def _bottleneck(self, x, inference_params=None, pointwise_as_linear=False):
         """tsfm_conv1 -> Mamba blocks -> add + norm_f -> tsfm_conv2.  x: (B, C, T)."""

@@ -310,6 +310,12 @@ int cum_mamba_step(int32_t streams, int32_t d_model, int32_t d_inner, int32_t d_
                    const float *dt_proj_b, const float *A, const float *D, float *ssm_state, const float *out_proj_w,
                    const float *out_proj_b, float *hidden_out, float *residual_out, void *stream);
 
+/* out[s][j] = bias[j] + sum_k W[j*cols + k] * x[s*x_stride + k], f32, one workgroup per row s: the 1x1 bottleneck
+ * convolutions of a streaming hop (tsfm_conv1 / tsfm_conv2 on one-column inputs, src/network/CleanUMamba.py:277,310).
+ * cols <= 1024; bias may be NULL. */
+int cum_small_linear(int32_t streams, int32_t rows, int32_t cols, const float *x, int64_t x_stride, const float *W,
+                     const float *bias, float *out, int64_t out_stride, void *stream);
+
 /* ---- streaming decoder glue (CleanUMamba._denoise_frame, src/network/CleanUMamba.py:476-488): overlap-add of a frame's
  * transposed-conv output with the previous frame's tail, activation, skip add and tail update for S streams in
  * lock-step, channels-last rows of Cp (C real channels):

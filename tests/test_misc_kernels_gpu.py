@@ -90,3 +90,18 @@ def test_stream_window_update_and_tail_rows(cuda, dt):
     with pytest.raises(RuntimeError):
         hip.check(lib.cum_stream_tail_rows(dc, S, 10, Cp, hip.ptr(window), pitch, rows, hip.ptr(dst), 12,
                                            hip.stream_ptr()))                # source rows out of range
+
+
+@pytest.mark.parametrize("rows,cols", [(114, 85), (85, 114), (300, 1000), (7, 3)])
+def test_small_linear_matches_torch(cuda, rows, cols):
+    """cum_small_linear (one workgroup per stream; LDS-staged matrix when it is small, wave-per-row otherwise)."""
+    from cleanumamba_amd import hip
+    g = torch.Generator().manual_seed(rows)
+    x, W, b = torch.randn(37, cols, generator=g), torch.randn(rows, cols, generator=g) / cols ** 0.5, torch.randn(rows, generator=g)
+    out = torch.empty(37, rows, device=cuda)
+    xd, Wd, bd = x.to(cuda), W.to(cuda), b.to(cuda)
+    with torch.cuda.device(cuda):
+        hip.check(hip.lib().cum_small_linear(37, rows, cols, hip.ptr(xd), cols, hip.ptr(Wd), hip.ptr(bd), hip.ptr(out), rows,
+                                             hip.stream_ptr()))
+    ref = x.double() @ W.double().t() + b.double()
+    assert rel_l2(out, ref) < 1e-6

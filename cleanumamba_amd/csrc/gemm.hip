@@ -48,6 +48,7 @@ struct GemmParams {
   const void *aux2;        // gate_only GLU_BWD: the GLU output y saved by the forward [M][ldy]
   int64_t lda, ldw, ldc, ldr, ldz, ldy;
   int gate_only;           // GLU / GLU_BWD: aux holds only the gate pre-activation b ([M][ldz], output-column order)
+  int allow_split_k;       // few-tile launches may use gemm_nt_splitk_kernel
   int mask_bits;           // RELU: aux receives the SIGN (value > 0) of each element instead of the activation, four
                            // consecutive channels per byte (low nibble; byte index (m * ld + n) / 4) -- what a lane
                            // holds after the MFMA, so no cross-lane packing; MASK: res is such an array.
@@ -484,6 +485,111 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(4,
   nt_epilogue<T, EPI>(p, acc, bv, m0, n0, wm, wn, g, r);
 }
 
+// ---------------------------------------------------------------- small-M variant (streaming hops)
+// Launches with only a few dozen 128x128 tiles (M = streams x a handful of rows) leave most of the chip idle while
+// every workgroup walks the whole K axis at one exposed DMA latency per step.  Here a workgroup owns a 64x64 tile and
+// its four waves split the K steps among themselves (wave w takes steps w, w + 4, ...), each with its own
+// double-buffered LDS stage; the four partial tiles meet in LDS and wave 0 runs the usual epilogue.  4x the tiles and
+// 4x shorter K chains per tile; results differ from the 128x128 kernel only in summation order.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(const GemmParams p) {
+  constexpr int EPC = Elem<T>::EPC, BK = 8 * EPC;
+  constexpr int WSTG = 128 * 8;                        // 16-byte chunks of one wave's stage: 64 A rows + 64 W rows
+  __shared__ uint4 lds_all[4 * 2 * WSTG];              // [wave][stage]: 128 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int NB = (p.N + 63) / 64;
+  const int m0 = ((int)blockIdx.x / NB) * 64, n0 = ((int)blockIdx.x % NB) * 64;
+  if (blockIdx.x == 0) {
+    T *o = static_cast<T *>(p.out);
+    T *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD && !(EPI == EPI_RELU && p.mask_bits)) ? static_cast<T *>(p.aux) : nullptr;
+    for (int64_t i = threadIdx.x; i < p.zero_head; i += 256) {
+      o[-1 - i] = Elem<T>::from_f(0.f);
+      if (x) x[-1 - i] = Elem<T>::from_f(0.f);
+    }
+    const int64_t tail0 = (int64_t)p.M * p.ldc, tailx = (int64_t)p.M * p.ldz;
+    for (int64_t i = threadIdx.x; i < p.zero_tail; i += 256) {
+      o[tail0 + i] = Elem<T>::from_f(0.f);
+      if (x) x[tailx + i] = Elem<T>::from_f(0.f);
+    }
+  }
+  const T *A = static_cast<const T *>(p.A);
+  const T *W = static_cast<const T *>(p.W);
+  // a wave instruction fills 1 KB = 8 rows: instruction `it` covers rows 8 it .. 8 it + 7, lane L = (row, chunk)
+  const T *ga[8], *gw[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = 8 * it + (lane >> 3), cphys = lane & 7, clog = cphys ^ (row & 7);
+    int am = m0 + row, wr = n0 + row;
+    am = am < p.M ? am : p.M - 1;
+    wr = wr < p.N ? wr : p.N - 1;
+    ga[it] = A + (int64_t)am * p.lda + clog * EPC;
+    gw[it] = W + (int64_t)wr * p.ldw + clog * EPC;
+  }
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+  uint4 *mine = lds_all + wave * 2 * WSTG;
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      __builtin_amdgcn_global_load_lds((glb_ptr)(ga[it] + kt * BK), (lds_ptr)(&mine[stage * WSTG + it * 64]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(gw[it] + kt * BK), (lds_ptr)(&mine[stage * WSTG + 512 + it * 64]), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bv[4][4];
+  nt_load_bias(p, n0, 0, g, bv);
+  const int nk = p.K / BK;
+  int stage = 0;
+  if (wave < nk) issue(wave, 0);
+  for (int kt = wave; kt < nk; kt += 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stage landed (wave-private LDS: no barrier)
+    if (kt + 4 < nk) issue(kt + 4, stage ^ 1);
+    nt_compute<T>(mine + stage * WSTG, mine + stage * WSTG + 512, acc, 0, 0, g, r);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // fragment reads done before the stage is refilled
+    stage ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- meet in LDS: waves 1..3 park their partial tiles (16 KB each, in their own stage area), wave 0 adds them
+  f32x4 *park = reinterpret_cast<f32x4 *>(mine);
+  if (wave != 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) park[(i * 4 + j) * 64 + lane] = acc[i][j];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(lds_all + w * 2 * WSTG);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += src[(i * 4 + j) * 64 + lane];
+  }
+  nt_epilogue<T, EPI>(p, acc, bv, m0, n0, 0, 0, g, r);
+}
+
+template <typename T>
+static int launch_gemm_splitk(const GemmParams &p, int epi, hipStream_t st) {
+  dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64)), block(256);
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_splitk_kernel<T, EPI_BIAS>), grid, block, 0, st, p); break;
+    case EPI_RELU: hipLaunchKernelGGL((gemm_nt_splitk_kernel<T, EPI_RELU>), grid, block, 0, st, p); break;
+    case EPI_MASK: hipLaunchKernelGGL((gemm_nt_splitk_kernel<T, EPI_MASK>), grid, block, 0, st, p); break;
+    case EPI_GLU_BWD: hipLaunchKernelGGL((gemm_nt_splitk_kernel<T, EPI_GLU_BWD>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_nt_splitk_kernel<T, EPI_GLU>), grid, block, 0, st, p); break;
+  }
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
 // ---------------------------------------------------------------- elementwise backward
 // GLU backward on the packed pre-activation: Z [M][ldz] holds per 32 columns 16 a then 16 b;
 // dOut [M][ldo] holds the 16 matching output channels per group.  dZ has Z's layout.
@@ -613,6 +719,11 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
   const int64_t mb256 = (p.M + 255) / 256;
   const int64_t tiles_256x256 = mb256 * ((p.N + 255) / 256), tiles_256x128 = mb256 * ((p.N + 127) / 128);
   int tile = nt_tile_override();
+  // few tiles and a K axis worth splitting: the small-M kernel (64x64 tiles, K split over the four waves)
+  const int64_t tiles_128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const int bk = sizeof(T) == 2 ? 64 : 32;
+  if ((tile == 64 || (!tile && p.allow_split_k && tiles_128 <= 64)) && p.K >= 4 * bk) return launch_gemm_splitk<T>(p, epi, st);
+  if (tile == 64) tile = 128;
   if (!tile) {
     // 256x256 (one workgroup per CU) once it fills the chip and N wastes little of the 256-wide tile; 256-row
     // tiles while they still give every CU >= 2 workgroups per XCD-round; K >= 256 so the saved weight traffic
@@ -655,6 +766,7 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
   p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr; p.ldz = d->ldz; p.ldy = d->ldy;
   p.gate_only = d->gate_only;
   p.mask_bits = d->mask_bits;
+  p.allow_split_k = d->allow_split_k;
   CUM_REQUIRE(!d->mask_bits || (d->epilogue == EPI_RELU && aux) || d->epilogue == EPI_MASK,
               "gemm: mask_bits applies to RELU (aux = sign array) and MASK (res = sign array)");
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;

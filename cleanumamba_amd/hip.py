@@ -44,7 +44,7 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [("dtype", c_i32), ("epilogue", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("lda", c_i64), ("ldw", c_i64), ("ldc", c_i64), ("ldr", c_i64), ("ldz", c_i64),
                 ("pitch", c_i32), ("valid", c_i32), ("n_store", c_i32), ("zero_head", c_i64), ("zero_tail", c_i64),
-                ("gate_only", c_i32), ("ldy", c_i64), ("mask_bits", c_i32)]
+                ("gate_only", c_i32), ("ldy", c_i64), ("mask_bits", c_i32), ("allow_split_k", c_i32)]
 
 
 CUM_F32, CUM_BF16 = 0, 1

@@ -466,6 +466,10 @@ class CleanUMamba(nn.Module):
         return hg["static_out"].clone()
 
     def _denoise_frame_fused(self, frame, inplace=True):
+        with cs.small_m_gemms():
+            return self._denoise_frame_fused_impl(frame)
+
+    def _denoise_frame_fused_impl(self, frame):
         """One hop on the fused GEMM kernels, same arithmetic as _denoise_frame.  Every encoder layer keeps a persistent
         window of its output (the decoder's skips read its oldest rows); the first hop of a stream computes the
         windows whole (S independent clips of valid_length(1) samples), later hops compute only the hop's new rows

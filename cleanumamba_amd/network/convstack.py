@@ -78,6 +78,7 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
     d.pitch, d.valid, d.n_store = pitch, valid, n_store
     d.gate_only, d.ldy = int(gate_only), ldy if aux2 is not None else 4
     d.mask_bits = int(mask_bits)
+    d.allow_split_k = int(_SPLIT_K_OK)     # small-M split-K kernel: streaming hops only (see small_m_gemms)
     if geo is not None:      # out (and an activation-type aux) is a row buffer of this geometry: frame it with zeros
         d.zero_head, d.zero_tail = geo.head, geo.tail
     # offsets are in elements of the GEMM dtype; bit arrays (mask_bits) are passed as views that start at the right word
@@ -85,6 +86,23 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
     with torch.cuda.device(A.device):
         hip.check(hip.lib().cum_gemm_nt(ctypes.byref(d), P(A, a_off), P(Wp, 0), hip.ptr(bias), P(res, r_off),
                                         P(out, o_off), P(aux, x_off), P(aux2, y_off), hip.stream_ptr()))
+
+
+_SPLIT_K_OK = False
+
+
+class small_m_gemms:
+    """Context: cum_gemm_nt launches inside may use the small-M kernel (64x64 tiles, K split over the waves), which
+    differs from the standard kernels in summation order.  The streaming hop opts in; training and the parallel
+    forward keep one summation order for every shape (grad mode cannot be the switch: it is off inside backward())."""
+
+    def __enter__(self):
+        global _SPLIT_K_OK
+        self.prev, _SPLIT_K_OK = _SPLIT_K_OK, True
+
+    def __exit__(self, *exc):
+        global _SPLIT_K_OK
+        _SPLIT_K_OK = self.prev
 
 
 def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True, out=None):

@@ -218,7 +218,11 @@ class CleanUMamba(nn.Module):
             if not cs.supported(self):
                 raise NotImplementedError("fused conv stack covers kernel 4 / stride 2 / ungrouped / sigmoid-GLU "
                                           "layers; set model.use_fused_convs = False for other variants")
-            x, skip_connections, tsfm_out = self._forward_fused(x)
+            if torch.is_grad_enabled():
+                x, skip_connections, tsfm_out = self._forward_fused(x)
+            else:
+                with cs.small_m_gemms():     # inference on short inputs: few-tile GEMMs may split K over the waves
+                    x, skip_connections, tsfm_out = self._forward_fused(x)
         else:
             skip_connections = []
             for downsampling_block in self.encoder:

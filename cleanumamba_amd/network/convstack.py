@@ -93,8 +93,8 @@ _SPLIT_K_OK = False
 
 class small_m_gemms:
     """Context: cum_gemm_nt launches inside may use the small-M kernel (64x64 tiles, K split over the waves), which
-    differs from the standard kernels in summation order.  The streaming hop opts in; training and the parallel
-    forward keep one summation order for every shape (grad mode cannot be the switch: it is off inside backward())."""
+    differs from the standard kernels in summation order.  The streaming hop and the no-grad parallel forward opt in;
+    training keeps one summation order for every shape (grad mode cannot be the switch: it is off inside backward())."""
 
     def __enter__(self):
         global _SPLIT_K_OK

@@ -189,8 +189,8 @@ typedef struct {
                              /* res is such an array (byte index (m*ldr + n) / 4).  1/8 of the bytes of a bf16 mask */
   int32_t allow_split_k;     /* 1: launches with few tiles (M = streams x a handful of rows) may use the small-M      */
                              /* kernel, which splits the K axis over the four waves of a 64x64 tile: same result up  */
-                             /* to summation order.  The host sets it for the streaming hops; training and the      */
-                             /* parallel forward keep one summation order for every shape.                          */
+                             /* to summation order.  The host sets it for inference (streaming hops, no-grad forward);  */
+                             /* training keeps one summation order for every shape.                                 */
 } cum_gemm_desc;
 
 int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias,

@@ -22,6 +22,7 @@ net = net.to(dev).eval()
 if len(sys.argv) > 3:
     net.use_fused_stream = sys.argv[3] != "cached"      # third argument "cached": torch-module hop with encoder caches
     net.stream_bf16 = sys.argv[3] == "bf16"              # "bf16": fused hop with bf16 activations / GEMMs
+    net.fused_min_streams = 1                            # an explicit variant also applies to a single stream
 n = int(SECONDS * 16000)
 x = 0.05 * torch.randn(S, n, device=dev)
 hop = net.total_stride

@@ -5,7 +5,7 @@ src/network/S4/MambaS4.py:454-463; torch equivalent ``act(conv1d(x)[..., :L])`` 
 :455).  x: (B, D, L) logical, any strides (channel-contiguous preferred);
 weight: (D, W); W <= 4.  No CPU path.
 
-x may be float32 or bfloat16 (what autocast hands over): the kernels read and write that element type
+x may be float32, bfloat16 or float16 (what autocast hands over): the kernels read and write that element type
 directly (cum_conv_shape.io_dtype) and compute in fp32; weights and their gradients are always fp32.
 """
 import ctypes
@@ -77,7 +77,7 @@ class CausalConv1dFn(torch.autograd.Function):
 
 def causal_conv1d_fn(x, weight, bias=None, activation=None):
     in_dtype = x.dtype
-    if in_dtype not in (torch.float32, torch.bfloat16):
+    if in_dtype not in hip.IO_TYPES:
         x = x.float()
     return CausalConv1dFn.apply(x, weight.float(), None if bias is None else bias.float(), activation).to(in_dtype)
 
@@ -93,9 +93,11 @@ def causal_conv1d_update(x, conv_state, weight, bias=None, activation=None):
     bsz, dim, W = conv_state.shape
     x = x.contiguous()
     y = torch.empty_like(x)
+    # named locals: a contiguous() temporary must outlive the launch (ctypes passes bare addresses)
+    wc = weight.contiguous()
+    bc = None if bias is None else bias.contiguous()
     with torch.cuda.device(x.device):
-        hip.check(hip.lib().cum_causal_conv1d_update(bsz, dim, W, hip.ptr(conv_state), hip.ptr(x),
-                                                     hip.ptr(weight.contiguous()),
-                                                     hip.ptr(None if bias is None else bias.contiguous()),
-                                                     int(activation is not None), hip.ptr(y), hip.stream_ptr()))
+        hip.check(hip.lib().cum_causal_conv1d_update(bsz, dim, W, hip.ptr(conv_state), hip.ptr(x), hip.ptr(wc),
+                                                     hip.ptr(bc), int(activation is not None), hip.ptr(y),
+                                                     hip.stream_ptr()))
     return y

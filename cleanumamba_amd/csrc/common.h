@@ -29,6 +29,11 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 namespace cum {
 
+typedef _Float16 f16;
+// 16-bit element types share every tiling decision (8 elements per 16-byte chunk, K tile 64)
+static inline bool is16(int dt) { return dt == CUM_BF16 || dt == CUM_F16; }
+static inline bool dtype_ok(int dt) { return dt == CUM_F32 || dt == CUM_BF16 || dt == CUM_F16; }
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 

@@ -61,19 +61,29 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const ConvParams p) {
 // bf16, channel-contiguous rows: one lane walks TWO adjacent channels (4-byte loads / stores: a wave instruction moves
 // 256 B instead of 128 B, half as many memory instructions) and the arithmetic runs on float2 pairs (v_pk_* ops).
 typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 bf16x2_to_f2(uint32_t v) {
+template <typename T>
+__device__ __forceinline__ f2 h2_to_f2(uint32_t v);
+template <>
+__device__ __forceinline__ f2 h2_to_f2<__bf16>(uint32_t v) {
   f2 r;
   r.x = __builtin_bit_cast(float, v << 16);
   r.y = __builtin_bit_cast(float, v & 0xffff0000u);
   return r;
 }
-__device__ __forceinline__ uint32_t f2_to_bf16x2(f2 v) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-  const bf16x2 o = {(__bf16)v.x, (__bf16)v.y};
+template <>
+__device__ __forceinline__ f2 h2_to_f2<f16>(uint32_t v) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+  const f16x2 h = __builtin_bit_cast(f16x2, v);
+  return f2{(float)h.x, (float)h.y};
+}
+template <typename T>
+__device__ __forceinline__ uint32_t f2_to_h2(f2 v) {
+  typedef __attribute__((ext_vector_type(2))) T hx2;
+  const hx2 o = {(T)v.x, (T)v.y};
   return __builtin_bit_cast(uint32_t, o);
 }
 
-template <int W>
+template <int W, typename TH>
 __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const ConvParams p) {
   const int lane = threadIdx.x & 63;
   const int d = blockIdx.x * 128 + 2 * lane;
@@ -86,14 +96,14 @@ __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const ConvParams p) {
 #pragma unroll
   for (int k = 0; k < W; ++k) wk[k] = f2{p.w[d * W + k], p.w[(d + 1) * W + k]};
   const f2 bs = p.bias ? f2{p.bias[d], p.bias[d + 1]} : f2{0.f, 0.f};
-  const __bf16 *xp = static_cast<const __bf16 *>(p.x) + b * p.s.x_sb + d;
-  __bf16 *yp = static_cast<__bf16 *>(p.y) + b * p.s.y_sb + d;
+  const TH *xp = static_cast<const TH *>(p.x) + b * p.s.x_sb + d;
+  TH *yp = static_cast<TH *>(p.y) + b * p.s.y_sb + d;
   f2 xv[TC + W - 1];
 #pragma unroll
   for (int i = 0; i < TC + W - 1; ++i) {
     const int t = t0 - (W - 1) + i;
     const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
-    const f2 v = bf16x2_to_f2(*reinterpret_cast<const uint32_t *>(xp + (int64_t)tc * p.s.x_sl));
+    const f2 v = h2_to_f2<TH>(*reinterpret_cast<const uint32_t *>(xp + (int64_t)tc * p.s.x_sl));
     xv[i] = (t >= 0 && t < L) ? v : f2{0.f, 0.f};
   }
 #pragma unroll
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const ConvParams p) {
       acc.x = acc.x * sigmoidf_(acc.x);
       acc.y = acc.y * sigmoidf_(acc.y);
     }
-    if (t < L) *reinterpret_cast<uint32_t *>(yp + (int64_t)t * p.s.y_sl) = f2_to_bf16x2(acc);
+    if (t < L) *reinterpret_cast<uint32_t *>(yp + (int64_t)t * p.s.y_sl) = f2_to_h2<TH>(acc);
   }
 }
 
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const ConvParams p) {
   ws[(int64_t)MAXW * p.s.dim] = db;
 }
 
-template <int W>
+template <int W, typename TH>
 __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(const ConvParams p) {
   const int lane = threadIdx.x & 63;
   const int d = blockIdx.x * 128 + 2 * lane;
@@ -185,22 +195,22 @@ __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(const ConvParams p) {
 #pragma unroll
   for (int k = 0; k < W; ++k) wk[k] = f2{p.w[d * W + k], p.w[(d + 1) * W + k]};
   const f2 bs = p.bias ? f2{p.bias[d], p.bias[d + 1]} : f2{0.f, 0.f};
-  const __bf16 *xp = static_cast<const __bf16 *>(p.x) + b * p.s.x_sb + d;
-  const __bf16 *dyp = static_cast<const __bf16 *>(p.dy) + b * p.s.y_sb + d;
-  __bf16 *dxp = static_cast<__bf16 *>(p.dx) + b * p.dx_sb + d;
+  const TH *xp = static_cast<const TH *>(p.x) + b * p.s.x_sb + d;
+  const TH *dyp = static_cast<const TH *>(p.dy) + b * p.s.y_sb + d;
+  TH *dxp = static_cast<TH *>(p.dx) + b * p.dx_sb + d;
   f2 xv[TC + 2 * (W - 1)], g[TC + W - 1];
 #pragma unroll
   for (int i = 0; i < TC + 2 * (W - 1); ++i) {
     const int t = t0 - (W - 1) + i;
     const int tc = t < 0 ? 0 : (t < L ? t : L - 1);
-    const f2 v = bf16x2_to_f2(*reinterpret_cast<const uint32_t *>(xp + (int64_t)tc * p.s.x_sl));
+    const f2 v = h2_to_f2<TH>(*reinterpret_cast<const uint32_t *>(xp + (int64_t)tc * p.s.x_sl));
     xv[i] = (t >= 0 && t < L) ? v : f2{0.f, 0.f};
   }
 #pragma unroll
   for (int i = 0; i < TC + W - 1; ++i) {
     const int s = t0 + i;
     const int sc = s < L ? s : L - 1;
-    const f2 v = bf16x2_to_f2(*reinterpret_cast<const uint32_t *>(dyp + (int64_t)sc * p.s.y_sl));
+    const f2 v = h2_to_f2<TH>(*reinterpret_cast<const uint32_t *>(dyp + (int64_t)sc * p.s.y_sl));
     f2 gi = s < L ? v : f2{0.f, 0.f};
     if (p.s.silu) {
       f2 pre = bs;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd2_kernel(const ConvParams p) {
     f2 acc = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < W; ++k) acc = wk[k] * g[i + (W - 1) - k] + acc;
-    if (t < L) *reinterpret_cast<uint32_t *>(dxp + (int64_t)t * p.dx_sl) = f2_to_bf16x2(acc);
+    if (t < L) *reinterpret_cast<uint32_t *>(dxp + (int64_t)t * p.dx_sl) = f2_to_h2<TH>(acc);
 #pragma unroll
     for (int k = 0; k < W; ++k) dwk[k] = g[i] * xv[i + k] + dwk[k];
     db += g[i];
@@ -291,7 +301,7 @@ static int conv_check(const cum_conv_shape *s) {
   CUM_REQUIRE(s != nullptr, "conv: null shape");
   CUM_REQUIRE(s->batch >= 0 && s->dim >= 1 && s->len >= 0, "conv: bad batch/dim/len");
   CUM_REQUIRE(s->width >= 1 && s->width <= MAXW, "conv: width must be in [1, 4]");
-  CUM_REQUIRE(s->io_dtype == CUM_F32 || s->io_dtype == CUM_BF16, "conv: io_dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(s->io_dtype), "conv: io_dtype must be CUM_F32, CUM_BF16 or CUM_F16");
   CUM_REQUIRE(s->batch <= 65535, "conv: batch > 65535");
   return CUM_OK;
 }
@@ -306,24 +316,25 @@ extern "C" int cum_causal_conv1d_fwd(const cum_conv_shape *s, const void *x, con
   p.nchunks = (s->len + TC - 1) / TC;
   dim3 grid((s->dim + 63) / 64, (p.nchunks + 3) / 4, s->batch), block(256);
   hipStream_t st = (hipStream_t)stream;
-  const bool h = s->io_dtype == CUM_BF16;
-  const bool pair = h && s->dim % 2 == 0 && s->x_sd == 1 && s->y_sd == 1 && s->x_sl % 2 == 0 && s->y_sl % 2 == 0 &&
+  const int io = s->io_dtype;
+  const bool pair = is16(io) && s->dim % 2 == 0 && s->x_sd == 1 && s->y_sd == 1 && s->x_sl % 2 == 0 && s->y_sl % 2 == 0 &&
                     s->x_sb % 2 == 0 && s->y_sb % 2 == 0 && ((uintptr_t)x & 3) == 0 && ((uintptr_t)y & 3) == 0;
-  if (pair) {
-    dim3 grid2((s->dim / 2 + 63) / 64, grid.y, grid.z);
-    switch (s->width) {
-      case 1: hipLaunchKernelGGL(dwconv_fwd2_kernel<1>, grid2, block, 0, st, p); break;
-      case 2: hipLaunchKernelGGL(dwconv_fwd2_kernel<2>, grid2, block, 0, st, p); break;
-      case 3: hipLaunchKernelGGL(dwconv_fwd2_kernel<3>, grid2, block, 0, st, p); break;
-      default: hipLaunchKernelGGL(dwconv_fwd2_kernel<4>, grid2, block, 0, st, p); break;
-    }
-  } else
+#define CUM_DW_FWD(W)                                                                                         \
+  do {                                                                                                        \
+    if (pair && io == CUM_BF16) hipLaunchKernelGGL((dwconv_fwd2_kernel<W, __bf16>), grid2, block, 0, st, p);  \
+    else if (pair) hipLaunchKernelGGL((dwconv_fwd2_kernel<W, f16>), grid2, block, 0, st, p);                  \
+    else if (io == CUM_BF16) hipLaunchKernelGGL((dwconv_fwd_kernel<W, __bf16>), grid, block, 0, st, p);       \
+    else if (io == CUM_F16) hipLaunchKernelGGL((dwconv_fwd_kernel<W, f16>), grid, block, 0, st, p);           \
+    else hipLaunchKernelGGL((dwconv_fwd_kernel<W, float>), grid, block, 0, st, p);                            \
+  } while (0)
+  dim3 grid2((s->dim / 2 + 63) / 64, grid.y, grid.z);
   switch (s->width) {
-    case 1: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<1, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<1, float>), grid, block, 0, st, p); break;
-    case 2: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<2, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<2, float>), grid, block, 0, st, p); break;
-    case 3: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<3, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<3, float>), grid, block, 0, st, p); break;
-    default: if (h) hipLaunchKernelGGL((dwconv_fwd_kernel<4, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_fwd_kernel<4, float>), grid, block, 0, st, p); break;
+    case 1: CUM_DW_FWD(1); break;
+    case 2: CUM_DW_FWD(2); break;
+    case 3: CUM_DW_FWD(3); break;
+    default: CUM_DW_FWD(4); break;
   }
+#undef CUM_DW_FWD
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }
@@ -351,26 +362,27 @@ extern "C" int cum_causal_conv1d_bwd(const cum_conv_shape *s, const void *x, con
   p.dx_sb = dx_sb; p.dx_sd = dx_sd; p.dx_sl = dx_sl;
   p.nchunks = (s->len + TC - 1) / TC;
   dim3 grid((s->dim + 63) / 64, (p.nchunks + 3) / 4, s->batch), block(256);
-  const bool h = s->io_dtype == CUM_BF16;
+  const int io = s->io_dtype;
   // two channels per lane when every row of x, dy and dx starts 4-byte aligned with unit channel stride
-  const bool pair = h && s->dim % 2 == 0 && s->x_sd == 1 && s->y_sd == 1 && dx_sd == 1 && s->x_sl % 2 == 0 &&
+  const bool pair = is16(io) && s->dim % 2 == 0 && s->x_sd == 1 && s->y_sd == 1 && dx_sd == 1 && s->x_sl % 2 == 0 &&
                     s->y_sl % 2 == 0 && dx_sl % 2 == 0 && s->x_sb % 2 == 0 && s->y_sb % 2 == 0 && dx_sb % 2 == 0 &&
                     ((uintptr_t)x & 3) == 0 && ((uintptr_t)dy & 3) == 0 && ((uintptr_t)dx & 3) == 0;
-  if (pair) {
-    dim3 grid2((s->dim / 2 + 63) / 64, (p.nchunks + 3) / 4, s->batch);
-    switch (s->width) {
-      case 1: hipLaunchKernelGGL(dwconv_bwd2_kernel<1>, grid2, block, 0, st, p); break;
-      case 2: hipLaunchKernelGGL(dwconv_bwd2_kernel<2>, grid2, block, 0, st, p); break;
-      case 3: hipLaunchKernelGGL(dwconv_bwd2_kernel<3>, grid2, block, 0, st, p); break;
-      default: hipLaunchKernelGGL(dwconv_bwd2_kernel<4>, grid2, block, 0, st, p); break;
-    }
-  } else
+#define CUM_DW_BWD(W)                                                                                         \
+  do {                                                                                                        \
+    if (pair && io == CUM_BF16) hipLaunchKernelGGL((dwconv_bwd2_kernel<W, __bf16>), grid2, block, 0, st, p);  \
+    else if (pair) hipLaunchKernelGGL((dwconv_bwd2_kernel<W, f16>), grid2, block, 0, st, p);                  \
+    else if (io == CUM_BF16) hipLaunchKernelGGL((dwconv_bwd_kernel<W, __bf16>), grid, block, 0, st, p);       \
+    else if (io == CUM_F16) hipLaunchKernelGGL((dwconv_bwd_kernel<W, f16>), grid, block, 0, st, p);           \
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<W, float>), grid, block, 0, st, p);                            \
+  } while (0)
+  dim3 grid2((s->dim / 2 + 63) / 64, (p.nchunks + 3) / 4, s->batch);
   switch (s->width) {
-    case 1: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<1, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<1, float>), grid, block, 0, st, p); break;
-    case 2: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<2, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<2, float>), grid, block, 0, st, p); break;
-    case 3: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<3, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<3, float>), grid, block, 0, st, p); break;
-    default: if (h) hipLaunchKernelGGL((dwconv_bwd_kernel<4, __bf16>), grid, block, 0, st, p); else hipLaunchKernelGGL((dwconv_bwd_kernel<4, float>), grid, block, 0, st, p); break;
+    case 1: CUM_DW_BWD(1); break;
+    case 2: CUM_DW_BWD(2); break;
+    case 3: CUM_DW_BWD(3); break;
+    default: CUM_DW_BWD(4); break;
   }
+#undef CUM_DW_BWD
   CUM_CHECK_LAUNCH();
   const int total = (MAXW + 1) * s->dim;
   hipLaunchKernelGGL(dwconv_bwd_finalize_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace,

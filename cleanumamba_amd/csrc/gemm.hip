@@ -33,6 +33,7 @@
 namespace cum {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_GLU = 2, EPI_MASK = 3, EPI_GLU_BWD = 4 };
@@ -73,6 +74,13 @@ struct Elem<__bf16> {
   static __device__ __forceinline__ __bf16 from_f(float v) { return (__bf16)v; }
 };
 
+template <>
+struct Elem<f16> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ float to_f(f16 v) { return (float)v; }
+  static __device__ __forceinline__ f16 from_f(float v) { return (f16)v; }
+};
+
 template <typename T>
 __device__ __forceinline__ void store4(T *p, const float (&v)[4]);
 template <>
@@ -84,6 +92,12 @@ __device__ __forceinline__ void store4<__bf16>(__bf16 *p, const float (&v)[4]) {
   typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
   bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
   *reinterpret_cast<bf16x4 *>(p) = o;
+}
+template <>
+__device__ __forceinline__ void store4<f16>(f16 *p, const float (&v)[4]) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+  f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  *reinterpret_cast<f16x4 *>(p) = o;
 }
 template <typename T>
 __device__ __forceinline__ void load4(const T *p, float (&v)[4]);
@@ -100,6 +114,14 @@ __device__ __forceinline__ void load4<__bf16>(const __bf16 *p, float (&v)[4]) {
   for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
 }
 
+template <>
+__device__ __forceinline__ void load4<f16>(const f16 *p, float (&v)[4]) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+  const f16x4 t = *reinterpret_cast<const f16x4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
+}
+
 // One K-step of a wave's 64x64 sub-tile from the staged tiles (ldsA / ldsW: [row * 8 + chunk], chunk index
 // XOR-swizzled by row & 7).
 template <typename T>
@@ -108,20 +130,26 @@ __device__ __forceinline__ void nt_compute(const uint4 *ldsA, const uint4 *ldsW,
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[4], af[4];
+      uint4 wf[4], af[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int wrow = wn * 64 + i * 16 + r;
         const int arow = wm * 64 + i * 16 + r;
         const int cl = ks * 4 + g;
-        wf[i] = __builtin_bit_cast(bf16x8, ldsW[wrow * 8 + (cl ^ (wrow & 7))]);
-        af[i] = __builtin_bit_cast(bf16x8, ldsA[arow * 8 + (cl ^ (arow & 7))]);
+        wf[i] = ldsW[wrow * 8 + (cl ^ (wrow & 7))];
+        af[i] = ldsA[arow * 8 + (cl ^ (arow & 7))];
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        for (int mi = 0; mi < 4; ++mi) {
+          if constexpr (__is_same(T, f16))
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[ni]),
+                                                                 __builtin_bit_cast(f16x8, af[mi]), acc[ni][mi], 0, 0, 0);
+          else
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ni]),
+                                                                  __builtin_bit_cast(bf16x8, af[mi]), acc[ni][mi], 0, 0, 0);
+        }
     }
   } else {
     // f32: lane reads k = 8g .. 8g+7 (two chunks) of its row; MFMA k-slot g at sub-step s is k = 8g + s
@@ -180,6 +208,17 @@ struct Raw4<__bf16> {
   typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
   bf16x4 v;
   __device__ __forceinline__ void ld(const __bf16 *p) { v = *reinterpret_cast<const bf16x4 *>(p); }
+  __device__ __forceinline__ void get(float (&o)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+  }
+};
+
+template <>
+struct Raw4<f16> {
+  typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+  f16x4 v;
+  __device__ __forceinline__ void ld(const f16 *p) { v = *reinterpret_cast<const f16x4 *>(p); }
   __device__ __forceinline__ void get(float (&o)[4]) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
@@ -744,13 +783,13 @@ using namespace cum;
 extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias, const void *res,
                            void *out, void *aux, const void *aux2, void *stream) {
   CUM_REQUIRE(d && A && W && out, "gemm: null argument");
-  CUM_REQUIRE(d->dtype == CUM_F32 || d->dtype == CUM_BF16, "gemm: dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(d->dtype), "gemm: dtype must be CUM_F32, CUM_BF16 or CUM_F16");
   CUM_REQUIRE(d->epilogue >= 0 && d->epilogue <= 4, "gemm: bad epilogue");
   CUM_REQUIRE(d->epilogue != EPI_MASK || res, "gemm: the MASK epilogue needs the gating activation in res");
   CUM_REQUIRE(d->epilogue != EPI_GLU_BWD || (aux && d->zero_head == 0 && d->zero_tail == 0),
               "gemm: the GLU_BWD epilogue needs Z in aux and writes no framing rows");
-  const int bk = d->dtype == CUM_BF16 ? 64 : 32;
-  const int epc = d->dtype == CUM_BF16 ? 8 : 4;
+  const int bk = is16(d->dtype) ? 64 : 32;
+  const int epc = is16(d->dtype) ? 8 : 4;
   CUM_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0 && d->K % bk == 0, "gemm: K must be a positive multiple of the K tile");
   CUM_REQUIRE(d->N % (d->epilogue == 2 ? 32 : 16) == 0, "gemm: N must be a multiple of 16 (32 for GLU)");
   CUM_REQUIRE(d->lda % epc == 0 && d->ldw % epc == 0, "gemm: lda/ldw must keep rows 16-byte aligned");
@@ -772,6 +811,7 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;
   p.zero_head = d->zero_head; p.zero_tail = d->zero_tail;
   if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);
+  if (d->dtype == CUM_F16) return launch_gemm<f16>(p, d->epilogue, (hipStream_t)stream);
   return launch_gemm<float>(p, d->epilogue, (hipStream_t)stream);
 }
 
@@ -786,6 +826,9 @@ extern "C" int cum_glu_bwd_gate(int32_t dtype, int64_t M, int32_t n_groups, int3
   if (dtype == CUM_BF16)
     hipLaunchKernelGGL(glu_bwd_gate_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Bg,
                        (const __bf16 *)Y, (const __bf16 *)dOut, (__bf16 *)dZ, M, n_groups, ldb, ldy, ldo, ldz, n_out);
+  else if (dtype == CUM_F16)
+    hipLaunchKernelGGL(glu_bwd_gate_kernel<f16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16 *)Bg,
+                       (const f16 *)Y, (const f16 *)dOut, (f16 *)dZ, M, n_groups, ldb, ldy, ldo, ldz, n_out);
   else
     hipLaunchKernelGGL(glu_bwd_gate_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)Bg,
                        (const float *)Y, (const float *)dOut, (float *)dZ, M, n_groups, ldb, ldy, ldo, ldz, n_out);
@@ -803,6 +846,9 @@ extern "C" int cum_glu_bwd(int32_t dtype, int64_t M, int32_t n_groups, int32_t n
   if (dtype == CUM_BF16)
     hipLaunchKernelGGL(glu_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Z,
                        (const __bf16 *)dOut, (__bf16 *)dZ, M, n_groups, ldz, ldo, n_out);
+  else if (dtype == CUM_F16)
+    hipLaunchKernelGGL(glu_bwd_kernel<f16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16 *)Z,
+                       (const f16 *)dOut, (f16 *)dZ, M, n_groups, ldz, ldo, n_out);
   else
     hipLaunchKernelGGL(glu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)Z,
                        (const float *)dOut, (float *)dZ, M, n_groups, ldz, ldo, n_out);
@@ -820,6 +866,9 @@ extern "C" int cum_relu_bwd(int32_t dtype, int64_t M, int32_t n_cols, const void
   if (dtype == CUM_BF16)
     hipLaunchKernelGGL(relu_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)Y,
                        (const __bf16 *)dOut, (__bf16 *)dZ, M, n_cols / 4, ldy, ldo, ldz, zero_head, zero_tail);
+  else if (dtype == CUM_F16)
+    hipLaunchKernelGGL(relu_bwd_kernel<f16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16 *)Y,
+                       (const f16 *)dOut, (f16 *)dZ, M, n_cols / 4, ldy, ldo, ldz, zero_head, zero_tail);
   else
     hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)Y,
                        (const float *)dOut, (float *)dZ, M, n_cols / 4, ldy, ldo, ldz, zero_head, zero_tail);
@@ -844,6 +893,8 @@ extern "C" int cum_colsum(int32_t dtype, int64_t M, int32_t n_cols, const void *
   dim3 grid((n_cols + 63) / 64, parts), block(64);
   if (dtype == CUM_BF16)
     hipLaunchKernelGGL(colsum_stage1<__bf16>, grid, block, 0, st, (const __bf16 *)X, M, n_cols, ld, 1024, workspace);
+  else if (dtype == CUM_F16)
+    hipLaunchKernelGGL(colsum_stage1<f16>, grid, block, 0, st, (const f16 *)X, M, n_cols, ld, 1024, workspace);
   else
     hipLaunchKernelGGL(colsum_stage1<float>, grid, block, 0, st, (const float *)X, M, n_cols, ld, 1024, workspace);
   CUM_CHECK_LAUNCH();

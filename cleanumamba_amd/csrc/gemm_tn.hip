@@ -24,6 +24,8 @@ namespace cum {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct TnParams {
@@ -49,6 +51,8 @@ struct TnCfg<__bf16> {
   // 32-byte block (two chunks) together.
   static __device__ __forceinline__ int swz(int row) { return 2 * ((row & 3) | (((row >> 3) & 1) << 2)); }
 };
+template <>
+struct TnCfg<f16> : TnCfg<__bf16> {};
 template <>
 struct TnCfg<float> {
   static constexpr int EPC = 4, BMK = 32;
@@ -132,7 +136,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       for (int i = 0; i < NCH; ++i) {
         const int row = tid / CPR + (256 / CPR) * i;
         const uint4 v = lds[0][row * CPR + (bc ^ TnCfg<T>::swz(row))];
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (__is_same(T, f16)) {
+          const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[e] += (float)h[e];
+        } else if constexpr (sizeof(T) == 2) {
           const bf16x8 h = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
           for (int e = 0; e < 8; ++e) bsum[e] += (float)h[e];
@@ -170,8 +178,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int ki = 0; ki < 4; ++ki)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ki], zf[ni], acc[ki][ni], 0, 0, 0);
+          for (int ni = 0; ni < 4; ++ni) {
+            // the transposing read moves 16-bit lanes; only the MFMA interprets them
+            if constexpr (__is_same(T, f16))
+              acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf[ki]),
+                                                                   __builtin_bit_cast(f16x8, zf[ni]), acc[ki][ni], 0, 0, 0);
+            else
+              acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ki], zf[ni], acc[ki][ni], 0, 0, 0);
+          }
       }
     } else {
 #pragma unroll
@@ -286,7 +300,7 @@ static void tn_plan(int64_t M, int32_t N, int32_t K, int32_t dtype, int *Np, int
   *Np = (N + TN_T - 1) / TN_T * TN_T;
   *Kp = (K + TN_T - 1) / TN_T * TN_T;
   const int tiles = (*Np / TN_T) * (*Kp / TN_T);
-  const int bmk = dtype == CUM_BF16 ? 32 : 16;
+  const int bmk = is16(dtype) ? 32 : 16;
   // Splits are dealt to the 8 XCDs round-robin and an XCD holds 96 workgroups at a time (32 CUs x 3).  One split
   // with >= 96 tiles already fills its XCD: 8 splits.  Smaller tile counts take as many splits per XCD as fit into
   // ONE resident round (32 tiles -> 3 per XCD = 24 splits): a second, partly filled round costs a full round's
@@ -319,9 +333,9 @@ extern "C" int64_t cum_gemm_tn_workspace_elems(int32_t dtype, int64_t M, int32_t
 
 extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
                            int64_t ldx, float *dW, int64_t ldw, float *db, float *workspace, void *stream) {
-  CUM_REQUIRE(dtype == CUM_F32 || dtype == CUM_BF16, "gemm_tn: dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(dtype), "gemm_tn: dtype must be CUM_F32, CUM_BF16 or CUM_F16");
   CUM_REQUIRE(dZ && X && dW && workspace && M >= 0 && N > 0 && K > 0, "gemm_tn: bad argument");
-  const int epc = dtype == CUM_BF16 ? 8 : 4;
+  const int epc = is16(dtype) ? 8 : 4;
   CUM_REQUIRE(N % epc == 0 && K % epc == 0 && ldz % epc == 0 && ldx % epc == 0 && ldw % 4 == 0,
               "gemm_tn: N, K and strides must keep 16-byte alignment");
   CUM_REQUIRE(((uintptr_t)dZ & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)dW & 15) == 0,
@@ -343,6 +357,8 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   dim3 grid(8 * (Np / TN_T) * (Kp / TN_T) * ((S + 7) / 8)), block(256);
   if (dtype == CUM_BF16)
     hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, block, 0, st, p);
+  else if (dtype == CUM_F16)
+    hipLaunchKernelGGL(gemm_tn_kernel<f16>, grid, block, 0, st, p);
   else
     hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();

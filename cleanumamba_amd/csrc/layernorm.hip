@@ -26,6 +26,13 @@ __device__ __forceinline__ void ld8<__bf16>(const __bf16 *p, float (&v)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
 }
+template <>
+__device__ __forceinline__ void ld8<f16>(const f16 *p, float (&v)[8]) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+  const f16x8 t = *reinterpret_cast<const f16x8 *>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
 template <typename T>
 __device__ __forceinline__ void st8(T *p, const float (&v)[8]);
 template <>
@@ -40,6 +47,15 @@ __device__ __forceinline__ void st8<__bf16>(__bf16 *p, const float (&v)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) t[i] = (__bf16)v[i];
   *reinterpret_cast<bf16x8 *>(p) = t;
+}
+
+template <>
+__device__ __forceinline__ void st8<f16>(f16 *p, const float (&v)[8]) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+  f16x8 t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = (f16)v[i];
+  *reinterpret_cast<f16x8 *>(p) = t;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -245,8 +261,8 @@ extern "C" int cum_add_layernorm_fwd(int32_t x_dtype, int32_t y_dtype, int64_t b
                                      const float *weight, const float *bias, float eps, float *residual_out, void *y,
                                      float *mean, float *rstd, void *stream) {
   if (int rc = ln_check(batch, len, dim)) return rc;
-  CUM_REQUIRE((x_dtype == CUM_F32 || x_dtype == CUM_BF16) && (y_dtype == CUM_F32 || y_dtype == CUM_BF16),
-              "add_layernorm: dtypes must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(x_dtype) && dtype_ok(y_dtype) && !(is16(x_dtype) && is16(y_dtype) && x_dtype != y_dtype),
+              "add_layernorm: dtypes must be CUM_F32 / CUM_BF16 / CUM_F16 (one 16-bit type per call)");
   const int64_t rows = batch * len;
   if (rows == 0) return CUM_OK;
   CUM_REQUIRE(x && weight && residual_out && y && mean && rstd, "add_layernorm_fwd: null pointer");
@@ -256,7 +272,13 @@ extern "C" int cum_add_layernorm_fwd(int32_t x_dtype, int32_t y_dtype, int64_t b
   p.x_sb = x_sb; p.x_sl = x_sl; p.rows = rows; p.len = len; p.dim = dim; p.nch = dim / 8; p.eps = eps;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (x_dtype == CUM_BF16 && y_dtype == CUM_BF16)
+  if (x_dtype == CUM_F16 && y_dtype == CUM_F16)
+    hipLaunchKernelGGL((add_layernorm_fwd_kernel<f16, f16>), grid, block, 0, st, p);
+  else if (x_dtype == CUM_F16)
+    hipLaunchKernelGGL((add_layernorm_fwd_kernel<f16, float>), grid, block, 0, st, p);
+  else if (y_dtype == CUM_F16)
+    hipLaunchKernelGGL((add_layernorm_fwd_kernel<float, f16>), grid, block, 0, st, p);
+  else if (x_dtype == CUM_BF16 && y_dtype == CUM_BF16)
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<__bf16, __bf16>), grid, block, 0, st, p);
   else if (x_dtype == CUM_BF16)
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<__bf16, float>), grid, block, 0, st, p);
@@ -275,8 +297,8 @@ extern "C" int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t r
                                      const float *rstd, const float *weight, float *dx32, void *dxh, float *dweight,
                                      float *dbias, float *workspace, void *stream) {
   if (int rc = ln_check(rows, 1, dim)) return rc;
-  CUM_REQUIRE((y_dtype == CUM_F32 || y_dtype == CUM_BF16) && (h_dtype == CUM_F32 || h_dtype == CUM_BF16),
-              "add_layernorm: dtypes must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(y_dtype) && dtype_ok(h_dtype) && !(is16(y_dtype) && is16(h_dtype) && y_dtype != h_dtype),
+              "add_layernorm: dtypes must be CUM_F32 / CUM_BF16 / CUM_F16 (one 16-bit type per call)");
   CUM_REQUIRE(dweight && workspace, "add_layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (rows == 0) {
@@ -290,7 +312,13 @@ extern "C" int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t r
   p.dx32 = dx32; p.dxh = dxh; p.slab = workspace; p.rows = rows; p.dim = dim; p.nch = dim / 8;
   const int groups = (int)((rows + 3) / 4 < kLnBwdGroups ? (rows + 3) / 4 : kLnBwdGroups);
   dim3 grid(groups), block(256);
-  if (y_dtype == CUM_BF16 && h_dtype == CUM_BF16)
+  if (y_dtype == CUM_F16 && h_dtype == CUM_F16)
+    hipLaunchKernelGGL((add_layernorm_bwd_kernel<f16, f16>), grid, block, 0, st, p);
+  else if (y_dtype == CUM_F16)
+    hipLaunchKernelGGL((add_layernorm_bwd_kernel<f16, float>), grid, block, 0, st, p);
+  else if (h_dtype == CUM_F16)
+    hipLaunchKernelGGL((add_layernorm_bwd_kernel<float, f16>), grid, block, 0, st, p);
+  else if (y_dtype == CUM_BF16 && h_dtype == CUM_BF16)
     hipLaunchKernelGGL((add_layernorm_bwd_kernel<__bf16, __bf16>), grid, block, 0, st, p);
   else if (y_dtype == CUM_BF16)
     hipLaunchKernelGGL((add_layernorm_bwd_kernel<__bf16, float>), grid, block, 0, st, p);

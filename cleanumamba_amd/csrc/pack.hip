@@ -23,6 +23,15 @@ struct Vec4<__bf16> {
   }
 };
 
+template <>
+struct Vec4<f16> {
+  typedef __attribute__((ext_vector_type(4))) _Float16 type;
+  static __device__ __forceinline__ type make(float a, float b, float c, float d) {
+    type v = {(f16)a, (f16)b, (f16)c, (f16)d};
+    return v;
+  }
+};
+
 // 8 elements per thread and sweep: two 16-byte index loads, eight independent gathers in flight, two vector stores
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void gather_kernel(const TS *__restrict__ src, const int32_t *__restrict__ idx,
@@ -53,8 +62,8 @@ using namespace cum;
 
 extern "C" int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n, int32_t dst_dtype,
                           void *dst, void *stream) {
-  CUM_REQUIRE((src_dtype == CUM_F32 || src_dtype == CUM_BF16) && (dst_dtype == CUM_F32 || dst_dtype == CUM_BF16),
-              "gather: dtypes must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(src_dtype) && dtype_ok(dst_dtype) && !(is16(src_dtype) && is16(dst_dtype) && src_dtype != dst_dtype),
+              "gather: dtypes must be CUM_F32 / CUM_BF16 / CUM_F16 (no bf16 <-> f16 conversion)");
   CUM_REQUIRE(n >= 0, "gather: negative length");
   if (n == 0) return CUM_OK;
   CUM_REQUIRE(src && idx && dst && ((uintptr_t)idx & 15) == 0 && ((uintptr_t)dst & 15) == 0,
@@ -62,7 +71,13 @@ extern "C" int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx
   const int64_t want = (n + 2047) / 2048;
   dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (src_dtype == CUM_F32 && dst_dtype == CUM_F32)
+  if (src_dtype == CUM_F32 && dst_dtype == CUM_F16)
+    hipLaunchKernelGGL((gather_kernel<float, f16>), grid, block, 0, st, (const float *)src, idx, (f16 *)dst, n);
+  else if (src_dtype == CUM_F16 && dst_dtype == CUM_F32)
+    hipLaunchKernelGGL((gather_kernel<f16, float>), grid, block, 0, st, (const f16 *)src, idx, (float *)dst, n);
+  else if (src_dtype == CUM_F16)
+    hipLaunchKernelGGL((gather_kernel<f16, f16>), grid, block, 0, st, (const f16 *)src, idx, (f16 *)dst, n);
+  else if (src_dtype == CUM_F32 && dst_dtype == CUM_F32)
     hipLaunchKernelGGL((gather_kernel<float, float>), grid, block, 0, st, (const float *)src, idx, (float *)dst, n);
   else if (src_dtype == CUM_F32)
     hipLaunchKernelGGL((gather_kernel<float, __bf16>), grid, block, 0, st, (const float *)src, idx, (__bf16 *)dst, n);

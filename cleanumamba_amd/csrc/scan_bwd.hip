@@ -467,7 +467,9 @@ static int launch_bwd_io(const ScanParams &p, hipStream_t st) {
 
 template <int NW>
 static int launch_bwd(const ScanParams &p, hipStream_t st) {
-  return p.s.io_dtype == CUM_BF16 ? launch_bwd_io<NW, __bf16>(p, st) : launch_bwd_io<NW, float>(p, st);
+  if (p.s.io_dtype == CUM_BF16) return launch_bwd_io<NW, __bf16>(p, st);
+  if (p.s.io_dtype == CUM_F16) return launch_bwd_io<NW, f16>(p, st);
+  return launch_bwd_io<NW, float>(p, st);
 }
 
 }  // namespace cum

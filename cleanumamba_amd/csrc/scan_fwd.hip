@@ -377,14 +377,16 @@ static int launch_fwd_io(const ScanParams &p, hipStream_t st) {
 
 template <int NW>
 static int launch_fwd(const ScanParams &p, hipStream_t st) {
-  return p.s.io_dtype == CUM_BF16 ? launch_fwd_io<NW, __bf16>(p, st) : launch_fwd_io<NW, float>(p, st);
+  if (p.s.io_dtype == CUM_BF16) return launch_fwd_io<NW, __bf16>(p, st);
+  if (p.s.io_dtype == CUM_F16) return launch_fwd_io<NW, f16>(p, st);
+  return launch_fwd_io<NW, float>(p, st);
 }
 
 int scan_check_shape(const cum_scan_shape *s) {
   CUM_REQUIRE(s != nullptr, "scan: null shape");
   CUM_REQUIRE(s->batch >= 0 && s->dim >= 1 && s->len >= 0, "scan: bad batch/dim/len");
   CUM_REQUIRE(s->dstate >= 1 && s->dstate <= 64, "scan: d_state must be in [1, 64]");
-  CUM_REQUIRE(s->io_dtype == CUM_F32 || s->io_dtype == CUM_BF16, "scan: io_dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(s->io_dtype), "scan: io_dtype must be CUM_F32, CUM_BF16 or CUM_F16");
   const int64_t lim = 2147483647LL;
   const int64_t Lm = s->len > 0 ? s->len - 1 : 0;
   CUM_REQUIRE(s->u_sl >= 0 && s->dt_sl >= 0 && s->z_sl >= 0 && s->o_sl >= 0 && s->B_sl >= 0 && s->C_sl >= 0 &&

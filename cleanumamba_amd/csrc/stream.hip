@@ -136,7 +136,7 @@ extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t 
                                         void *window, const void *fresh, int64_t pitch, int64_t fresh_pitch,
                                         int32_t fresh_row0, void *tmp, void *tail_dst, int64_t tail_pitch,
                                         void *stream) {
-  CUM_REQUIRE(dtype == CUM_F32 || dtype == CUM_BF16, "stream_window_update: dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(dtype), "stream_window_update: dtype must be CUM_F32, CUM_BF16 or CUM_F16");
   CUM_REQUIRE(streams >= 0 && rows > 0 && n_new > 0 && n_new <= rows && Cp > 0 && pitch >= rows,
               "stream_window_update: bad shape");
   CUM_REQUIRE(fresh_row0 >= 0 && fresh_row0 <= rows - n_new && fresh_pitch >= rows - fresh_row0,
@@ -146,7 +146,7 @@ extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t 
   hipStream_t st = (hipStream_t)stream;
   const int keep = rows - n_new;
   CUM_REQUIRE(!tail_dst || (keep >= 2 && tail_pitch >= n_new + 2), "stream_window_update: tail_dst needs two carried rows");
-  const int esz = dtype == CUM_BF16 ? 2 : 4;
+  const int esz = is16(dtype) ? 2 : 4;
   const bool vec_ok = (Cp * esz) % 16 == 0 && ((uintptr_t)window & 15) == 0 && ((uintptr_t)fresh & 15) == 0 &&
                       ((uintptr_t)tail_dst & 15) == 0;
   if (keep <= kShiftRegs * 256 && vec_ok) {   // in place, one launch: every workgroup's kept rows fit its registers
@@ -164,7 +164,7 @@ extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t 
   CUM_REQUIRE(tmp, "stream_window_update: this window needs the scratch buffer (tmp)");
   const int64_t total = (int64_t)streams * rows * Cp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  if (dtype == CUM_BF16) {
+  if (is16(dtype)) {     // pure data movement: one 16-bit instantiation serves bf16 and f16
     hipLaunchKernelGGL(stream_window_shift_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)window,
                        (const __bf16 *)fresh, (__bf16 *)tmp, pitch, fresh_pitch, fresh_row0, streams, rows, n_new, Cp);
     hipLaunchKernelGGL(stream_window_store_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)tmp,
@@ -181,7 +181,7 @@ extern "C" int cum_stream_window_update(int32_t dtype, int32_t streams, int32_t 
 
 extern "C" int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows, int32_t Cp, const void *src,
                                     int64_t src_pitch, int32_t src_row0, void *dst, int64_t dst_pitch, void *stream) {
-  CUM_REQUIRE(dtype == CUM_F32 || dtype == CUM_BF16, "stream_tail_rows: dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(dtype), "stream_tail_rows: dtype must be CUM_F32, CUM_BF16 or CUM_F16");
   CUM_REQUIRE(streams >= 0 && rows > 0 && Cp > 0 && src_row0 >= 0 && src_pitch >= src_row0 + rows && dst_pitch >= rows,
               "stream_tail_rows: bad shape");
   if (streams == 0) return CUM_OK;
@@ -189,7 +189,7 @@ extern "C" int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)streams * rows * Cp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  if (dtype == CUM_BF16)
+  if (is16(dtype))         // pure data movement
     hipLaunchKernelGGL(stream_tail_rows_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)src, src_pitch,
                        src_row0, (__bf16 *)dst, dst_pitch, streams, rows, Cp);
   else
@@ -202,7 +202,7 @@ extern "C" int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows
 extern "C" int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t Cp, int32_t C, const void *y,
                                       int64_t y_pitch, void *tail, const float *bias, const void *skip,
                                       int64_t skip_pitch, void *out, int64_t out_pitch, int32_t relu, void *stream) {
-  CUM_REQUIRE(dtype == CUM_F32 || dtype == CUM_BF16, "stream_overlap_add: dtype must be CUM_F32 or CUM_BF16");
+  CUM_REQUIRE(dtype_ok(dtype), "stream_overlap_add: dtype must be CUM_F32, CUM_BF16 or CUM_F16");
   CUM_REQUIRE(streams >= 0 && L2 >= 2 && Cp > 0 && C > 0 && C <= Cp, "stream_overlap_add: bad shape");
   if (streams == 0) return CUM_OK;
   CUM_REQUIRE(y && tail && out && y_pitch >= L2 + 2 && out_pitch >= L2, "stream_overlap_add: bad buffer");
@@ -212,6 +212,10 @@ extern "C" int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2
   if (dtype == CUM_BF16) {
     hipLaunchKernelGGL(stream_overlap_add_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)y, y_pitch,
                        (__bf16 *)tail, bias, (const __bf16 *)skip, skip_pitch, (__bf16 *)out, out_pitch, streams, L2, Cp, C,
+                       relu);
+  } else if (dtype == CUM_F16) {
+    hipLaunchKernelGGL(stream_overlap_add_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16 *)y, y_pitch,
+                       (f16 *)tail, bias, (const f16 *)skip, skip_pitch, (f16 *)out, out_pitch, streams, L2, Cp, C,
                        relu);
   } else {
     hipLaunchKernelGGL(stream_overlap_add_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)y, y_pitch,

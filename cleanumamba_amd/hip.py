@@ -47,7 +47,9 @@ class GemmDesc(ctypes.Structure):
                 ("gate_only", c_i32), ("ldy", c_i64), ("mask_bits", c_i32), ("allow_split_k", c_i32)]
 
 
-CUM_F32, CUM_BF16 = 0, 1
+CUM_F32, CUM_BF16, CUM_F16 = 0, 1, 2
+HALF_TYPES = (torch.bfloat16, torch.float16)          # 16-bit element types the kernels read / write directly
+IO_TYPES = (torch.float32,) + HALF_TYPES
 EPI_BIAS, EPI_RELU, EPI_GLU, EPI_MASK, EPI_GLU_BWD = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); mirrors include/cleanumamba_hip.h one to one.
@@ -95,6 +97,13 @@ SIGNATURES = {
     "cum_cfft": (c_i32, [c_i32, c_i64, _P, _P, c_i32, _P]),
     "cum_stft_loss_fwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P]),
     "cum_stft_loss_bwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P, _P, _P]),
+    "cum_optim_state_elems": (c_i32, []),
+    "cum_optim_sumsq_parts": (c_i32, [c_i64]),
+    "cum_optim_sumsq": (c_i32, [_P, c_i64, _P, _P]),
+    "cum_optim_prepare": (c_i32, [_P, _P, c_i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i32, ctypes.c_float,
+                                  ctypes.c_float, c_i32, _P]),
+    "cum_optim_adam": (c_i32, [_P, _P, _P, _P, c_i64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                               _P]),
 }
 
 _lib = None
@@ -112,7 +121,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 5:
+        if L.cum_abi_version() != 6:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -132,7 +141,9 @@ def dtype_code(dtype):
         return CUM_F32
     if dtype == torch.bfloat16:
         return CUM_BF16
-    raise RuntimeError(f"cleanumamba_amd GEMM kernels take float32 or bfloat16 (got {dtype})")
+    if dtype == torch.float16:
+        return CUM_F16
+    raise RuntimeError(f"cleanumamba_amd kernels take float32, bfloat16 or float16 (got {dtype})")
 
 
 def require_gpu(*tensors, any_dtype=False):

@@ -88,7 +88,7 @@ def _proj(x, w, bias=None):
     if _PROJ_TN and bias is None and x.is_cuda and torch.is_grad_enabled() and w.requires_grad and w.shape[0] % 8 == 0 \
             and w.shape[1] % 8 == 0:
         cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-        if cd in (torch.bfloat16, torch.float32) and (cd == torch.bfloat16 or w.dtype == torch.float32):
+        if cd in hip.IO_TYPES and (cd in hip.HALF_TYPES or w.dtype == torch.float32):
             return _ProjFn.apply(x, w, cd)
     return F.linear(x, w, bias)
 
@@ -263,16 +263,23 @@ class Block(nn.Module):
         h = hidden_states.reshape(bsz, dm).contiguous()
         r = None if residual is None else residual.reshape(bsz, dm).contiguous()
         out, res_out = torch.empty_like(h), torch.empty_like(h)
-        c = lambda t: None if t is None else t.detach().contiguous()
+        keep = []        # contiguous copies must outlive the launch: ctypes passes bare addresses
+
+        def c(t):
+            if t is None:
+                return None
+            keep.append(t.detach().contiguous())
+            return keep[-1]
         with torch.cuda.device(h.device):
             hip.check(hip.lib().cum_mamba_step(
                 bsz, dm, d_inner, d_state, dt_rank, d_conv, float(self.norm.eps), hip.ptr(h), hip.ptr(r),
                 hip.ptr(c(self.norm.weight)), hip.ptr(c(self.norm.bias)), hip.ptr(c(m.in_proj.weight)),
                 hip.ptr(c(m.in_proj.bias)), hip.ptr(conv_state), hip.ptr(c(m.conv1d.weight).view(d_inner, d_conv)),
                 hip.ptr(c(m.conv1d.bias)), hip.ptr(c(m.x_proj.weight)), hip.ptr(c(m.dt_proj.weight)),
-                hip.ptr(c(m.dt_proj.bias)), hip.ptr(m._neg_exp_A_log()), hip.ptr(c(m.D)), hip.ptr(ssm_state),
+                hip.ptr(c(m.dt_proj.bias)), hip.ptr(c(m._neg_exp_A_log())), hip.ptr(c(m.D)), hip.ptr(ssm_state),
                 hip.ptr(c(m.out_proj.weight)), hip.ptr(c(m.out_proj.bias)), hip.ptr(out), hip.ptr(res_out),
                 hip.stream_ptr()))
+        del keep
         return out.view(bsz, 1, dm), res_out.view(bsz, 1, dm)
 
     def forward(self, hidden_states, residual=None, inference_params=None):

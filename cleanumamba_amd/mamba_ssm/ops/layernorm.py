@@ -20,7 +20,7 @@ def supported(hidden, norm):
     return (_ENABLED and hidden.is_cuda and isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine
             and norm.weight.dtype == torch.float32 and dim % 8 == 0 and dim <= 2048 and hidden.dim() == 3
             and hidden.stride(2) == 1 and hidden.stride(0) % 8 == 0 and hidden.stride(1) % 8 == 0
-            and hidden.data_ptr() % 16 == 0 and hidden.dtype in (torch.float32, torch.bfloat16))
+            and hidden.data_ptr() % 16 == 0 and hidden.dtype in hip.IO_TYPES)
 
 
 class AddLayerNormFn(torch.autograd.Function):
@@ -60,7 +60,8 @@ class AddLayerNormFn(torch.autograd.Function):
         lib = hip.lib()
         if dy is None:                                    # only the residual stream was used downstream
             dy = torch.zeros(bsz, L, dim, dtype=torch.float32, device=dev)
-        if dy.dtype not in (torch.float32, torch.bfloat16):
+        if dy.dtype not in hip.IO_TYPES or (dy.dtype != torch.float32 and ctx.h_dtype != torch.float32
+                                            and dy.dtype != ctx.h_dtype):
             dy = dy.float()
         dy = dy.contiguous()
         if dres_out is not None:
@@ -85,7 +86,8 @@ def add_layer_norm(hidden, residual, norm):
     """LayerNorm(hidden + residual) and the fp32 sum; output in the autocast dtype when autocast is on (what the
     projection that follows would cast it to), else in the weight dtype as nn.LayerNorm returns it."""
     out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else norm.weight.dtype
-    if out_dtype not in (torch.float32, torch.bfloat16):
+    if out_dtype not in hip.IO_TYPES or (hidden.dtype != torch.float32 and out_dtype != torch.float32
+                                         and out_dtype != hidden.dtype):
         out_dtype = torch.float32
     if residual is not None and residual.dtype != torch.float32:
         residual = residual.float()

@@ -8,7 +8,7 @@ B, C: (B, N, L) or (B, 1, N, L) -- but any strides are accepted; the kernels are
 tuned for channel-contiguous storage ((B, L, D) memory viewed as (B, D, L)), which
 is what ``Mamba.forward`` here passes.  No CPU path: tensors must be on the GPU.
 
-u, delta, z may be float32 or bfloat16 (what autocast hands over, as upstream takes fp16/bf16): the kernels
+u, delta, z may be float32, bfloat16 or float16 (what autocast hands over, as upstream takes fp16/bf16): the kernels
 read them and write out / du / ddelta / dz in that element type directly (cum_scan_shape.io_dtype); the
 recurrence, A, B, C, D, the bias and their gradients are fp32.
 """
@@ -136,7 +136,7 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
                       return_last_state=False):
     """out (and last_state (B, D, N) if requested); gate ``z`` is applied inside the kernel."""
     in_dtype = u.dtype
-    io = in_dtype if in_dtype in (torch.float32, torch.bfloat16) else torch.float32
+    io = in_dtype if in_dtype in hip.IO_TYPES else torch.float32
     u, delta = u.to(io), delta.to(io)
     z = None if z is None else z.to(io)
     A, B, C = A.float(), B.float(), C.float()
@@ -165,10 +165,12 @@ def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, 
     if C.stride(-1) != 1:
         C = C.contiguous()
     out = torch.empty_like(x)
+    # named locals: a contiguous() temporary must outlive the launch (ctypes passes bare addresses)
+    Dc = None if D is None else D.contiguous()
+    bias_c = None if dt_bias is None else dt_bias.contiguous()
     with torch.cuda.device(x.device):
         hip.check(hip.lib().cum_selective_state_update(
             bsz, dim, N, hip.ptr(state), hip.ptr(x), hip.ptr(dt), hip.ptr(A), hip.ptr(B), B.stride(0),
-            hip.ptr(C), C.stride(0), hip.ptr(None if D is None else D.contiguous()), hip.ptr(z),
-            hip.ptr(None if dt_bias is None else dt_bias.contiguous()), int(bool(dt_softplus)), hip.ptr(out),
+            hip.ptr(C), C.stride(0), hip.ptr(Dc), hip.ptr(z), hip.ptr(bias_c), int(bool(dt_softplus)), hip.ptr(out),
             hip.stream_ptr()))
     return out

@@ -17,9 +17,8 @@ Differences from the reference, on purpose:
   * ablation variants (LSTM, Mamba2, MambaS4, residual_projection, rms_norm,
     fused_add_norm) are out of scope and raise NotImplementedError.
 """
-import copy
-import itertools
 import os
+import warnings
 import time
 from functools import partial
 
@@ -135,7 +134,8 @@ class CleanUMamba(nn.Module):
         # streaming state
         self.total_time = 0
         self.cat_time = 0
-        self.frames = 0
+        self.frames = 0                 # frames denoised since reset_time_per_frame(): only for time_per_frame
+        self._std_frames = 0            # frames of the CURRENT stream: denominator of the running input std
         self.input_std = 0
         self.pending = torch.zeros(self.channels_input, 0, dtype=self.dtype, device=device)
         self.frame_length = self.valid_length(1)
@@ -176,11 +176,13 @@ class CleanUMamba(nn.Module):
             # one-column input: a workgroup per stream with the matrix staged in LDS (csrc/mamba_step.hip)
             xin = x.reshape(x.shape[0], x.shape[1]).contiguous()
             out = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+            # named locals: a contiguous() temporary must outlive the launch (ctypes passes bare addresses)
+            wc = w.detach().contiguous()
+            bc = None if conv.bias is None else conv.bias.detach().contiguous()
             with torch.cuda.device(x.device):
                 hip.check(hip.lib().cum_small_linear(x.shape[0], w.shape[0], w.shape[1], hip.ptr(xin), w.shape[1],
-                                                     hip.ptr(w.detach().contiguous()),
-                                                     hip.ptr(None if conv.bias is None else conv.bias.detach()),
-                                                     hip.ptr(out), w.shape[0], hip.stream_ptr()))
+                                                     hip.ptr(wc), hip.ptr(bc), hip.ptr(out), w.shape[0],
+                                                     hip.stream_ptr()))
             return out.unsqueeze(-1)
         return F.linear(x.transpose(1, 2), w, conv.bias).transpose(1, 2)
 
@@ -249,7 +251,11 @@ class CleanUMamba(nn.Module):
         E = self.encoder_n_layers
         dt = torch.float32
         if torch.is_autocast_enabled("cuda"):
-            dt = torch.bfloat16            # fp16 autocast also maps to bf16 MFMA (f32 accumulate)
+            # the autocast dtype is the element type of every activation and GEMM operand: float16 (torch's default,
+            # what the reference trains with: src/training/train.py:278-280) or bfloat16; accumulation is f32
+            dt = torch.get_autocast_dtype("cuda")
+            if dt not in hip.HALF_TYPES:
+                raise RuntimeError(f"autocast dtype {dt} is not supported by the fused conv stack")
         save = torch.is_grad_enabled()
         self._activate_pack_plan(dt)
         geo = cs.Geo(B, T0, 1)
@@ -356,7 +362,7 @@ class CleanUMamba(nn.Module):
         self.inference_params = None
         self.encoder_decoder_state = {}
         self.input_std = 0
-        self.frames = 0
+        self._std_frames = 0
         self.__dict__.pop("_hop_graph", None)    # it captured the addresses of the dropped state buffers
 
     @torch.no_grad()
@@ -382,8 +388,8 @@ class CleanUMamba(nn.Module):
         padding = torch.zeros(self.pending.shape[0], self.frame_length, device=self.pending.device, dtype=self.dtype)
         frames_before, time_before = self.frames, self.total_time
         out = self.feed_batch(padding)[:, :pending_length]
-        self.reset_stream()
-        self.frames, self.total_time = frames_before, time_before
+        self.reset_stream()              # the next clip starts a fresh stream: its running std starts over too
+        self.frames, self.total_time = frames_before, time_before     # the padding frame is not a timed frame
         return out
 
     @torch.no_grad()
@@ -410,11 +416,14 @@ class CleanUMamba(nn.Module):
         denoised_frames = []
         while self.pending.shape[1] >= self.frame_length:
             self.frames += 1
+            self._std_frames = getattr(self, "_std_frames", 0) + 1
             frame = self.pending[:, :self.frame_length]
             if self.normalize_input:
-                # running mean of the per-frame std, per stream (src/network/CleanUMamba.py:399-401)
-                self.input_std = (frame.std(dim=1, keepdim=True) + 1e-3) / self.frames \
-                    + (1 - 1 / self.frames) * self.input_std
+                # running mean of the per-frame std, per stream (src/network/CleanUMamba.py:399-401).  The mean runs
+                # over the frames of THIS stream (the reference shares one counter with time_per_frame and never
+                # resets either; a stream here ends at flush(), so the counter of its running mean ends there too)
+                n = self._std_frames
+                self.input_std = (frame.std(dim=1, keepdim=True) + 1e-3) / n + (1 - 1 / n) * self.input_std
                 frame = frame / self.input_std
             out = self._hop(frame)[:, :total_stride]
             if self.normalize_input:
@@ -425,6 +434,20 @@ class CleanUMamba(nn.Module):
         if denoised_frames:
             return torch.cat(denoised_frames, 1)
         return torch.zeros(S, 0, device=noisy_input.device)
+
+    @property
+    def hop_graph_status(self):
+        """"off" (disabled), "pending" (no hop captured yet), "captured", or "failed: <error>" (hops run eagerly)."""
+        if not getattr(self, "use_hop_graph", False):
+            return "off"
+        hg = self.__dict__.get("_hop_graph")
+        if hg is None:
+            return "pending"
+        return "failed: " + hg["error"] if hg.get("failed") else "captured"
+
+    def _weights_version(self):
+        # in-place updates of any parameter (optimizer steps, load_state_dict) bump these counters
+        return sum(p._version for p in self.parameters())
 
     def _hop(self, frame):
         """Eager first hop (it creates the state buffers), hipGraph replay afterwards."""
@@ -438,6 +461,8 @@ class CleanUMamba(nn.Module):
         if not (getattr(self, "use_hop_graph", False) and frame.is_cuda and self.encoder_decoder_state):
             return denoise(frame)
         hg = self.__dict__.get("_hop_graph")
+        if hg is not None and not hg.get("failed") and hg.get("weights") != self._weights_version():
+            hg = None          # the graph replays kernels on the weight copies of its capture: capture again
         if hg is None:
             hg = {"failed": False}
             try:
@@ -448,7 +473,7 @@ class CleanUMamba(nn.Module):
                     saved = {k: v.clone() for k, v in self.encoder_decoder_state.items()}
                     cache = {k: tuple(t.clone() for t in v)
                              for k, v in self.inference_params.key_value_memory_dict.items()}
-                    denoise(static_in, inplace=True)
+                    denoise(static_in, True)
                     # undo the warm-up's state changes
                     for k, v in saved.items():
                         self.encoder_decoder_state[k].copy_(v)
@@ -458,11 +483,14 @@ class CleanUMamba(nn.Module):
                 torch.cuda.current_stream().wait_stream(stream)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    static_out = denoise(static_in, inplace=True)
+                    static_out = denoise(static_in, True)
                 # capture does not execute: state is untouched
-                hg.update(graph=graph, static_in=static_in, static_out=static_out, shape=tuple(frame.shape))
+                hg.update(graph=graph, static_in=static_in, static_out=static_out, shape=tuple(frame.shape),
+                          weights=self._weights_version())
             except Exception as exc:                 # noqa: BLE001 - capture is an optimisation; stay eager
                 hg = {"failed": True, "error": repr(exc)}
+                warnings.warn(f"CleanUMamba: hipGraph capture of the streaming hop failed ({exc!r}); this stream "
+                              "runs its hops eagerly (2-4x slower).  See model.hop_graph_status.")
             self.__dict__["_hop_graph"] = hg
         if hg.get("failed") or hg["shape"] != tuple(frame.shape):
             return denoise(frame)
@@ -471,6 +499,7 @@ class CleanUMamba(nn.Module):
         return hg["static_out"].clone()
 
     def _denoise_frame_fused(self, frame, inplace=True):
+        assert inplace, "the fused hop always updates its stream state in place"
         with cs.small_m_gemms():
             return self._denoise_frame_fused_impl(frame)
 
@@ -617,45 +646,39 @@ class CleanUMamba(nn.Module):
 
     # ------------------------------------------------------------ pruned loading
     def load_pruned_state_dict(self, pruned_state_dict):
-        """Adopt the (smaller, odd) shapes of a pruned checkpoint, then load it strictly.
-        Interface of src/network/CleanUMamba.py:492-550."""
-
-        def adopt_shapes(module, local_sd, prefix=""):
-            persistent = {k: v for k, v in module._buffers.items() if k not in module._non_persistent_buffers_set}
-            for name, param in itertools.chain(module._parameters.items(), persistent.items()):
-                if param is None:
-                    continue
-                key = prefix + name
-                if key not in local_sd:
-                    print(f"Error cant find {key} in {module}")
-                    continue
-                param.data = copy.deepcopy(local_sd[key].data).to(device=param.device)
-                if isinstance(module, (nn.LayerNorm, nn.Conv1d, nn.ConvTranspose1d, nn.Linear)):
-                    weight = module.weight
-                    if isinstance(module, nn.LayerNorm):
-                        module.normalized_shape = tuple(weight.shape)
-                    if isinstance(module, nn.Conv1d):
-                        module.in_channels = weight.shape[1]
-                        module.out_channels = weight.shape[0]
-                        if module.groups > 1:
-                            module.groups = weight.shape[0]
-                    if isinstance(module, nn.ConvTranspose1d):
-                        module.in_channels = weight.shape[0]
-                        module.out_channels = weight.shape[1]
-                    if isinstance(module, nn.Linear):
-                        module.in_features = weight.shape[1]
-                        module.out_features = weight.shape[0]
-            for name, child in module._modules.items():
-                if child is not None:
-                    child_prefix = prefix + name + "."
-                    adopt_shapes(child, {k: v for k, v in local_sd.items() if k.startswith(child_prefix)},
-                                 child_prefix)
-            if module.__class__.__name__ == "Mamba":
+        """Load a structurally pruned checkpoint (interface of src/network/CleanUMamba.py:492-550, used by
+        src/examples/loading_pretrained_models.py:12-13): every parameter takes the checkpoint's shape, the
+        modules' size attributes follow their new weights, then the dict is loaded strictly.  Keys absent from the
+        checkpoint keep their current tensors and are reported by the strict load."""
+        resize = {
+            nn.LayerNorm: lambda m, w: setattr(m, "normalized_shape", tuple(w.shape)),
+            nn.Linear: lambda m, w: (setattr(m, "out_features", w.shape[0]), setattr(m, "in_features", w.shape[1])),
+            nn.ConvTranspose1d: lambda m, w: (setattr(m, "in_channels", w.shape[0]),
+                                              setattr(m, "out_channels", w.shape[1])),
+            # a depthwise conv (the Mamba conv1d) stays depthwise: groups follows the channel count.  in_channels is
+            # set to weight.shape[1] (= 1 there) as the reference does; F.conv1d only looks at the tensors.
+            nn.Conv1d: lambda m, w: (setattr(m, "out_channels", w.shape[0]), setattr(m, "in_channels", w.shape[1]),
+                                     setattr(m, "groups", w.shape[0] if m.groups > 1 else m.groups)),
+        }
+        for prefix, module in self.named_modules():
+            dot = prefix + "." if prefix else ""
+            own = list(module._parameters.items()) + [(k, b) for k, b in module._buffers.items()
+                                                       if k not in module._non_persistent_buffers_set]
+            for name, tensor in own:
+                src = pruned_state_dict.get(dot + name)
+                if tensor is not None and src is not None:
+                    tensor.data = src.detach().clone().to(device=tensor.device)
+            if getattr(module, "weight", None) is not None:
+                for kind, fix in resize.items():
+                    if isinstance(module, kind):
+                        fix(module, module.weight)
+                        break
+        for module in self.modules():
+            if type(module).__name__ == "Mamba":       # by name, as the reference does (:540): pickled models qualify
+                module.d_model = module.in_proj.in_features
+                module.d_inner = module.x_proj.in_features
                 module.dt_rank = module.dt_proj.in_features
                 module.d_state = (module.x_proj.out_features - module.dt_rank) // 2
-                module.d_inner = module.x_proj.in_features
-                module.d_model = module.in_proj.in_features
                 module.expand = module.d_inner / module.d_model
-
-        adopt_shapes(self, pruned_state_dict)
         self.load_state_dict(pruned_state_dict, strict=True)
+        self.invalidate_packed_weights()

@@ -59,7 +59,7 @@ class Geo:
 
 
 def bk_of(dtype):
-    return 64 if dtype == torch.bfloat16 else 32
+    return 64 if dtype in hip.HALF_TYPES else 32
 
 
 # ------------------------------------------------------------------ GEMM launcher
@@ -144,9 +144,11 @@ def colsum(X, x_off, ld, M, n):
 _INDEX_CACHE = {}
 
 
-def gather(src_flat, idx32, dtype):
-    """[src_flat[idx] or 0 where idx < 0] as ``dtype``; csrc/pack.hip (32-bit index, conversion in the same pass)."""
-    out = torch.empty(idx32.numel(), dtype=dtype, device=src_flat.device)
+def gather(src_flat, idx32, dtype, out=None):
+    """[src_flat[idx] or 0 where idx < 0] as ``dtype``; csrc/pack.hip (32-bit index, conversion in the same pass).
+    ``out``: write into this buffer (same length and dtype) instead of allocating."""
+    if out is None or out.numel() != idx32.numel() or out.dtype != dtype or out.device != src_flat.device:
+        out = torch.empty(idx32.numel(), dtype=dtype, device=src_flat.device)
     if not src_flat.is_contiguous():
         src_flat = src_flat.contiguous()
     with torch.cuda.device(src_flat.device):
@@ -180,6 +182,7 @@ class PackPlan:
         self.dirty = False
         self.gidx = {}                        # dtype -> (device index tensor, [(reqkey, start, numel, shape)])
         self.current = {}
+        self.big = {}                         # dtype -> the flat buffer all packed operands of that dtype are views of
 
     def record(self, key, src, idx, shape, dtype):
         rk = (key, src.data_ptr(), dtype)
@@ -192,10 +195,14 @@ class PackPlan:
         self.dirty = True
 
     def refresh(self):
-        """Recompute every recorded pack from the current parameter values."""
-        self.current = {}
+        """Recompute every recorded pack from the current parameter values.  While the set of recorded packs is
+        unchanged the packed operands are rewritten IN PLACE: a captured streaming hop (CleanUMamba._hop) replays
+        kernels that hold their addresses."""
         if not self.reqs:
+            self.current = {}
             return
+        if self.dirty:
+            self.current, self.big = {}, {}
         dev = self.params[0].device
         if self.dirty:
             self.gidx = {}
@@ -214,9 +221,11 @@ class PackPlan:
             flat = torch.cat([p.detach().reshape(-1) for p in self.params])
             for dt, (gi, metas) in self.gidx.items():
                 # cast first: the gather then reads 2-byte elements of a source that stays cache-resident
-                big = gather(flat if flat.dtype == dt else flat.to(dt), gi, dt)
-                for rk, start, n, shape in metas:
-                    self.current[rk] = big[start:start + n].view(shape)
+                big = gather(flat if flat.dtype == dt else flat.to(dt), gi, dt, out=self.big.get(dt))
+                if self.big.get(dt) is not big:
+                    self.big[dt] = big
+                    for rk, start, n, shape in metas:
+                        self.current[rk] = big[start:start + n].view(shape)
 
 
 _ACTIVE_PLAN = None

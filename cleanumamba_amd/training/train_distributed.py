@@ -5,8 +5,9 @@ apply_gradient_allreduce).
 The reference flattens all 41.4 M gradients into one buffer AFTER backward, runs a
 single blocking all-reduce, divides, and copies everything back (two extra
 full-gradient passes over HBM, no overlap).  Here, one process per GPU:
-  * gradients live permanently in a few flat fp32 buckets (``p.grad`` is a view),
-    so there is no flatten and no copy-back;
+  * parameters and gradients live permanently in flat fp32 buffers (``p.data`` / ``p.grad``
+    are views; a bucket is a contiguous slice), so there is no flatten and no copy-back,
+    and the optimizer section runs on the same buffers (training/flat_optim.py);
   * a bucket's all-reduce is issued from a post-accumulate hook as soon as its last
     gradient has been produced, on the communicator's own stream, overlapping the
     rest of backward; buckets are filled in reverse registration order, which is
@@ -42,51 +43,38 @@ def init_distributed(rank, num_gpus, group_name=None, dist_backend="nccl", dist_
 
 
 class GradBuckets:
-    """Flat gradient storage + overlapped all-reduce for one module."""
+    """Flat gradient storage + overlapped all-reduce for one module.
 
-    def __init__(self, module, bucket_bytes=32 << 20, process_group=None):
+    Parameters and gradients are views of two flat fp32 buffers (training/flat_optim.py::FlatParams, laid out in
+    gradient-ready order); a bucket is a contiguous slice of the gradient buffer.  ``require_sync = False`` skips the
+    exchange for one backward (gradient accumulation: the reference all-reduces on every micro-step,
+    src/training/train_distributed.py:145-148 -- correct but wasteful; the sum of the micro-step gradients is
+    exchanged once at the accumulation boundary here).  Without an initialised process group the class is only the
+    flat storage (world size 1)."""
+
+    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, flat=None):
+        from .flat_optim import FlatParams
         self.group = process_group
-        self.world = dist.get_world_size(process_group)
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        backend = dist.get_backend(process_group)
-        self.use_avg = backend == "nccl"
-        self.buckets = []          # (flat, [params], pending_count)
-        self.where = {}            # id(param) -> (bucket index, view)
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.use_avg = self.distributed and dist.get_backend(process_group) == "nccl"
+        self.flat = flat if flat is not None else FlatParams(module)
+        self.params = self.flat.params
+        self.require_sync = True
+        self.buckets = []          # [flat gradient slice, [params], pending count]
+        self.where = {}            # id(param) -> (bucket index, gradient view)
         self.handles = []
         self._armed = False
-        order = list(reversed(self.params))
-        by_key = {}
-        for p in order:
-            by_key.setdefault((p.dtype, p.device), []).append(p)
-        for (dtype, device), plist in by_key.items():
-            cap = max(1, bucket_bytes // torch.empty((), dtype=dtype).element_size())
-            cur, n = [], 0
-            for p in plist:
-                if cur and n + p.numel() > cap:
-                    self._make_bucket(cur, dtype, device)
-                    cur, n = [], 0
-                cur.append(p)
-                n += p.numel()
-            if cur:
-                self._make_bucket(cur, dtype, device)
+        for start, end, members in self.flat.slices(bucket_bytes):
+            plist = [self.params[i] for i in members]
+            for i in members:
+                self.where[id(self.params[i])] = (len(self.buckets), self.flat.grad_views[i])
+            self.buckets.append([self.flat.grad[start:end], plist, len(plist)])
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
 
-    def _make_bucket(self, plist, dtype, device):
-        flat = torch.zeros(sum(p.numel() for p in plist), dtype=dtype, device=device)
-        idx, off = len(self.buckets), 0
-        for p in plist:
-            view = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-            self.where[id(p)] = (idx, view)
-            p.grad = view
-        self.buckets.append([flat, plist, len(plist)])
-
     def zero_grad(self):
-        for flat, plist, _ in self.buckets:
-            flat.zero_()
-            for p in plist:
-                p.grad = self.where[id(p)][1]
+        self.flat.zero_grad()
 
     def _hook(self, p):
         idx, view = self.where[id(p)]
@@ -95,6 +83,8 @@ class GradBuckets:
             if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
             p.grad = view
+        if self.world == 1 or not self.require_sync:
+            return
         if not self._armed:
             self._armed = True
             for b in self.buckets:
@@ -106,8 +96,6 @@ class GradBuckets:
             self._launch(b[0])
 
     def _launch(self, flat):
-        if self.world == 1:
-            return
         if self.use_avg:
             self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
         else:

@@ -1,11 +1,19 @@
 """One optimisation step with the semantics of the reference's hot loop
-(src/training/train.py:255-312): zero grads, loss_fn under optional autocast,
-(scaled) backward with the gradient exchange inside it, unscale, clip_grad_norm_(10),
-Adam step (lr 1e-4, betas .9/.999, eps 1e-8, fused), LR schedule.
+(src/training/train.py:255-312): zero grads, ``repeats`` micro-steps of loss_fn under optional autocast with
+(scaled) backward of loss / repeats -- the gradient exchange inside the last one --, unscale,
+clip_grad_norm_(10), Adam step (lr 1e-4, betas .9/.999, eps 1e-8), loss-scale update, LR schedule.
 
-Host-side differences: no per-step ``loss.item()`` -- the loss stays
-on the device and is synchronised only when the caller reads it.
+Host-side differences:
+  * no per-step ``loss.item()`` -- the loss stays on the device and is synchronised only when the caller reads it;
+  * on the GPU, parameters / gradients / Adam moments are flat buffers and the optimizer section is three launches
+    with device-side loss scaling (training/flat_optim.py, csrc/optim.hip) instead of ~10 multi-tensor launches over
+    103 tensors and GradScaler's device->host sync;
+  * with static shapes the whole step (forward, loss, backward, optimizer section) is captured ONCE in a hipGraph and
+    replayed: ~430 launches per step leave the host's critical path (``use_graph``; single-process runs only -- a
+    captured collective is not something this pool can validate, so ranks > 1 run eagerly).
 """
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -18,53 +26,158 @@ DEFAULT_LOSS = {"ell_p": 1, "ell_p_lambda": 1, "stft_lambda": 1,
                 "stft_config": {"sc_lambda": 0.5, "mag_lambda": 0.5, "band": "full",
                                 "hop_sizes": [50, 120, 240], "win_lengths": [240, 600, 1200],
                                 "fft_sizes": [512, 1024, 2048]}}
+GRAPH_WARMUP_STEPS = 3       # eager steps before the capture (lazy initialisation, allocator warm-up)
 
 
 class TrainStep:
-    def __init__(self, net, optimization=None, loss_config=None, autocast_dtype=None, iteration=0):
+    """``step = TrainStep(net, ...); loss, grad_norm = step(clean, noisy)``.
+
+    repeats: gradient-accumulation micro-steps per optimizer step (reference: ``repeats`` of
+      src/training/train.py:282-300).  ``__call__`` splits the batch it is given into ``repeats`` equal micro-batches;
+      ``micro_step`` / ``optimizer_step`` expose the two halves for loaders that deliver micro-batches one by one.
+    flat_optimizer: None = on for fp32 CUDA models.  Off: torch.optim.Adam + clip_grad_norm_ + GradScaler.
+    use_graph: None = on for single-process CUDA runs with the flat optimizer."""
+
+    def __init__(self, net, optimization=None, loss_config=None, autocast_dtype=None, iteration=0, repeats=1,
+                 flat_optimizer=None, use_graph=None):
         self.net = net
         self.opt_cfg = dict(DEFAULT_OPTIM, **(optimization or {}))
         self.loss_cfg = dict(DEFAULT_LOSS, **(loss_config or {}))
+        self.repeats = int(repeats)
         dev = next(net.parameters()).device
-        fused = bool(self.opt_cfg["fused_adam"]) and dev.type == "cuda"
-        self.optimizer = torch.optim.Adam(net.parameters(), lr=self.opt_cfg["learning_rate"],
-                                          betas=tuple(self.opt_cfg["betas"]), eps=self.opt_cfg["eps"],
-                                          fused=fused, weight_decay=self.opt_cfg["weight_decay"])
+        self.buckets = getattr(net, "grad_buckets", None)
+        if flat_optimizer is None:
+            flat_optimizer = dev.type == "cuda" and all(p.dtype == torch.float32 for p in net.parameters())
+        self.autocast_dtype = autocast_dtype
+        fp16 = autocast_dtype == torch.float16
+        self.scaler = None
+        if flat_optimizer:
+            from .flat_optim import FlatAdam
+            from .train_distributed import GradBuckets
+            if self.buckets is None:          # single process: flat storage only, no exchange
+                self.buckets = net.grad_buckets = GradBuckets(net)
+            self.optimizer = FlatAdam(self.buckets.flat, lr=self.opt_cfg["learning_rate"],
+                                      betas=tuple(self.opt_cfg["betas"]), eps=self.opt_cfg["eps"],
+                                      weight_decay=self.opt_cfg["weight_decay"],
+                                      max_grad_norm=self.opt_cfg["clip_grad_norm_max"], loss_scaling=fp16)
+        else:
+            fused = bool(self.opt_cfg["fused_adam"]) and dev.type == "cuda"
+            self.optimizer = torch.optim.Adam(net.parameters(), lr=self.opt_cfg["learning_rate"],
+                                              betas=tuple(self.opt_cfg["betas"]), eps=self.opt_cfg["eps"],
+                                              fused=fused, weight_decay=self.opt_cfg["weight_decay"])
+            # fp16 autocast needs loss scaling (reference: GradScaler, train.py:158-160); bf16 does not
+            self.scaler = torch.amp.GradScaler("cuda") if fp16 else None
+        self.flat = flat_optimizer
         self.scheduler = LinearWarmupCosineDecay(self.optimizer, lr_max=self.opt_cfg["learning_rate"],
                                                  n_iter=self.opt_cfg["n_iters"], iteration=iteration, divider=25,
                                                  warmup_proportion=0.05, phase=("linear", "cosine"))
         self.mrstft = None
         if self.loss_cfg["stft_lambda"] > 0:
             self.mrstft = MultiResolutionSTFTLoss(**self.loss_cfg["stft_config"]).to(dev)
-        self.autocast_dtype = autocast_dtype
-        # fp16 autocast needs loss scaling (reference: GradScaler, train.py:158-160); bf16 does not
-        self.scaler = torch.amp.GradScaler("cuda") if autocast_dtype == torch.float16 else None
-        self.buckets = getattr(net, "grad_buckets", None)
+        world = self.buckets.world if self.buckets is not None else 1
+        if use_graph is None:
+            use_graph = self.flat and dev.type == "cuda" and world == 1
+        if use_graph and (not self.flat or world != 1):
+            raise ValueError("use_graph needs the flat optimizer and a single process")
+        self.use_graph = bool(use_graph)
+        self._graph = None              # {"graph", "clean", "noisy", "loss"} | {"failed": error}
+        self._eager_steps = 0
 
+    # ------------------------------------------------------------------ pieces
     def zero_grad(self):
         if self.buckets is not None:
             self.buckets.zero_grad()
         else:
             self.optimizer.zero_grad(set_to_none=True)
 
-    def __call__(self, clean_audio, noisy_audio):
-        """Returns (loss tensor on device, grad_norm tensor)."""
-        self.zero_grad()
+    def _loss(self, clean_audio, noisy_audio):
         kw = {k: v for k, v in self.loss_cfg.items() if k != "stft_config"}
         if self.autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
-                loss, _ = loss_fn(self.net, (clean_audio, noisy_audio), mrstftloss=self.mrstft, **kw)
+                return loss_fn(self.net, (clean_audio, noisy_audio), mrstftloss=self.mrstft, **kw)[0]
+        return loss_fn(self.net, (clean_audio, noisy_audio), mrstftloss=self.mrstft, **kw)[0]
+
+    def micro_step(self, clean_audio, noisy_audio, last=True):
+        """Forward + backward of one micro-batch; gradients accumulate.  ``last``: this backward closes the
+        accumulation window, so it carries the gradient exchange."""
+        if self.buckets is not None:
+            self.buckets.require_sync = bool(last)
+        loss = self._loss(clean_audio, noisy_audio)
+        scaled = loss / self.repeats if self.repeats > 1 else loss
+        if self.flat:
+            self.optimizer.scale_loss(scaled).backward()
+        elif self.scaler is not None:
+            self.scaler.scale(scaled).backward()
         else:
-            loss, _ = loss_fn(self.net, (clean_audio, noisy_audio), mrstftloss=self.mrstft, **kw)
+            scaled.backward()
+        return loss.detach()
+
+    def optimizer_step(self, write_lr=True):
+        """unscale -> clip -> Adam -> scale update.  Returns the gradient norm (device scalar)."""
+        if self.flat:
+            self.optimizer.step(write_lr=write_lr)
+            return self.optimizer.grad_norm
         if self.scaler is not None:
-            self.scaler.scale(loss).backward()
             self.scaler.unscale_(self.optimizer)
             grad_norm = nn.utils.clip_grad_norm_(self.net.parameters(), self.opt_cfg["clip_grad_norm_max"])
             self.scaler.step(self.optimizer)
             self.scaler.update()
         else:
-            loss.backward()
             grad_norm = nn.utils.clip_grad_norm_(self.net.parameters(), self.opt_cfg["clip_grad_norm_max"])
             self.optimizer.step()
+        return grad_norm
+
+    def _body(self, clean_audio, noisy_audio, write_lr=True):
+        self.zero_grad()
+        if self.repeats == 1:
+            loss = self.micro_step(clean_audio, noisy_audio)
+        else:
+            if clean_audio.shape[0] % self.repeats:
+                raise ValueError(f"batch of {clean_audio.shape[0]} clips does not split into {self.repeats} micro-batches")
+            parts = zip(clean_audio.chunk(self.repeats), noisy_audio.chunk(self.repeats))
+            losses = [self.micro_step(c, n, last=(i == self.repeats - 1)) for i, (c, n) in enumerate(parts)]
+            loss = torch.stack(losses).mean()
+        return loss, self.optimizer_step(write_lr=write_lr)
+
+    # ------------------------------------------------------------------ hipGraph
+    @property
+    def graph_status(self):
+        if not self.use_graph:
+            return "off"
+        if self._graph is None:
+            return "pending"
+        return "failed: " + self._graph["failed"] if "failed" in self._graph else "captured"
+
+    def _capture(self, clean_audio, noisy_audio):
+        g = {"clean": clean_audio.clone(), "noisy": noisy_audio.clone()}
+        try:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss, norm = self._body(g["clean"], g["noisy"], write_lr=False)
+            g.update(graph=graph, loss=loss, norm=norm)
+        except Exception as exc:          # noqa: BLE001 - capture is an optimisation; stay eager
+            g = {"failed": repr(exc)}
+            warnings.warn(f"TrainStep: hipGraph capture of the train step failed ({exc!r}); steps run eagerly")
+        self._graph = g
+
+    def __call__(self, clean_audio, noisy_audio):
+        """Returns (loss tensor on device, grad_norm tensor)."""
+        g = self._graph
+        if self.use_graph and g is None and self._eager_steps >= GRAPH_WARMUP_STEPS:
+            self._capture(clean_audio, noisy_audio)       # capture does not execute: the replay below is this step
+            g = self._graph
+        if self.use_graph and g is not None and "graph" in g and g["clean"].shape == clean_audio.shape \
+                and g["clean"].dtype == clean_audio.dtype:
+            if self.buckets is not None and not self.buckets.flat.intact():
+                raise RuntimeError("parameters were re-allocated after the train step was captured; build a new TrainStep")
+            g["clean"].copy_(clean_audio)
+            g["noisy"].copy_(noisy_audio)
+            self.optimizer.write_lr()
+            g["graph"].replay()
+            loss, grad_norm = g["loss"].clone(), g["norm"].clone()
+        else:
+            loss, grad_norm = self._body(clean_audio, noisy_audio)
+            self._eager_steps += 1
         self.scheduler.step()
-        return loss.detach(), grad_norm
+        return loss, grad_norm

@@ -13,69 +13,55 @@ import torch.nn.functional as F
 from .stft_loss import MultiResolutionSTFTLoss
 
 
+@torch.no_grad()
 def weight_scaling_init(layer):
-    """w, b /= sqrt(10 * std(w))  (weight rescaling of arXiv:1911.13254)."""
-    w = layer.weight.detach()
-    alpha = 10.0 * w.std()
-    layer.weight.data /= torch.sqrt(alpha)
-    layer.bias.data /= torch.sqrt(alpha)
+    """Divide a conv layer's weight and bias by sqrt(10 * std(weight)) -- the rescaling of arXiv:1911.13254 the
+    reference applies to every Conv1d / ConvTranspose1d at construction (src/util/util.py:174-181)."""
+    scale = layer.weight.std().mul(10.0).sqrt()
+    layer.weight.div_(scale)
+    layer.bias.div_(scale)
 
 
-def anneal_linear(start, end, proportion):
-    return start + proportion * (end - start)
-
-
-def anneal_cosine(start, end, proportion):
-    cos_val = cos(pi * proportion) + 1
-    return end + (start - end) / 2 * cos_val
-
-
-class Phase:
-    def __init__(self, start, end, n_iter, cur_iter, anneal_fn):
-        self.start, self.end = start, end
-        self.n_iter = n_iter
-        self.anneal_fn = anneal_fn
-        self.n = cur_iter
-
-    def step(self):
-        self.n += 1
-        return self.anneal_fn(self.start, self.end, self.n / self.n_iter)
-
-    def reset(self):
-        self.n = 0
-
-    @property
-    def is_done(self):
-        return self.n >= self.n_iter
+_RAMPS = {
+    # value at fraction f in [0, 1] of a segment that starts at a and ends at b
+    "linear": lambda a, b, f: a + (b - a) * f,
+    "cosine": lambda a, b, f: b + (a - b) * 0.5 * (1.0 + cos(pi * f)),
+}
 
 
 class LinearWarmupCosineDecay:
-    """Linear warm-up from lr_max/divider to lr_max over ``warmup_proportion`` of the run,
-    then cosine decay to lr_max/divider/1e4."""
+    """Learning-rate schedule of the reference's training loop (src/util/util.py:115-161, driven from
+    src/training/train.py:236-244, 312) as a closed form of the step count.
+
+    With W = int(n_iter * warmup_proportion) warm-up steps and lo = lr_max / divider, the k-th call of ``step()``
+    (k = 1, 2, ..., counted from ``iteration`` when resuming) sets
+        k <= W :  ramp[0] from lo     to lr_max     at fraction k / W
+        k >  W :  ramp[1] from lr_max to lo / 1e4   at fraction (k - W) / (n_iter - W)
+    and the count wraps to zero after n_iter steps (the reference restarts both segments)."""
 
     def __init__(self, optimizer, lr_max, n_iter, iteration=0, divider=25, warmup_proportion=0.3,
                  phase=("linear", "cosine")):
         self.optimizer = optimizer
-        phase1 = int(n_iter * warmup_proportion)
-        phase2 = n_iter - phase1
-        lr_min = lr_max / divider
-        phase_map = {"linear": anneal_linear, "cosine": anneal_cosine}
-        self.lr_phase = [
-            Phase(lr_min, lr_max, phase1, iteration, phase_map[phase[0]]),
-            Phase(lr_max, lr_min / 1e4, phase2, max(0, iteration - phase1), phase_map[phase[1]]),
-        ]
-        self.phase = 0 if iteration < phase1 else 1
+        self.n_iter = n_iter
+        self.warmup = int(n_iter * warmup_proportion)
+        self.lr_max = lr_max
+        self.lr_lo = lr_max / divider
+        self.ramps = (_RAMPS[phase[0]], _RAMPS[phase[1]])
+        self.k = iteration
+
+    def lr_at(self, k):
+        """Learning rate in force after k steps of a run (1 <= k <= n_iter)."""
+        if k <= self.warmup:
+            return self.ramps[0](self.lr_lo, self.lr_max, k / self.warmup)
+        return self.ramps[1](self.lr_max, self.lr_lo / 1e4, (k - self.warmup) / (self.n_iter - self.warmup))
 
     def step(self):
-        lr = self.lr_phase[self.phase].step()
+        self.k += 1
+        lr = self.lr_at(self.k)
         for group in self.optimizer.param_groups:
             group["lr"] = lr
-        if self.lr_phase[self.phase].is_done:
-            self.phase += 1
-        if self.phase >= len(self.lr_phase):
-            for phase in self.lr_phase:
-                phase.reset()
-            self.phase = 0
+        if self.k >= self.n_iter:
+            self.k = 0
         return lr
 
 

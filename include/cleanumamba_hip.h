@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 5
+#define CUM_ABI_VERSION 6
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -68,7 +68,7 @@ typedef struct {
   int64_t B_sb, B_sn, B_sl;          /* Bm */
   int64_t C_sb, C_sn, C_sl;          /* Cm */
   int32_t delta_softplus;            /* apply softplus (threshold 20) to delta + bias */
-  int32_t io_dtype;                  /* CUM_F32 / CUM_BF16: element type of u, delta, z, out and of dout, du,
+  int32_t io_dtype;                  /* CUM_F32 / CUM_BF16 / CUM_F16: element type of u, delta, z, out and of dout, du,
                                         ddelta, dz (what autocast hands over); all arithmetic and every other
                                         tensor stay fp32 */
 } cum_scan_shape;
@@ -120,7 +120,7 @@ typedef struct {
   int64_t x_sb, x_sd, x_sl;
   int64_t y_sb, y_sd, y_sl;
   int32_t silu;
-  int32_t io_dtype;                  /* CUM_F32 / CUM_BF16: element type of x, y, dy, dx; weights stay fp32 */
+  int32_t io_dtype;                  /* CUM_F32 / CUM_BF16 / CUM_F16: element type of x, y, dy, dx; weights stay fp32 */
 } cum_conv_shape;
 
 int cum_causal_conv1d_fwd(const cum_conv_shape *s, const void *x, const float *weight,
@@ -169,10 +169,12 @@ int cum_causal_conv1d_update(int32_t batch, int32_t dim, int32_t width, float *c
  * dtype: element type of A, W, res, out, aux; accumulation is always f32. */
 #define CUM_F32 0
 #define CUM_BF16 1
+#define CUM_F16 2   /* IEEE half: what torch.autocast("cuda") hands over by default (the reference's training mode,
+                       configs/config.json:14, src/training/train.py:158-160, 278-280) */
 
 typedef struct {
   int32_t dtype, epilogue;
-  int32_t M, N, K;           /* N multiple of 16 (32 for GLU); K multiple of 64 (bf16) / 32 (f32) */
+  int32_t M, N, K;           /* N multiple of 16 (32 for GLU); K multiple of 64 (bf16, f16) / 32 (f32) */
   int64_t lda, ldw, ldc, ldr, ldz;
   int32_t pitch, valid;
   int32_t n_store;           /* output columns written (multiple of 4) */
@@ -343,6 +345,27 @@ int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows, int32_t C
 int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t Cp, int32_t C, const void *y,
                            int64_t y_pitch, void *tail, const float *bias, const void *skip, int64_t skip_pitch,
                            void *out, int64_t out_pitch, int32_t relu, void *stream);
+
+/* ---- optimizer section of the train step on flat buffers (src/training/train.py:303-310: scaler.unscale_,
+ * clip_grad_norm_(clip_grad_norm_max), scaler.step(Adam), scaler.update; Adam built at :145-148 with betas / eps /
+ * weight_decay of configs/config.json, GradScaler at :158-160).  p, g, m, v: f32 buffers of n elements, 16-byte
+ * aligned (all parameters of the model back to back; training/flat_optim.py).  `state`: cum_optim_state_elems() f32 in
+ * device memory, zero-initialised by the caller except [3] = initial loss scale and [8] = learning rate (written by
+ * the caller before every step):
+ *   [0] total gradient norm (unscaled)  [1] multiplier applied to g (clip coefficient / loss scale)  [2] found inf/nan
+ *   [3] loss scale  [4] growth tracker  [5] Adam step count  [6] 1 - beta1^t  [7] sqrt(1 - beta2^t)  [8] learning rate
+ *   [9] skipped steps
+ * Sequence per optimizer step: cum_optim_sumsq (partials: cum_optim_sumsq_parts(n) f32) -> cum_optim_prepare ->
+ * cum_optim_adam.  Nothing returns to the host; with found inf/nan the Adam launch leaves p, m, v untouched and the
+ * loss scale backs off (torch.amp.GradScaler semantics: growth x `growth` after `growth_interval` clean steps).
+ * max_norm <= 0 disables clipping; use_scaler = 0: gradients are unscaled, state[3] is ignored. */
+int32_t cum_optim_state_elems(void);
+int32_t cum_optim_sumsq_parts(int64_t n);
+int cum_optim_sumsq(const float *g, int64_t n, float *partials, void *stream);
+int cum_optim_prepare(float *state, const float *partials, int32_t nparts, float max_norm, float beta1, float beta2,
+                      int32_t use_scaler, float growth, float backoff, int32_t growth_interval, void *stream);
+int cum_optim_adam(float *p, const float *g, float *m, float *v, int64_t n, const float *state, float beta1,
+                   float beta2, float eps, float weight_decay, void *stream);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,10 @@ What is pinned by what:
            tests/test_oracle_golden.py.
   loss   : produced by the reference's src/util/stft_loss.py + F.l1_loss
            (src/util/util.py:313-322).
+  ckpt_* / e2e_* of the other seven pruned checkpoints (`python -m oracle.make_golden pruned`): same recipe as
+           pruned500k -- every loadable checkpoint the reference ships (src/examples/loading_pretrained_models.py:7-19).
+  lr_schedule : values returned by the reference's LinearWarmupCosineDecay.step() (src/util/util.py:115-161), fresh
+           and resumed runs, past the wrap-around (`python -m oracle.make_golden lr`).
 """
 import json
 import os
@@ -200,9 +204,42 @@ def make_loss(ref):
                         cfg=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8))
 
 
+PRUNED = {  # fixture name -> shipped file (checkpoints/pruned/)
+    "e8_pruned200k": "CleanUMamba-3N-E8_pruned-200K.pkl", "e8_pruned1m": "CleanUMamba-3N-E8_pruned-1M.pkl",
+    "e8_pruned2m": "CleanUMamba-3N-E8_pruned-2M.pkl", "e6_pruned200k": "CleanUMamba-3N-E6_pruned-200k.pkl",
+    "e6_pruned500k": "CleanUMamba-3N-E6_pruned-500k.pkl", "e6_pruned1m": "CleanUMamba-3N-E6_pruned-1M.pkl",
+    "e6_pruned2m": "CleanUMamba-3N-E6_pruned-2M.pkl",
+}
+
+
+def make_lr(ref):
+    import importlib
+    util = importlib.import_module("src.util.util")
+    out = {}
+    for tag, (n_iter, warm, it0) in {"fresh": (1000, 0.05, 0), "resume30": (1000, 0.05, 30), "resume50": (1000, 0.05, 50),
+                                     "resume700": (1000, 0.05, 700), "warm30pct": (400, 0.3, 0),
+                                     "nowarm": (300, 0.0, 0)}.items():
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        sch = util.LinearWarmupCosineDecay(opt, lr_max=1e-4, n_iter=n_iter, iteration=it0, divider=25,
+                                           warmup_proportion=warm, phase=("linear", "cosine"))
+        # (with no warm-up the reference divides by zero on the first step after the wrap: stop at the wrap)
+        out[tag] = np.array([sch.step() for _ in range(n_iter - it0 + (100 if warm > 0 else 0))], dtype=np.float64)
+        out[tag + "_args"] = np.array([n_iter, warm, it0], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "lr_schedule.npz"), **out)
+
+
 def main():
+    import sys
     os.makedirs(OUT, exist_ok=True)
     ref = reference_shim.load_reference()
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("pruned", "all"):
+        for name, fn in PRUNED.items():
+            e2e_from_ckpt(ref, name, os.path.join(REF, "checkpoints/pruned", fn), 16000, True)
+    if what in ("lr", "all"):
+        make_lr(ref)
+    if what != "all":
+        return
     for i, (b, d, n, l) in enumerate([(2, 8, 8, 33), (2, 48, 13, 257), (1, 128, 16, 61), (2, 64, 64, 96)]):
         make_scan(i, b, d, n, l, seed=i)
     make_scan(4, 1, 16, 8, 40, with_z=False, with_bias=False, with_D=False, seed=4)

@@ -12,7 +12,10 @@ value = global_batch * 160000 * K / (max-over-ranks time of K steps).
 roofline: the kernel with the largest share of the step (rocprofv3 --stats: gemm_tn_kernel<bf16>, the conv-stack
 weight gradients): algorithmic flops 2*M*N*K / mean launch duration measured with HIP events over the 16 encoder
 launch shapes of the step, against the dense bf16 MFMA peak.  `kernels` lists the other heavy kernels the same way
-(forward GEMMs; selective scan forward / backward with the SURVEY.md 8d byte counts and state updates / s).
+(forward GEMMs; selective scan forward / backward with the SURVEY.md 8d byte counts and state updates / s);
+`layers` is the per-layer table of SURVEY.md 8(d) rows a5 / a12: the two forward launches of every encoder / decoder
+layer summed, against the FUSED layer's algorithmic bytes (HBM roof) and flops (MFMA roof); `scan` lists the
+selective scan at d_state 64 / 16 / 8 (where HBM, not v_exp_f32 issue, is the binding roof).
 cpu_baseline: the CPU oracle (oracle/cleanumamba_ref.py, kind "port") doing forward + loss + backward
 on a bounded sample (2 clips of 10 s), rank 0, N = 1 only.
 """
@@ -42,16 +45,23 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"],
                     help="autocast dtype of the GEMM/conv stack (reference trains under fp16 autocast); "
                          "scan / depthwise-conv kernels always compute in f32")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-clip", type=int, default=CLIP, help="samples in the CPU-baseline clip")
     return ap.parse_args()
 
 
-MFMA_PEAK_TFS = 2500.0      # MI355X_MICROARCH.md: bf16 dense
-# PMC passes of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over tools/bench_gemm.py tn (profiles/r01_gemm_tn_pmc.md):
-# HBM bytes per gemm_tn launch (kernel + slab reduce), mean over the 16 encoder weight-gradient shapes
+MFMA_PEAK_TFS = 2500.0      # MI355X_MICROARCH.md: bf16 / f16 dense
+# HBM bytes per gemm_tn launch (kernel + slab reduce), mean over the 16 encoder weight-gradient shapes.  NOT measured
+# in this run: a constant from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over
+# tools/bench_gemm.py tn, corrected as MI355X_MICROARCH.md prescribes (profiles/r01_gemm_tn_pmc.md).
 TN_TRAFFIC_BYTES = 409.1e6
+# selective-scan issue roof: state updates per clock and SIMD of the bare inner-loop instruction mix (v_pk_mul,
+# 2 x v_exp_f32, v_pk_mul, 2 x v_pk_fma per state pair = 32 issue cycles per 128 lane-updates; MI355X_MICROARCH.md
+# cycle table), times 1024 SIMDs, times the clock the chip holds under that loop (tools/clock_probe.hip)
+SCAN_UPDATES_PER_CLK_SIMD = 4.0
+SCAN_CLOCK_GHZ = float(os.environ.get("CUM_SCAN_CLOCK_GHZ", "2.1"))
 
 B16 = 16
 ENC_T = [160254, 80126, 40062, 20030, 10014, 5006, 2502, 1250, 624]
@@ -75,14 +85,17 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
-def tn_roofline(dev):
+def _name(dt):
+    return {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}[dt]
+
+
+def tn_roofline(dev, dt=torch.bfloat16):
     """The kernel with the largest share of the step (rocprofv3: gemm_tn_kernel<bf16>, 34 launches per step):
     weight gradients dW = dZ^T X of the conv stack.  Timed live with HIP events on the 16 launch shapes the
     ENCODER contributes to one E8 / B=16 step (conv and 1x1 of each layer; the decoder's 16 launches mirror them
     with the same M*N*K).  achieved = sum of algorithmic flops (2*M*N*K) / sum of mean
     launch durations (kernel + its deterministic slab reduce)."""
     from cleanumamba_amd.network import convstack as cs
-    dt = torch.bfloat16
     rows, flops_sum, ms_sum = [], 0.0, 0.0
     for i in range(8):
         M, Cin, H = B16 * (ENC_T[i + 1] + 2), _rup(ENC_C[i], 8), ENC_C[i + 1]
@@ -97,22 +110,83 @@ def tn_roofline(dev):
             ms_sum += ms
             del dz, X
     tf = flops_sum / ms_sum / 1e9
-    return {"bound": "mfma", "kernel": "gemm_tn_kernel<bf16> + tn_reduce_kernel, the 16 encoder weight-gradient "
+    return {"bound": "mfma", "kernel": f"gemm_tn_kernel<{_name(dt)}> + tn_reduce_kernel, the 16 encoder weight-gradient "
                                        "launches of one E8 B=16 step",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFS, 4),
-            "traffic": TN_TRAFFIC_BYTES, "traffic_source": "profiles/r01_gemm_tn_pmc.md",
+            "traffic": TN_TRAFFIC_BYTES, "traffic_source": "constant from profiles/r01_gemm_tn_pmc.md (separate PMC "
+                                                             "passes), not measured in this run",
             "launch_ms": round(ms_sum / len(rows), 4), "algorithmic_flops": flops_sum / len(rows),
             "launches": len(rows), "per_shape": rows}
 
 
-def other_kernels(dev):
-    """Live HIP-event timings of the other heavy kernels of the step, each against the roof that bounds it
-    (bf16 MFMA 2.5 PFLOP/s dense; HBM 8 TB/s).  Informational; `roofline` is the weight-gradient GEMM."""
-    from cleanumamba_amd import hip
+def _scan_case(dev, bsz, dim, Ns, L, io, backward):
+    """One selective-scan shape: forward without checkpoints (inference), and optionally forward + backward."""
     from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    g = torch.Generator(device=dev).manual_seed(1)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+    R = max(4, dim // 64)
+    xz = rn(bsz, L, 2 * dim).to(io).requires_grad_(True)
+    dl = (0.3 * rn(bsz, L, dim)).to(io).requires_grad_(True)
+    Am = (-torch.exp(torch.log(torch.arange(1, Ns + 1, device=dev).float())[None].repeat(dim, 1))).requires_grad_(True)
+    xd = rn(bsz, L, R + 2 * Ns).requires_grad_(True)
+    Dv, bv = rn(dim).requires_grad_(True), (0.3 * rn(dim)).requires_grad_(True)
+    dout = rn(bsz, L, dim).to(io).transpose(1, 2)
+
+    def fwd():
+        return selective_scan_fn(xz[..., :dim].transpose(1, 2), dl.transpose(1, 2), Am, xd[..., R:R + Ns].transpose(1, 2),
+                                 xd[..., R + Ns:].transpose(1, 2), Dv, z=xz[..., dim:].transpose(1, 2), delta_bias=bv,
+                                 delta_softplus=True)
+
+    def fwd_nograd():
+        with torch.no_grad():
+            return fwd()
+    t_i = _time(fwd_nograd)
+    t_b = None
+    if backward:
+        t_f = _time(fwd)
+        t_b = _time(lambda: fwd().backward(dout)) - t_f
+    return t_i, t_b
+
+
+def scan_rows(dev, dt):
+    """The north_star kernel against both of its roofs.  Algorithmic bytes: SURVEY.md 8(d), B*T*(s*4*D + 4*2*N) forward
+    (u, delta, z, out in the I/O type of s bytes; B, C in f32), B*T*(s*7*D + 4*4*N) backward.  State updates: B*T*D*N.
+    HBM roof 8 TB/s; issue roof = SCAN_UPDATES_PER_CLK_SIMD * 1024 SIMDs * SCAN_CLOCK_GHZ (one v_exp_f32 per update).
+    At d_state 64 the issue roof binds; at d_state <= 16 the HBM roof does."""
+    issue_roof = SCAN_UPDATES_PER_CLK_SIMD * 1024 * SCAN_CLOCK_GHZ * 1e9
+    cases = [("E8 bottleneck B=16 D=2048 N=64 L=624", 16, 2048, 64, 624, dt, True),
+             ("E8 bottleneck, f32 I/O", 16, 2048, 64, 624, torch.float32, False),
+             ("E6 bottleneck B=32 D=2048 N=64 L=2499", 32, 2048, 64, 2499, dt, False),
+             ("D=2048 N=16 L=2499 B=16", 16, 2048, 16, 2499, dt, True),
+             ("D=2048 N=16 L=2499 B=16, f32 I/O", 16, 2048, 16, 2499, torch.float32, False),
+             ("D=2048 N=8 L=2499 B=16", 16, 2048, 8, 2499, dt, True),
+             ("D=2048 N=8 L=2499 B=16, f32 I/O", 16, 2048, 8, 2499, torch.float32, False),
+             ("442K model B=16 D=128 N=16 L=624", 16, 128, 16, 624, torch.float32, False),
+             ("pruned-E8 block B=256 D=48 N=8 L=1875 (30 s)", 256, 48, 8, 1875, torch.float32, False)]
+    rows = []
+    for name, bsz, dim, Ns, L, io, bwd in cases:
+        t_i, t_b = _scan_case(dev, bsz, dim, Ns, L, io, bwd)
+        sz = torch.empty((), dtype=io).element_size()
+        upd = bsz * L * dim * Ns
+        for kind, ms, byt in (("fwd", t_i, bsz * L * (sz * 4 * dim + 4 * 2 * Ns)),
+                              ("bwd", t_b, bsz * L * (sz * 7 * dim + 4 * 4 * Ns))):
+            if ms is None:
+                continue
+            gbs, ups = byt / (ms * 1e-3) / 1e9, upd / (ms * 1e-3)
+            rows.append({"kernel": f"selective scan {kind}, {name}, {_name(io)} I/O", "launch_ms": round(ms, 4),
+                         "algorithmic_bytes": byt, "achieved_GBps": round(gbs, 1),
+                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "state_updates_T_per_s": round(ups / 1e12, 3),
+                         "issue_roof_frac": round(ups / issue_roof, 4) if kind == "fwd" else None,
+                         "binding_roof": "hbm" if byt / (HBM_PEAK_GBS * 1e9) > upd / issue_roof else "v_exp_f32 issue"})
+    return rows
+
+
+def other_kernels(dev, dt=torch.bfloat16):
+    """Live HIP-event timings of the other heavy kernels of the step, each against the roof that bounds it
+    (16-bit MFMA 2.5 PFLOP/s dense; HBM 8 TB/s).  Informational; `roofline` is the weight-gradient GEMM."""
+    from cleanumamba_amd import hip
     from cleanumamba_amd.network import convstack as cs
     out = []
-    dt = torch.bfloat16
     # forward GEMMs of the encoder (conv k4 s2 + ReLU, 1x1 + GLU), all 16 launch shapes of one step
     fl_sum = ms_sum = 0.0
     for i in range(8):
@@ -127,48 +201,74 @@ def other_kernels(dev):
             fl_sum += 2.0 * M * N * K
             del A, W, y
     tf = fl_sum / ms_sum / 1e9
-    out.append({"kernel": "gemm_nt_kernel<bf16> (ReLU / GLU epilogues), the 16 encoder forward launches of one step",
+    out.append({"kernel": f"gemm_nt_kernel<{_name(dt)}> (ReLU / GLU epilogues), the 16 encoder forward launches of one step",
                 "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_PEAK_TFS, 4), "launch_ms": round(ms_sum / 16, 4)})
-    # selective scan at the E8 bottleneck shape, bf16 element type as in the autocast step
-    bsz, dim, Ns, L = 16, 2048, 64, 624
-    g = torch.Generator(device=dev).manual_seed(1)
-    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
-    xz = rn(bsz, L, 2 * dim).bfloat16().requires_grad_(True)
-    dl = (0.3 * rn(bsz, L, dim)).bfloat16().requires_grad_(True)
-    Am = (-torch.exp(torch.log(torch.arange(1, Ns + 1, device=dev).float())[None].repeat(dim, 1))).requires_grad_(True)
-    xd = rn(bsz, L, 32 + 2 * Ns).requires_grad_(True)
-    Dv, bv = rn(dim).requires_grad_(True), (0.3 * rn(dim)).requires_grad_(True)
-    dout = rn(bsz, dim, L).bfloat16()
-
-    def fwd():
-        return selective_scan_fn(xz[..., :dim].transpose(1, 2), dl.transpose(1, 2), Am, xd[..., 32:32 + Ns].transpose(1, 2),
-                                 xd[..., 32 + Ns:].transpose(1, 2), Dv, z=xz[..., dim:].transpose(1, 2), delta_bias=bv,
-                                 delta_softplus=True)
-
-    def fwd_nograd():
-        with torch.no_grad():
-            return fwd()
-    t_i = _time(fwd_nograd)
-    t_f = _time(fwd)
-    t_fb = _time(lambda: fwd().backward(dout))
-    upd = bsz * L * dim * Ns
-    byt = bsz * L * (2 * 4 * dim + 4 * 2 * Ns)           # u, delta, z, out in bf16; B, C in f32  (s = 2 / 4)
-    gbs = byt / (t_i * 1e-3) / 1e9
-    out.append({"kernel": "scan_fwd_lds_kernel<8,bf16> (B=16,D=2048,N=64,L=624), no checkpoints", "bound": "hbm",
-                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "launch_ms": round(t_i, 4), "algorithmic_bytes": byt,
-                "state_updates_per_s": round(upd / (t_i * 1e-3) / 1e12, 3), "state_updates_unit": "T/s",
-                "note": "one v_exp_f32 per state update: transcendental-issue bound at N=64 (DESIGN.md 3.1)"})
-    ms = t_fb - t_f
-    byt = bsz * L * (2 * 7 * dim + 4 * 4 * Ns)           # u, delta, z, dout, du, ddelta, dz in bf16; B, C, dB, dC in f32
-    gbs = byt / (ms * 1e-3) / 1e9
-    out.append({"kernel": "scan_bwd_kernel<8,LDS B/C,bf16> + finalize (B=16,D=2048,N=64,L=624)", "bound": "hbm",
-                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "launch_ms": round(ms, 4), "algorithmic_bytes": byt,
-                "state_updates_per_s": round(upd / (ms * 1e-3) / 1e12, 3), "state_updates_unit": "T/s",
-                "note": "1.25 v_exp_f32 + ~9 packed VALU ops per state element: instruction-issue bound (DESIGN.md 3.2)"})
     return out
+
+
+def layer_table(net, dev, dt):
+    """SURVEY.md 8(d) rows a5 / a12 on the E8 B=16 training shapes: per encoder / decoder layer the TWO forward launches
+    (conv + ReLU, 1x1 + GLU | 1x1 + GLU, transposed conv + ReLU + skip) summed, against the FUSED layer's algorithmic
+    traffic s*B*(Cin*Tin + H*Tout) (+ weights; decoder: s*B*(2*H*T + Cout*(2T+2))) and flops 2*B*Tout*(4*Cin*H + 2*H^2).
+    The H-channel intermediate and the saved gate pre-activation are real traffic of the two-launch form that the
+    algorithmic figure does not count: hbm_frac is what a fused layer kernel could recover on the outer layers."""
+    from cleanumamba_amd.network import convstack as cs
+    B, s = B16, torch.empty((), dtype=dt).element_size()
+    with torch.no_grad():
+        net._activate_pack_plan(dt)                      # record + pack once; take() then returns cached views
+    rows = []
+    geo = cs.Geo(B, ENC_T[0], 1)
+    enc_geos = []
+    for i, enc in enumerate(net.encoder):
+        T1 = ENC_T[i + 1]
+        gm, go = cs.Geo(B, T1, enc[0].weight.shape[0]), cs.Geo(B, T1, enc[2].weight.shape[0] // 2)
+        enc_geos.append((geo, gm, go))
+        geo = go
+    with torch.no_grad():
+        for i, ((gi, gm, go), enc) in enumerate(zip(enc_geos, net.encoder)):
+            x = (0.5 * torch.randn(gi.R, gi.Cp, device=dev)).to(dt)
+
+            def run():
+                y1 = cs._conv_relu_fwd(x, enc[0].weight, enc[0].bias, gi, gm)
+                return cs._glu_fwd(y1, enc[2].weight, enc[2].bias, gm, go, True)
+            run()
+            net._activate_pack_plan(dt)
+            ms = _time(run, iters=5, warm=2)
+            Cin, H = gi.C, gm.C
+            byt = s * B * (Cin * gi.T + H * go.T) + s * (4 * Cin * H + 2 * H * H)
+            fl = 2.0 * B * go.T * (4 * Cin * H + 2 * H * H)
+            rows.append(_layer_row(f"enc{i} {Cin}->{H} T {gi.T}->{go.T}", ms, byt, fl))
+            del x
+        E = len(net.decoder)
+        gi = enc_geos[-1][2]
+        for j, dec in enumerate(net.decoder):
+            gg = cs.Geo(B, gi.T, dec[0].weight.shape[0] // 2)
+            go = cs.Geo(B, 2 * gi.T + 2, dec[2].weight.shape[1])
+            u = (0.5 * torch.randn(gi.R, gi.Cp, device=dev)).to(dt)
+            skip = (0.5 * torch.randn(go.R, go.Cp, device=dev)).to(dt) if j < E - 1 else None
+
+            def run():
+                g, _ = cs._glu_fwd(u, dec[0].weight, dec[0].bias, gi, gg, True)
+                return cs._convt_fwd(g, dec[2].weight, dec[2].bias, skip, gg, go, j < E - 1)
+            run()
+            net._activate_pack_plan(dt)
+            ms = _time(run, iters=5, warm=2)
+            H, Cout = gg.C, go.C
+            byt = s * B * (H * gi.T + Cout * go.T * (2 if skip is not None else 1)) + s * (2 * H * H + 4 * H * Cout)
+            fl = 2.0 * B * gi.T * (2 * H * H + 4 * H * Cout)
+            rows.append(_layer_row(f"dec{j} {H}->{Cout} T {gi.T}->{go.T}", ms, byt, fl))
+            gi = go
+            del u, skip
+    return rows
+
+
+def _layer_row(name, ms, byt, fl):
+    gbs, tf = byt / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
+    hb, mf = gbs / HBM_PEAK_GBS, tf / MFMA_PEAK_TFS
+    return {"layer": name, "launches": 2, "ms": round(ms, 4), "algorithmic_bytes": int(byt), "algorithmic_flops": int(fl),
+            "achieved_GBps": round(gbs, 1), "hbm_frac": round(hb, 4), "achieved_TFLOPs": round(tf, 1),
+            "mfma_frac": round(mf, 4), "bound": "hbm" if byt / (HBM_PEAK_GBS * 1e9) > fl / (MFMA_PEAK_TFS * 1e12) else "mfma"}
 
 
 def cpu_baseline(clip):
@@ -229,7 +329,7 @@ def main():
     if world > 1:
         net = apply_gradient_allreduce(net)
     ac = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": None}[args.dtype]
-    step = TrainStep(net, autocast_dtype=ac)
+    step = TrainStep(net, autocast_dtype=ac, use_graph=(world == 1 and not args.no_graph))
 
     B = args.batch_per_gpu
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -256,6 +356,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss)
+    graph_status = step.graph_status
 
     if rank == 0:
         gb = B * world
@@ -268,13 +369,18 @@ def main():
                                       " + grad all-reduce + clip + Adam; 10 s @ 16 kHz clips",
                           "global_batch": gb, "batch_per_gpu": B, "clip_samples": CLIP,
                           "parallelism": f"dp{world}", "weights": "random init (reference init, seed 0)"},
-               "final_loss": round(final_loss, 5)}
+               "final_loss": round(final_loss, 5), "step_graph": graph_status}
         if not args.no_roofline:
-            out["roofline"] = tn_roofline(dev)
+            del step, loss
+            torch.cuda.empty_cache()
+            kdt = ac if ac is not None else torch.bfloat16
+            out["roofline"] = tn_roofline(dev, kdt)
             if world == 1:
-                out["kernels"] = other_kernels(dev)
-                # the kernel north_star names, against the HBM roof it nominates (issue-bound at N = 64: DESIGN.md 3.1)
-                out["north_star_kernel"] = next(k for k in out["kernels"] if k["kernel"].startswith("scan_fwd"))
+                out["kernels"] = other_kernels(dev, kdt)
+                out["scan"] = scan_rows(dev, kdt)
+                # the kernel north_star names, against the HBM roof it nominates and the issue roof that binds at N = 64
+                out["north_star_kernel"] = out["scan"][0]
+                out["layers"] = layer_table(net, dev, kdt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_clip)
         print(json.dumps(out), flush=True)

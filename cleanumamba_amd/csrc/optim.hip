@@ -51,7 +51,7 @@ struct PrepareArgs {
   const float *partials;
   int nparts;
   float max_norm;          // <= 0: no clipping
-  float beta1, beta2;
+  double beta1, beta2;
   int use_scaler;          // 1: gradients carry state[ST_SCALE]; dynamic scale update as torch.amp.GradScaler
   float growth, backoff;
   int growth_interval;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void optim_prepare_kernel(const PrepareArgs a)
   } else {
     const float t = st[ST_STEP] + 1.f;
     st[ST_STEP] = t;
-    st[ST_BC1] = (float)(1.0 - pow((double)a.beta1, (double)t));
-    st[ST_BC2_SQRT] = (float)sqrt(1.0 - pow((double)a.beta2, (double)t));
+    st[ST_BC1] = (float)(1.0 - pow(a.beta1, (double)t));
+    st[ST_BC2_SQRT] = (float)sqrt(1.0 - pow(a.beta2, (double)t));
   }
   if (a.use_scaler) {                              // torch.amp.GradScaler.update()
     if (bad) {
@@ -110,15 +110,15 @@ struct AdamArgs {
   const float *g;
   int64_t n;
   const float *state;
-  float beta1, beta2, eps, weight_decay;
+  float beta1, beta2, omb1, omb2, eps, weight_decay;    // omb = 1 - beta, rounded from the double-precision difference
 };
 
 __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float mult, float lr_bc1, float inv_bc2s,
                                       const AdamArgs &a) {
   g *= mult;
   if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);      // Adam's L2 form (torch.optim.Adam)
-  m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
-  v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
+  m = fmaf(a.beta1, m, a.omb1 * g);
+  v = fmaf(a.beta2, v, a.omb2 * (g * g));
   const float denom = sqrtf(v) * inv_bc2s + a.eps;
   p -= lr_bc1 * (m / denom);
 }
@@ -165,8 +165,8 @@ extern "C" int cum_optim_sumsq(const float *g, int64_t n, float *partials, void 
   return CUM_OK;
 }
 
-extern "C" int cum_optim_prepare(float *state, const float *partials, int32_t nparts, float max_norm, float beta1,
-                                 float beta2, int32_t use_scaler, float growth, float backoff, int32_t growth_interval,
+extern "C" int cum_optim_prepare(float *state, const float *partials, int32_t nparts, float max_norm, double beta1,
+                                 double beta2, int32_t use_scaler, float growth, float backoff, int32_t growth_interval,
                                  void *stream) {
   CUM_REQUIRE(state && partials && nparts > 0, "optim_prepare: bad argument");
   CUM_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "optim_prepare: betas must be in [0, 1)");
@@ -176,12 +176,12 @@ extern "C" int cum_optim_prepare(float *state, const float *partials, int32_t np
   return CUM_OK;
 }
 
-extern "C" int cum_optim_adam(float *p, const float *g, float *m, float *v, int64_t n, const float *state, float beta1,
-                              float beta2, float eps, float weight_decay, void *stream) {
+extern "C" int cum_optim_adam(float *p, const float *g, float *m, float *v, int64_t n, const float *state, double beta1,
+                              double beta2, float eps, float weight_decay, void *stream) {
   CUM_REQUIRE(p && g && m && v && state && n >= 0, "optim_adam: null pointer");
   CUM_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "optim_adam: buffers must be 16-byte aligned");
   if (n == 0) return CUM_OK;
-  AdamArgs a{p, m, v, g, n, state, beta1, beta2, eps, weight_decay};
+  AdamArgs a{p, m, v, g, n, state, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay};
   const int64_t want = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(optim_adam_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want))), dim3(256), 0,
                      (hipStream_t)stream, a);

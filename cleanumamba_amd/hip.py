@@ -100,9 +100,9 @@ SIGNATURES = {
     "cum_optim_state_elems": (c_i32, []),
     "cum_optim_sumsq_parts": (c_i32, [c_i64]),
     "cum_optim_sumsq": (c_i32, [_P, c_i64, _P, _P]),
-    "cum_optim_prepare": (c_i32, [_P, _P, c_i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i32, ctypes.c_float,
+    "cum_optim_prepare": (c_i32, [_P, _P, c_i32, ctypes.c_float, ctypes.c_double, ctypes.c_double, c_i32, ctypes.c_float,
                                   ctypes.c_float, c_i32, _P]),
-    "cum_optim_adam": (c_i32, [_P, _P, _P, _P, c_i64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+    "cum_optim_adam": (c_i32, [_P, _P, _P, _P, c_i64, _P, ctypes.c_double, ctypes.c_double, ctypes.c_float, ctypes.c_float,
                                _P]),
 }
 

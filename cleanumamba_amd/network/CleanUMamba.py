@@ -384,12 +384,68 @@ class CleanUMamba(nn.Module):
 
     @torch.no_grad()
     def flush_batch(self):
-        pending_length = self.pending.shape[1]
-        padding = torch.zeros(self.pending.shape[0], self.frame_length, device=self.pending.device, dtype=self.dtype)
-        frames_before, time_before = self.frames, self.total_time
-        out = self.feed_batch(padding)[:, :pending_length]
+        """End of the streams: emit the samples still pending so that feed + flush reproduce ``forward`` on the whole
+        signal, tail included.  ``forward`` zero-pads the signal to ``valid_length`` and its last
+        ``frame_length - total_stride`` output samples come from the transposed convs' overhang of the LAST real
+        frame -- no later frame exists.  So flush (1) pads the stream with exactly the zeros ``forward`` would add
+        and runs the hops of the frames that exist, then (2) drains the decoder (``_drain``): the per-layer overlap
+        tails and the not-yet-consumed encoder rows are pushed through the remaining decoder layers with no new
+        frame.  (The reference's flush() feeds one whole frame of zeros after clearing the decoder state,
+        src/network/CleanUMamba.py:358-368 -- SURVEY fact 9: ~70 % error on the tail.)"""
+        S, pending_length = self.pending.shape[0], self.pending.shape[1]
+        dev = self.pending.device
+        consumed = getattr(self, "_std_frames", 0) * self.total_stride
+        if consumed + pending_length == 0:
+            return torch.zeros(S, 0, device=dev)
+        target = self.valid_length(consumed + pending_length)
+        pad = torch.zeros(S, target - consumed - pending_length, device=dev, dtype=self.pending.dtype)
+        head = self.feed_batch(pad)      # the frames forward() has: they count as timed frames like any other
+        out = torch.cat([head, self._drain().to(head.dtype)], 1)[:, :pending_length]
         self.reset_stream()              # the next clip starts a fresh stream: its running std starts over too
-        self.frames, self.total_time = frames_before, time_before     # the padding frame is not a timed frame
+        return out
+
+    def _drain(self):
+        """Output samples behind the last hop, (S, frame_length - total_stride): what ``forward`` produces there.
+        Decoder layer j still holds 2 overhang rows of its transposed conv (``dec{j}``, bias excluded) and encoder
+        layer i holds ``2^(E-i) - 2`` output rows no hop has consumed as skips yet; layer j maps its
+        ``2^(j+1) - 2`` trailing input rows to ``2^(j+2) - 2`` trailing output rows."""
+        state, E = self.encoder_decoder_state, self.encoder_n_layers
+        S, dev = self.pending.shape[0], self.pending.device
+
+        rows_layout = state["enc0"].dim() == 2                 # fused hop: 2-D row buffers; cached hop: (S, C, T)
+
+        def trailing_skip(i):
+            t = state[f"enc{i}"]
+            hop = self.total_stride // self.stride ** (i + 1)
+            if not rows_layout:                                # cached path: (S, C, rows not yet consumed)
+                return t.float()
+            C = self.encoder[i][2].weight.shape[0] // 2        # fused path: row buffer of the frame's whole window
+            T = self.frame_length
+            for _ in range(i + 1):
+                T = (T - self.kernel_size) // self.stride + 1
+            return cs.from_rows(t, cs.Geo(S, T, C))[..., hop:].float()
+
+        def tail(j):
+            t = state[f"dec{j}"]
+            if rows_layout:                                    # fused path: (S, 2, Cp) channels-last
+                return t.transpose(1, 2)[:, :self.decoder[j][2].weight.shape[1]].float()
+            return t.float()                                   # cached path: (S, C, 2)
+
+        x = None
+        for j, dec in enumerate(self.decoder):
+            w = dec[2].weight
+            if j == 0:
+                y = tail(0).to(w.dtype) + dec[2].bias.view(1, -1, 1)
+            else:
+                x = x + trailing_skip(E - 1 - j)[..., :x.shape[-1]].to(x.dtype)
+                y = dec[2](dec[1](dec[0](x)))
+                y[..., :self.stride] += tail(j).to(y.dtype)
+            if j != E - 1:
+                y = dec[3](y)
+            x = y
+        out = x[:, 0]
+        if self.normalize_input:
+            out = out * self.input_std
         return out
 
     @torch.no_grad()

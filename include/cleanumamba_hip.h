@@ -362,10 +362,11 @@ int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t C
 int32_t cum_optim_state_elems(void);
 int32_t cum_optim_sumsq_parts(int64_t n);
 int cum_optim_sumsq(const float *g, int64_t n, float *partials, void *stream);
-int cum_optim_prepare(float *state, const float *partials, int32_t nparts, float max_norm, float beta1, float beta2,
+int cum_optim_prepare(float *state, const float *partials, int32_t nparts, float max_norm, double beta1, double beta2,
                       int32_t use_scaler, float growth, float backoff, int32_t growth_interval, void *stream);
-int cum_optim_adam(float *p, const float *g, float *m, float *v, int64_t n, const float *state, float beta1,
-                   float beta2, float eps, float weight_decay, void *stream);
+int cum_optim_adam(float *p, const float *g, float *m, float *v, int64_t n, const float *state, double beta1,
+                   double beta2, float eps, float weight_decay, void *stream);   /* betas as double: 1 - beta must not
+                                                                                    be formed in f32 (0.999f: 5e-5 off) */
 
 #ifdef __cplusplus
 }

@@ -3,10 +3,24 @@ F.conv1d / F.conv_transpose1d restatement, forward and backward, fp32 and bf16 (
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import record, rel_l2
 from oracle import cleanumamba_ref as R
 
 pytestmark = pytest.mark.gpu
+
+# (forward, backward) rel-L2 bounds of one fused layer against the f64 oracle evaluated on the SAME 16-bit-rounded
+# inputs and weights the kernels read: what is left is the rounding of the intermediate H-channel activation and of
+# the outputs (bf16: 2^-9 per element, f16: 2^-12) and f32 accumulation.  (Against UNROUNDED operands the input
+# gradient is dominated by ReLU gates that flip where |pre-activation| < one rounding step -- sqrt(2^-9) ~ 5 % -- which
+# says nothing about the kernels.)  Bounds are ~3x the largest value measured over the shapes below
+# (gpurun_out/test_measured.jsonl); a dropped K tile or a mis-packed weight row moves these by O(1 / K tiles) >> bound.
+LAYER_TOL = {torch.float32: (2e-5, 1e-4), torch.bfloat16: (6e-3, 1.2e-2), torch.float16: (8e-4, 1.6e-3)}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+
+
+def _rounded(t, dtype):
+    """The value a 16-bit kernel path sees for an f32 operand."""
+    return t.to(dtype).double()
 
 
 def _layer_params(cin, h, cout, seed):
@@ -19,16 +33,19 @@ def _layer_params(cin, h, cout, seed):
 
 
 @pytest.mark.parametrize("cin,h,tin", [(1, 64, 62), (53, 74, 30), (128, 256, 126), (768, 768, 14)])
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
-def test_encoder_layer_fwd_bwd(cuda, cin, h, tin, dtype, tol):
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_encoder_layer_fwd_bwd(cuda, cin, h, tin, dtype):
+    tol, btol = LAYER_TOL[dtype]
+    tag = f"enc_layer[{cin}-{h}-{tin}-{dtype}]"
     from cleanumamba_amd.network import convstack as cs
     B = 3
     sd = _layer_params(cin, h, h, seed=cin + h)
     x = torch.randn(B, cin, tin, generator=torch.Generator().manual_seed(1))
     tout = (tin - 4) // 2 + 1
     dout = torch.randn(B, h, tout, generator=torch.Generator().manual_seed(2))
-    ref = {k: v.double().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder")}
-    xr = x.double().requires_grad_(True)
+    ref = {k: (_rounded(v, dtype) if k.endswith("weight") else v.double()).requires_grad_(True)
+           for k, v in sd.items() if k.startswith("encoder")}          # biases stay f32 in the kernels
+    xr = _rounded(x, dtype).requires_grad_(True)
     yr = R.encoder_layer(ref, 0, xr)
     (yr * dout.double()).sum().backward()
 
@@ -39,28 +56,31 @@ def test_encoder_layer_fwd_bwd(cuda, cin, h, tin, dtype, tol):
     y1 = cs.ConvK4S2ReLU.apply(buf, dev["encoder.0.0.weight"], dev["encoder.0.0.bias"], gi, gm)
     ybuf = cs.PointwiseGLU.apply(y1, dev["encoder.0.2.weight"], dev["encoder.0.2.bias"], gm, go, True)
     y = cs.from_rows(ybuf, go).float()
-    assert rel_l2(y, yr) < tol
+    assert record(tag + ".fwd", rel_l2(y, yr)) < tol
     # closing rows / padded channels stay zero
     rows = go.rows(ybuf)
     assert float(rows[:, go.T:].abs().max()) == 0 and float(rows[:, :, go.C:].abs().max() if go.Cp > go.C else 0) == 0
     (y * dout.to(cuda)).sum().backward()
-    assert rel_l2(xd.grad, xr.grad) < 5 * tol
+    assert record(tag + ".dx", rel_l2(xd.grad, xr.grad)) < btol
     for k in dev:
-        assert rel_l2(dev[k].grad, ref[k].grad) < 5 * tol, k
+        assert record(tag + ".d" + k, rel_l2(dev[k].grad, ref[k].grad)) < btol, k
 
 
 @pytest.mark.parametrize("h,cout,t,relu,with_skip", [(64, 1, 30, False, False), (74, 53, 14, True, True),
                                                      (256, 128, 62, True, True), (768, 768, 6, True, True)])
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
-def test_decoder_layer_fwd_bwd(cuda, h, cout, t, relu, with_skip, dtype, tol):
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_decoder_layer_fwd_bwd(cuda, h, cout, t, relu, with_skip, dtype):
+    tol, btol = LAYER_TOL[dtype]
+    tag = f"dec_layer[{h}-{cout}-{t}-{dtype}]"
     from cleanumamba_amd.network import convstack as cs
     B = 2
     sd = _layer_params(h, h, cout, seed=h + cout)
     x = torch.randn(B, h, t, generator=torch.Generator().manual_seed(3))
     skip = torch.randn(B, cout, 2 * t + 2, generator=torch.Generator().manual_seed(4))
     dout = torch.randn(B, cout, 2 * t + 2, generator=torch.Generator().manual_seed(5))
-    ref = {k: v.double().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder")}
-    xr, sr = x.double().requires_grad_(True), skip.double().requires_grad_(True)
+    ref = {k: (_rounded(v, dtype) if k.endswith("weight") else v.double()).requires_grad_(True)
+           for k, v in sd.items() if k.startswith("decoder")}
+    xr, sr = _rounded(x, dtype).requires_grad_(True), _rounded(skip, dtype).requires_grad_(True)
     yr = R.decoder_layer(ref, 0, xr, last=not relu)
     if with_skip:
         yr = yr + sr
@@ -74,14 +94,14 @@ def test_decoder_layer_fwd_bwd(cuda, h, cout, t, relu, with_skip, dtype, tol):
     g = cs.PointwiseGLU.apply(buf, dev["decoder.0.0.weight"], dev["decoder.0.0.bias"], gi, gg, True)
     ybuf = cs.ConvT4S2.apply(g, dev["decoder.0.2.weight"], dev["decoder.0.2.bias"], sbuf, gg, go, relu)
     y = cs.from_rows(ybuf, go).float()
-    assert rel_l2(y, yr) < tol
+    assert record(tag + ".fwd", rel_l2(y, yr)) < tol
     assert float(go.rows(ybuf)[:, go.T:].abs().max()) == 0
     (y * dout.to(cuda)).sum().backward()
-    assert rel_l2(xd.grad, xr.grad) < 5 * tol
+    assert record(tag + ".dx", rel_l2(xd.grad, xr.grad)) < btol
     if with_skip:
-        assert rel_l2(sk.grad, sr.grad) < 5 * tol
+        assert record(tag + ".dskip", rel_l2(sk.grad, sr.grad)) < btol
     for k in dev:
-        assert rel_l2(dev[k].grad, ref[k].grad) < 5 * tol, k
+        assert record(tag + ".d" + k, rel_l2(dev[k].grad, ref[k].grad)) < btol, k
 
 
 def test_pointwise_with_residual(cuda):
@@ -108,7 +128,7 @@ def _ref_gemm(A, W, bias):
     return A.double() @ W.double().t() + (0 if bias is None else bias.double())
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 6e-3), (torch.float16, 8e-4)])   # output rounding only
 @pytest.mark.parametrize("M,N,K", [(300, 64, 64), (1000, 192, 512), (60001, 256, 256), (140003, 192, 256)])
 def test_gemm_backward_epilogues_against_torch(cuda, M, N, K, dtype, tol):
     """The backward epilogues of cum_gemm_nt through the C ABI, ragged M (edge tiles); the four shapes make the

@@ -8,7 +8,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("src_dt,dst_dt", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32),
-                                           (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16)])
+                                           (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                           (torch.float32, torch.float16), (torch.float16, torch.float32),
+                                           (torch.float16, torch.float16)])
 @pytest.mark.parametrize("n", [1, 7, 8, 1000, 100003])
 def test_gather_with_zero_padding(cuda, src_dt, dst_dt, n):
     from cleanumamba_amd.network import convstack as cs
@@ -57,7 +59,7 @@ def test_cfft_matches_torch_fft(cuda, n):
     assert float((back - z).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_stream_window_update_and_tail_rows(cuda, dt):
     """The streaming encoder glue against plain slicing: window <- cat(window[n_new:], new rows) with `fresh` either a
     whole recomputed window or only the new rows; tail_rows copies the newest rows into a compact clip buffer."""

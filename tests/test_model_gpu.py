@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_json, load_ckpt, load_golden, rel_l2
+from conftest import golden_json, load_ckpt, load_golden, record, rel_l2
 from oracle import cleanumamba_ref as R
 from oracle import synth
 
@@ -95,15 +95,14 @@ def test_streaming_equals_parallel_forward(cuda, name, pruned):
         outs.append(net.flush())
         seq = torch.cat(outs, 1)
     assert seq.shape == par.shape
-    # Every hop whose frame lies inside the padded signal is identical to the parallel forward.  The
-    # last < frame_length samples come out of flush(), which continues the stream with zeros, while
-    # the parallel forward ends the signal there: that tail carries the reference's own tolerance
-    # (atol=0.1, src/network/CleanUMamba.py:582).
+    # Every hop whose frame lies inside the padded signal is identical to the parallel forward ...
     exact = ((net.valid_length(16000) - net.frame_length) // net.total_stride + 1) * net.total_stride
     assert exact == 61 * 256
     assert rel_l2(seq[:, :exact], par[:, :exact]) < 1e-4
     assert rel_l2(seq[:, :exact], T(g["out_raw"])[0][:, :exact]) < 1e-4
-    assert torch.allclose(seq, par, atol=0.1)
+    # ... and so is the tail: flush() pads exactly as forward() does and drains the decoder instead of inventing frames
+    assert rel_l2(seq[:, exact:], par[:, exact:]) < 1e-4
+    assert rel_l2(seq, T(g["out_raw"])[0][:, :16000]) < 1e-4
     assert net.frames > 0 and net.time_per_frame > 0
     with torch.no_grad():                               # the stream state was reset by flush()
         again = torch.cat([net.feed(x), net.flush()], 1)
@@ -296,3 +295,52 @@ def test_fused_mamba_step_equals_separate_kernels(cuda, dims, monkeypatch):
         got[fused] = (torch.cat(outs, 1), res, conv_state.clone(), ssm_state.clone())
     for a, b, name in zip(got[True], got[False], ("hidden", "residual", "conv_state", "ssm_state")):
         assert a.shape == b.shape and rel_l2(a, b) < 1e-5, name
+
+
+PRUNED = ["pruned500k", "e8_pruned200k", "e8_pruned1m", "e8_pruned2m", "e6_pruned200k", "e6_pruned500k", "e6_pruned1m",
+          "e6_pruned2m"]
+
+
+@pytest.mark.parametrize("name", ["442k"] + PRUNED)
+def test_every_shipped_checkpoint_forward_and_stream(cuda, name):
+    """All nine loadable checkpoints of the reference (src/examples/loading_pretrained_models.py:7-19;
+    checkpoints/pruned/*.pkl: d_state 8-14, odd channel counts, E6 frame 190 / hop 64): the parallel forward against
+    the reference class's output, and feed + flush (fused hop and cached hop) against forward on the WHOLE signal."""
+    net = _net(name, cuda, pruned=name != "442k")
+    g = load_golden("e2e_" + name)
+    assert net.frame_length == int(g["frame_length"]) and net.total_stride == int(g["total_stride"])
+    assert net.valid_length(16000) == int(g["valid_length"])
+    x = T(g["input"]).to(cuda)
+    with torch.no_grad():
+        assert record(f"ckpt_fwd[{name}].norm", rel_l2(net(x), g["out_norm"])) < E2E_TOL
+        net.normalize_input = False
+        par = net(x)
+        assert record(f"ckpt_fwd[{name}].raw", rel_l2(par, g["out_raw"])) < E2E_TOL
+        assert rel_l2(par, g["out64_raw"]) < E2E_TOL
+        par = par[:, 0, :16000]
+        for fused in (True, False):
+            net.reset_stream()
+            net.use_fused_stream = fused
+            chunks = [net.feed_batch(x[:, 0, i:i + 3000]) for i in range(0, 16000, 3000)]
+            seq = torch.cat(chunks + [net.flush_batch()], 1)
+            assert seq.shape == par.shape
+            assert record(f"ckpt_stream[{name}-fused{int(fused)}]", rel_l2(seq, par)) < 1e-4
+            if fused:
+                assert net.hop_graph_status == "pending"       # flush() ended the stream; its graph went with it
+
+
+def test_stream_after_flush_starts_a_fresh_running_std(cuda):
+    """normalize_input=True: the running mean of the per-frame std (src/network/CleanUMamba.py:399-401) belongs to a
+    stream.  A second clip fed after flush() must come out exactly as from a freshly constructed model."""
+    g = torch.Generator().manual_seed(3)
+    clip1 = (0.3 * torch.randn(1, 5000, generator=g)).to(cuda)
+    clip2 = (0.02 * torch.randn(1, 7000, generator=g)).to(cuda)
+    used, fresh = _net("pruned500k", cuda, pruned=True), _net("pruned500k", cuda, pruned=True)
+    assert used.normalize_input and fresh.normalize_input
+    with torch.no_grad():
+        torch.cat([used.feed(clip1), used.flush()], 1)
+        a = torch.cat([used.feed(clip2), used.flush()], 1)
+        b = torch.cat([fresh.feed(clip2), fresh.flush()], 1)
+    assert a.shape == (1, 7000)
+    assert rel_l2(a, b) < 1e-6
+    assert used.frames > fresh.frames                          # time_per_frame keeps counting across clips

@@ -207,17 +207,18 @@ def test_streaming_step_kernels_vs_golden(cuda):
     assert rel_l2(cs, g["conv_state64"]) < 1e-6
 
 
+@pytest.mark.parametrize("io,tol", [(torch.bfloat16, 4e-3), (torch.float16, 5e-4)])
 @pytest.mark.parametrize("shape", [(2, 192, 64, 150), (1, 70, 20, 33), (2, 53, 8, 40)])   # 53: odd dim, one channel per lane
-def test_scan_and_dwconv_bf16_io_vs_oracle(cuda, shape):
-    """bf16 element type for u / delta / z / out (what autocast hands over; cum_scan_shape.io_dtype): against the
-    f64 oracle on the SAME bf16-rounded inputs the only differences are the kernels' f32 arithmetic and the final
-    rounding of each output to bf16 (2^-9 relative per element), hence rel-L2 <= 4e-3."""
+def test_scan_and_dwconv_16bit_io_vs_oracle(cuda, shape, io, tol):
+    """bf16 / f16 element type for u / delta / z / out (what autocast hands over; cum_scan_shape.io_dtype): against
+    the f64 oracle on the SAME rounded inputs the only differences are the kernels' f32 arithmetic and the final
+    rounding of each output (2^-9 relative per element in bf16, 2^-12 in f16), hence rel-L2 <= 4e-3 / 5e-4."""
     from cleanumamba_amd.causal_conv1d import causal_conv1d_fn
     from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
     bsz, dim, N, L = shape
     g = torch.Generator().manual_seed(sum(shape))
     rn = lambda *s: torch.randn(*s, generator=g)
-    bf = lambda t: t.bfloat16().float()
+    bf = lambda t: t.to(io).float()
     u, delta, z = bf(rn(bsz, L, dim)), bf(0.5 * rn(bsz, L, dim)), bf(rn(bsz, L, dim))
     A = -torch.exp(rn(dim, N) * 0.5)
     Bm, Cm, D, bias = rn(bsz, L, N), rn(bsz, L, N), rn(dim), 0.3 * rn(dim)
@@ -235,28 +236,29 @@ def test_scan_and_dwconv_bf16_io_vs_oracle(cuda, shape):
         out.backward(dout.to(dev).to(out.dtype).transpose(1, 2))
         return [out] + [t.grad for t in leaves + rest]
 
-    got = run(cuda, torch.bfloat16, torch.float32)
+    got = run(cuda, io, torch.float32)
     ref = run(torch.device("cpu"), torch.float64, torch.float64)
-    assert got[0].dtype == torch.bfloat16 and all(t.dtype == torch.bfloat16 for t in got[1:4])
+    assert got[0].dtype == io and all(t.dtype == io for t in got[1:4])
     for name, a, b in zip(("out", "du", "ddelta", "dz", "dA", "dB", "dC", "dD", "dbias"), got, ref):
-        assert rel_l2(a.float(), b) < 4e-3, name
+        assert rel_l2(a.float(), b) < tol, name
 
     # depthwise conv + SiLU, same comparison
     w, cb = rn(dim, 4), rn(dim)
-    xg = u.to(cuda).bfloat16().requires_grad_(True)
+    xg = u.to(cuda).to(io).requires_grad_(True)
     wg, bg = w.to(cuda).requires_grad_(True), cb.to(cuda).requires_grad_(True)
     y = causal_conv1d_fn(xg.transpose(1, 2), wg, bg, "silu")
-    y.backward(dout.to(cuda).bfloat16().transpose(1, 2))
+    y.backward(dout.to(cuda).to(io).transpose(1, 2))
     xr = u.double().requires_grad_(True)
     wr, br = w.double().requires_grad_(True), cb.double().requires_grad_(True)
     yr = M.causal_conv1d_ref(xr.transpose(1, 2), wr, br, "silu")
     yr.backward(dout.double().transpose(1, 2))
-    assert y.dtype == torch.bfloat16 and xg.grad.dtype == torch.bfloat16 and wg.grad.dtype == torch.float32
+    assert y.dtype == io and xg.grad.dtype == io and wg.grad.dtype == torch.float32
     for name, a, b in (("y", y, yr), ("dx", xg.grad, xr.grad), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad)):
-        assert rel_l2(a.float(), b) < 4e-3, name
+        assert rel_l2(a.float(), b) < tol, name
 
 
-@pytest.mark.parametrize("dim,dt", [(512, torch.float32), (512, torch.bfloat16), (72, torch.float32), (2048, torch.bfloat16)])
+@pytest.mark.parametrize("dim,dt", [(512, torch.float32), (512, torch.bfloat16), (72, torch.float32), (2048, torch.bfloat16),
+                                    (512, torch.float16), (2048, torch.float16)])
 def test_add_layernorm_vs_torch(cuda, dim, dt):
     """Residual add + LayerNorm (csrc/layernorm.hip) against the separate torch ops the reference executes
     (Block.forward, fused_add_norm=False), evaluated in float64: forward 1e-6 (f32 output) / bf16 rounding,
@@ -281,10 +283,10 @@ def test_add_layernorm_vs_torch(cuda, dim, dt):
     res_d = hd + rd
     y_d = torch.nn.functional.layer_norm(res_d, (dim,), wd, bd, 1e-5)
     ((y_d * gy.double()).sum() + (res_d * gr.double()).sum()).backward()
-    lo = dt == torch.bfloat16
+    ytol, gtol = {torch.float32: (1e-6, 1e-5), torch.bfloat16: (4e-3, 5e-3), torch.float16: (5e-4, 7e-4)}[dt]
     assert rel_l2(res, res_d) < 1e-6
-    assert rel_l2(y.float(), y_d) < (4e-3 if lo else 1e-6)
-    assert rel_l2(base.grad[:, :L, :dim].float(), hd.grad) < (5e-3 if lo else 1e-5)
+    assert rel_l2(y.float(), y_d) < ytol
+    assert rel_l2(base.grad[:, :L, :dim].float(), hd.grad) < gtol
     assert float(base.grad[:, L:].abs().max()) == 0.0
     for a, bb in ((r.grad, rd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
         assert rel_l2(a, bb) < 1e-5

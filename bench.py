@@ -57,11 +57,10 @@ MFMA_PEAK_TFS = 2500.0      # MI355X_MICROARCH.md: bf16 / f16 dense
 # in this run: a constant from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over
 # tools/bench_gemm.py tn, corrected as MI355X_MICROARCH.md prescribes (profiles/r01_gemm_tn_pmc.md).
 TN_TRAFFIC_BYTES = 409.1e6
-# selective-scan issue roof: state updates per clock and SIMD of the bare inner-loop instruction mix (v_pk_mul,
-# 2 x v_exp_f32, v_pk_mul, 2 x v_pk_fma per state pair = 32 issue cycles per 128 lane-updates; MI355X_MICROARCH.md
-# cycle table), times 1024 SIMDs, times the clock the chip holds under that loop (tools/clock_probe.hip)
-SCAN_UPDATES_PER_CLK_SIMD = 4.0
-SCAN_CLOCK_GHZ = float(os.environ.get("CUM_SCAN_CLOCK_GHZ", "2.1"))
+# selective-scan issue roof, MEASURED: the bare inner-loop instruction mix of the forward kernel (per state pair v_pk_mul,
+# 2 x v_exp_f32, v_pk_mul, 2 x v_pk_fma) on registers only, every SIMD of the chip busy (tools/clock_probe.hip)
+SCAN_ISSUE_ROOF = 8.6e12     # state updates / s: tools/clock_probe.hip on MI355X (profiles/r02_clock_probe.txt: 8.56-8.89 T/s
+                             # at 6-8 waves per SIMD, clock 2.30-2.36 GHz = 3.6-3.7 updates per clock and SIMD)
 
 B16 = 16
 ENC_T = [160254, 80126, 40062, 20030, 10014, 5006, 2502, 1250, 624]
@@ -151,9 +150,9 @@ def _scan_case(dev, bsz, dim, Ns, L, io, backward):
 def scan_rows(dev, dt):
     """The north_star kernel against both of its roofs.  Algorithmic bytes: SURVEY.md 8(d), B*T*(s*4*D + 4*2*N) forward
     (u, delta, z, out in the I/O type of s bytes; B, C in f32), B*T*(s*7*D + 4*4*N) backward.  State updates: B*T*D*N.
-    HBM roof 8 TB/s; issue roof = SCAN_UPDATES_PER_CLK_SIMD * 1024 SIMDs * SCAN_CLOCK_GHZ (one v_exp_f32 per update).
+    HBM roof 8 TB/s; issue roof = SCAN_ISSUE_ROOF, the measured rate of the bare update loop (one v_exp_f32 per update).
     At d_state 64 the issue roof binds; at d_state <= 16 the HBM roof does."""
-    issue_roof = SCAN_UPDATES_PER_CLK_SIMD * 1024 * SCAN_CLOCK_GHZ * 1e9
+    issue_roof = SCAN_ISSUE_ROOF
     cases = [("E8 bottleneck B=16 D=2048 N=64 L=624", 16, 2048, 64, 624, dt, True),
              ("E8 bottleneck, f32 I/O", 16, 2048, 64, 624, torch.float32, False),
              ("E6 bottleneck B=32 D=2048 N=64 L=2499", 32, 2048, 64, 2499, dt, False),
@@ -161,6 +160,9 @@ def scan_rows(dev, dt):
              ("D=2048 N=16 L=2499 B=16, f32 I/O", 16, 2048, 16, 2499, torch.float32, False),
              ("D=2048 N=8 L=2499 B=16", 16, 2048, 8, 2499, dt, True),
              ("D=2048 N=8 L=2499 B=16, f32 I/O", 16, 2048, 8, 2499, torch.float32, False),
+             ("D=2048 N=16 L=2499 B=128, f32 I/O", 128, 2048, 16, 2499, torch.float32, False),
+             ("D=2048 N=8 L=2499 B=128, f32 I/O", 128, 2048, 8, 2499, torch.float32, False),
+             ("D=2048 N=8 L=2499 B=128", 128, 2048, 8, 2499, dt, False),
              ("442K model B=16 D=128 N=16 L=624", 16, 128, 16, 624, torch.float32, False),
              ("pruned-E8 block B=256 D=48 N=8 L=1875 (30 s)", 256, 48, 8, 1875, torch.float32, False)]
     rows = []

@@ -41,15 +41,21 @@ def count_layers(sd, prefix):
     return (max(idx) + 1) if idx else 0
 
 
-def encoder_layer(sd, i, x, stride=2):
+def encoder_layer(sd, i, x, stride=2, store=None):
+    """``store``: optional map applied to the H-channel intermediate (tests pass the straight-through rounding to the
+    16-bit type a kernel path stores it in); None = the reference arithmetic."""
     p = f"encoder.{i}."
     x = F.relu(F.conv1d(x, sd[p + "0.weight"], sd[p + "0.bias"], stride=stride))
+    if store is not None:
+        x = store(x)
     return glu(F.conv1d(x, sd[p + "2.weight"], sd[p + "2.bias"]))
 
 
-def decoder_layer(sd, j, x, last, stride=2):
+def decoder_layer(sd, j, x, last, stride=2, store=None):
     p = f"decoder.{j}."
     x = glu(F.conv1d(x, sd[p + "0.weight"], sd[p + "0.bias"]))
+    if store is not None:
+        x = store(x)
     x = F.conv_transpose1d(x, sd[p + "2.weight"], sd[p + "2.bias"], stride=stride)
     return x if last else F.relu(x)
 

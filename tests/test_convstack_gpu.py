@@ -23,6 +23,15 @@ def _rounded(t, dtype):
     return t.to(dtype).double()
 
 
+def _store(dtype):
+    """Straight-through rounding of the H-channel intermediate to the type the kernels store it in: without it the
+    ReLU behind the decoder's transposed conv gates on pre-activations that differ by one rounding step of its INPUT,
+    and the flipped gates (not the kernels) set the input-gradient error (3e-2 bf16 / 2e-2 f16 measured)."""
+    if dtype == torch.float32:
+        return None
+    return lambda t: t + (t.to(dtype).double() - t).detach()
+
+
 def _layer_params(cin, h, cout, seed):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
@@ -46,7 +55,7 @@ def test_encoder_layer_fwd_bwd(cuda, cin, h, tin, dtype):
     ref = {k: (_rounded(v, dtype) if k.endswith("weight") else v.double()).requires_grad_(True)
            for k, v in sd.items() if k.startswith("encoder")}          # biases stay f32 in the kernels
     xr = _rounded(x, dtype).requires_grad_(True)
-    yr = R.encoder_layer(ref, 0, xr)
+    yr = R.encoder_layer(ref, 0, xr, store=_store(dtype))
     (yr * dout.double()).sum().backward()
 
     dev = {k: v.to(cuda).requires_grad_(True) for k, v in sd.items() if k.startswith("encoder")}
@@ -81,7 +90,7 @@ def test_decoder_layer_fwd_bwd(cuda, h, cout, t, relu, with_skip, dtype):
     ref = {k: (_rounded(v, dtype) if k.endswith("weight") else v.double()).requires_grad_(True)
            for k, v in sd.items() if k.startswith("decoder")}
     xr, sr = _rounded(x, dtype).requires_grad_(True), _rounded(skip, dtype).requires_grad_(True)
-    yr = R.decoder_layer(ref, 0, xr, last=not relu)
+    yr = R.decoder_layer(ref, 0, xr, last=not relu, store=_store(dtype))
     if with_skip:
         yr = yr + sr
     (yr * dout.double()).sum().backward()

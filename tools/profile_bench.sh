@@ -10,13 +10,11 @@ python3 - /tmp/short/step_results.db <<'PY' > $OUT/short_gaps.txt
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select start, end, name from kernels order by start").fetchall()
-# the last 10 steps: split by the Adam kernel (FusedOptimizer multi_tensor_apply)
-idx = [i for i, r in enumerate(rows) if "FusedOptimizerTensorListMetadata" in r[2] or "fused_adam" in r[2].lower()]
+# the last 10 steps: split by the Adam kernel (csrc/optim.hip: one optim_adam_kernel launch per step)
+idx = [i for i, r in enumerate(rows) if "optim_adam_kernel" in r[2]]
 print("kernels", len(rows), "adam launches", len(idx))
 if len(idx) >= 12:
-    a, b = idx[-11*3], idx[-1*3] if False else idx[-1]
-    # step boundaries every 3 adam launches
-    ends = idx[2::3]
+    ends = idx
     a, b = ends[-11], ends[-1]
     seg = rows[a + 1:b + 1]
     wall = (seg[-1][1] - seg[0][0]) / 1e6

@@ -431,17 +431,28 @@ class CleanUMamba(nn.Module):
                 return t.transpose(1, 2)[:, :self.decoder[j][2].weight.shape[1]].float()
             return t.float()                                   # cached path: (S, C, 2)
 
+        def conv_t(g, conv):
+            """ConvTranspose1d on a handful of columns as one matmul + K strided adds (the few-column shapes of the
+            drain are not worth a MIOpen solver search, and small transposed convs abort in MIOpen on some boxes)."""
+            w, K, S = conv.weight.float(), self.kernel_size, self.stride           # (Cin, Cout, K)
+            T = g.shape[-1]
+            taps = torch.einsum("bct,cok->bokt", g, w)
+            out = conv.bias.float().view(1, -1, 1).repeat(g.shape[0], 1, (T - 1) * S + K)
+            for k in range(K):
+                out[..., k:k + (T - 1) * S + 1:S] += taps[:, :, k]
+            return out
+
         x = None
         for j, dec in enumerate(self.decoder):
-            w = dec[2].weight
             if j == 0:
-                y = tail(0).to(w.dtype) + dec[2].bias.view(1, -1, 1)
+                y = tail(0) + dec[2].bias.float().view(1, -1, 1)
             else:
-                x = x + trailing_skip(E - 1 - j)[..., :x.shape[-1]].to(x.dtype)
-                y = dec[2](dec[1](dec[0](x)))
-                y[..., :self.stride] += tail(j).to(y.dtype)
+                x = x + trailing_skip(E - 1 - j)[..., :x.shape[-1]]
+                pre = torch.einsum("oc,bct->bot", dec[0].weight.float().squeeze(-1), x) + dec[0].bias.float().view(1, -1, 1)
+                y = conv_t(dec[1](pre), dec[2])
+                y[..., :self.stride] += tail(j)
             if j != E - 1:
-                y = dec[3](y)
+                y = torch.relu(y)
             x = y
         out = x[:, 0]
         if self.normalize_input:

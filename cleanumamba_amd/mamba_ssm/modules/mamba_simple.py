@@ -43,6 +43,8 @@ class _ProjFn(torch.autograd.Function):
         xc, wc = x.to(cd), w.to(cd)
         ctx.save_for_backward(xc, wc)
         ctx.x_dtype, ctx.w_dtype = x.dtype, w.dtype
+        # the parameter itself (identity only: gradient-sink lookup), when the weight is an f32 leaf
+        ctx.weight = w if (w.is_leaf and w.dtype == torch.float32) else None
         return F.linear(xc, wc)
 
     @staticmethod
@@ -61,8 +63,15 @@ class _ProjFn(torch.autograd.Function):
                 x2 = x2.contiguous()
             if d2.stride(1) != 1 or d2.stride(0) % 8 or d2.data_ptr() % 16:
                 d2 = d2.contiguous()
-            dw, _ = cs.wgrad(d2, 0, d2.stride(0), N, x2, 0, x2.stride(0), K, x2.shape[0], want_bias=False)
-            dw = dw.to(ctx.w_dtype)
+            sink = cs.grad_sink([ctx.weight]) if ctx.weight is not None else None
+            if sink is not None:           # straight into the flat gradient buffer (training/flat_optim.py)
+                flat, idx, offs = sink
+                cs.wgrad(d2, 0, d2.stride(0), N, x2, 0, x2.stride(0), K, x2.shape[0], want_bias=False,
+                         out_w=flat.grad[offs[0]:offs[0] + N * K])
+                flat.wrote(idx)
+            else:
+                dw, _ = cs.wgrad(d2, 0, d2.stride(0), N, x2, 0, x2.stride(0), K, x2.shape[0], want_bias=False)
+                dw = dw.to(ctx.w_dtype)
         return dx, dw, None
 
 

@@ -105,13 +105,18 @@ class small_m_gemms:
         _SPLIT_K_OK = self.prev
 
 
-def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True, out=None):
+def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True, out=None, out_w=None, out_b=None):
     """dW [N, K] f32 = dZ^T X (X rows may overlap), db [N] f32 = column sums of dZ.  csrc/gemm_tn.hip.
-    ``out = (flat f32 buffer, offset)`` places dW then db at that offset (N*K + N elements) instead of allocating."""
+    ``out = (flat f32 buffer, offset)`` places dW then db at that offset (N*K + N elements) instead of allocating;
+    ``out_w`` / ``out_b``: contiguous f32 tensors of N*K / N elements that receive dW / db (gradient views of the
+    flat buffer, see grad_sink)."""
     lib = hip.lib()
     dc = hip.dtype_code(dZ.dtype)
     dev = dZ.device
-    if out is not None:
+    if out_w is not None:
+        dW = out_w.view(N, K)
+        db = (out_b if out_b is not None else torch.empty(N, dtype=torch.float32, device=dev)) if want_bias else None
+    elif out is not None:
         arena, off = out
         dW = arena[off:off + N * K].view(N, K)
         db = arena[off + N * K:off + N * K + N] if want_bias else None
@@ -280,6 +285,29 @@ _ARENA_BATCH = os.environ.get("CUM_WGRAD_ARENA", "1") != "0"      # "0": one gat
 _ARENA_INDEX = {}
 
 
+def grad_sink(params):
+    """(FlatParams, [index], [offset]) if every parameter's gradient may be WRITTEN into the flat gradient buffer of
+    training/flat_optim.py right now (all flat-managed by one buffer, nothing accumulated since zero_grad), else None.
+    Producers then skip autograd's AccumulateGrad: one launch instead of one read-read-write add per tensor."""
+    from ..training.flat_optim import sink_of
+    flat = sink_of(params[0])
+    if flat is None or not _GRAD_SINK:
+        return None
+    idx, offs = [], []
+    for p in params:
+        if sink_of(p) is not flat:
+            return None
+        sl = flat.slot(p)
+        if sl is None:
+            return None
+        idx.append(sl[0])
+        offs.append(sl[1])
+    return flat, idx, offs
+
+
+_GRAD_SINK = os.environ.get("CUM_GRAD_SINK", "1") != "0"        # "0": every gradient goes through AccumulateGrad (A/B)
+
+
 class _WgradArena:
     def __init__(self, sizes, dev):
         """sizes: [(N, K)] per weight-gradient GEMM, in slot order."""
@@ -302,6 +330,23 @@ class _WgradArena:
         ids = inv_ids.reshape(-1)
         return torch.where(ids > 0, ids - 1 + self.offs[slot] + N * K, torch.full_like(ids, -1))
 
+    def unpack_into(self, key, build_parts, shapes, dst, offs):
+        """The same gather with the flat gradient buffer ``dst`` as destination: parameter k lands at element offset
+        offs[k]; elements between parameters (alignment padding) are written as zeros.  One launch."""
+        lo = min(offs)
+        hi = max(o + _numel(sh) for o, sh in zip(offs, shapes))
+        if sum((_numel(sh) + 3) // 4 * 4 for sh in shapes) < hi - lo:
+            raise RuntimeError("unpack_into: the parameters are not one contiguous run of the flat buffer")
+        ck = (key, "into", tuple(o - lo for o in offs), self.buf.device)
+        ent = _ARENA_INDEX.get(ck)
+        if ent is None:
+            full = torch.full((hi - lo,), -1, dtype=torch.int64)
+            for part, o, sh in zip(build_parts(), offs, shapes):
+                full[o - lo:o - lo + _numel(sh)] = part.reshape(-1)
+            ent = full.to(torch.int32).to(self.buf.device)
+            _ARENA_INDEX[ck] = ent
+        gather(self.buf, ent, torch.float32, out=dst[lo:hi])
+
     def unpack(self, key, build_parts, shapes):
         """One gather for all parameters; build_parts() -> [index tensor per parameter]; returns views per shape."""
         ent = _ARENA_INDEX.get((key, self.buf.device))
@@ -317,6 +362,20 @@ class _WgradArena:
             outs.append(flat[off:off + n].view(sh))
             off += n
         return outs
+
+
+def _contiguous_run(offs, shapes):
+    """True if the parameters (16-byte aligned, as FlatParams lays them out) fill [min offset, max end) without strangers."""
+    lo = min(offs)
+    hi = max(o + _numel(sh) for o, sh in zip(offs, shapes))
+    return sum((_numel(sh) + 3) // 4 * 4 for sh in shapes) >= hi - lo
+
+
+def _numel(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
 
 
 def lay_conv_fwd(wshape, cp_in, rows, cols):
@@ -574,6 +633,7 @@ class Pointwise(torch.autograd.Function):
         gemm(xbuf, gi.Cp, gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_BIAS, go.Cp,
              res=skip, r_off=go.Cp, ldr=go.Cp, geo=go)
         ctx.gi, ctx.go, ctx.has_skip = gi, go, skip is not None
+        ctx.bias = b                         # the parameter object: only its identity is used (gradient sink lookup)
         ctx.save_for_backward(xbuf, w)
         return ybuf
 
@@ -584,9 +644,18 @@ class Pointwise(torch.autograd.Function):
         dt, dev = xbuf.dtype, xbuf.device
         Cout, Cin, _ = w.shape
         dy = dy.contiguous()
-        dwp, dbp = wgrad(dy, go.Cp, go.Cp, go.Cp, xbuf, gi.Cp, gi.Cp, gi.Cp, go.M)
-        db = dbp[:Cout]
-        dw = dwp[:Cout, :Cin].unsqueeze(-1)
+        b = ctx.bias
+        sink = grad_sink([w, b]) if (b is not None and Cout == go.Cp and Cin == gi.Cp) else None
+        if sink is not None:               # dW / db written straight into the flat gradient buffer
+            flat, idx, offs = sink
+            wgrad(dy, go.Cp, go.Cp, go.Cp, xbuf, gi.Cp, gi.Cp, gi.Cp, go.M,
+                  out_w=flat.grad[offs[0]:offs[0] + Cout * Cin], out_b=flat.grad[offs[1]:offs[1] + Cout])
+            flat.wrote(idx)
+            dw = db = None
+        else:
+            dwp, dbp = wgrad(dy, go.Cp, go.Cp, go.Cp, xbuf, gi.Cp, gi.Cp, gi.Cp, go.M)
+            db = dbp[:Cout].to(w.dtype)
+            dw = dwp[:Cout, :Cin].unsqueeze(-1).to(w.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
             Nd, Kd = rup(gi.Cp, 16), rup(go.Cp, bk_of(dt))
@@ -594,7 +663,7 @@ class Pointwise(torch.autograd.Function):
             wt = take(w, ("plain_dgrad", sh, Nd, Kd), lambda: lay_plain(sh, Nd, Kd, transpose=True), dt)
             dx = gi.new(dt, dev)
             gemm(dy, go.Cp, go.Cp, wt, None, dx, gi.Cp, gi.Cp, gi.M, gi.P, gi.T, hip.EPI_BIAS, gi.Cp, geo=gi)
-        return dx, dw.to(w.dtype), db.to(w.dtype), (dy if ctx.has_skip else None), None, None
+        return dx, dw, db, (dy if ctx.has_skip else None), None, None
 
 
 # ===================================================================== row <-> tensor glue
@@ -816,7 +885,16 @@ class EncoderStack(torch.autograd.Function):
                     out.append(arena.db_index(2 * i + 1, _invert(lay_glu_vec(sh2[0]), (sh2[0],))))
                 return out
             key = ("enc", tuple(shapes), tuple((g[0].Cp, g[1].Cp) for g in geos), tuple(z.shape[1] for z in zs))
-            grads = [g.to(p.dtype) for g, p in zip(arena.unpack(key, parts, shapes), params)]
+            sink = grad_sink(params)
+            if sink is not None and not _contiguous_run(sink[2], shapes):
+                sink = None
+            if sink is not None:           # straight into the flat gradient buffer: no AccumulateGrad adds
+                flat, idx, offs = sink
+                arena.unpack_into(key, parts, shapes, flat.grad, offs)
+                flat.wrote(idx)
+                grads = [None] * len(params)
+            else:
+                grads = [g.to(p.dtype) for g, p in zip(arena.unpack(key, parts, shapes), params)]
         return (dx0, None, None, *grads)
 
 
@@ -930,8 +1008,34 @@ class DecoderStack(torch.autograd.Function):
                     out.append(arena.dw_index(2 * j + 1, _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)))
                 return out
             key = ("dec", tuple(shapes), tuple((g[0].Cp, g[1].Cp, g[2].Cp) for g in geos), tuple(z.shape[1] for z in zs))
-            un = arena.unpack(key, parts, shapes)
-            for j in range(E):
-                for k in range(3):
-                    grads[4 * j + k] = un[3 * j + k].to(params[4 * j + k].dtype)
+            three = [params[4 * j + k] for j in range(E) for k in range(3)]
+            sink = grad_sink(three)
+            if sink is not None:           # w1, b1, wt straight into the flat gradient buffer (bt keeps the autograd path)
+                flat, idx, offs = sink
+                # the transposed-conv biases sit between the gathered parameters: they must not be overwritten with
+                # zeros by the gap fill, so the gather runs per contiguous run of gathered parameters
+                order = sorted(range(len(three)), key=lambda q: offs[q])
+                runs, cur = [], [order[0]]
+                for q_prev, q in zip(order, order[1:]):
+                    end_prev = offs[q_prev] + (_numel(shapes[q_prev]) + 3) // 4 * 4
+                    if offs[q] == end_prev:
+                        cur.append(q)
+                    else:
+                        runs.append(cur)
+                        cur = [q]
+                runs.append(cur)
+                all_parts = None
+                for r, run in enumerate(runs):
+                    def run_parts(run=run):
+                        nonlocal all_parts
+                        if all_parts is None:
+                            all_parts = parts()
+                        return [all_parts[q] for q in run]
+                    arena.unpack_into((key, r), run_parts, [shapes[q] for q in run], flat.grad, [offs[q] for q in run])
+                flat.wrote(idx)
+            else:
+                un = arena.unpack(key, parts, shapes)
+                for j in range(E):
+                    for k in range(3):
+                        grads[4 * j + k] = un[3 * j + k].to(params[4 * j + k].dtype)
         return (du, None, None, None, *dskips, *grads)

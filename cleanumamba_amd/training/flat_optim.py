@@ -13,6 +13,7 @@ second one, so that
 The host only writes the learning rate into the device-side state vector before each step.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -20,6 +21,18 @@ from .. import hip
 
 # layout of the device-side state vector (csrc/optim.hip)
 ST_NORM, ST_MULT, ST_FOUND_INF, ST_SCALE, ST_TRACKER, ST_STEP, ST_BC1, ST_BC2_SQRT, ST_LR, ST_SKIPPED = range(10)
+
+
+_SINKS = {}          # parameter data_ptr -> weakref(FlatParams) that owns it
+
+
+def sink_of(param):
+    """The FlatParams whose flat buffers hold ``param`` (None if the parameter is not flat-managed)."""
+    ref = _SINKS.get(param.data_ptr())
+    flat = ref() if ref is not None else None
+    if flat is None or flat.by_ptr.get(param.data_ptr()) is None:
+        return None
+    return flat
 
 
 class FlatParams:
@@ -59,6 +72,12 @@ class FlatParams:
                 p.grad = gview
                 self.grad_views.append(gview)
         self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
+        # fresh[i]: nothing has been accumulated into gradient i since zero_grad() -- a producer may then WRITE its
+        # result into the view (GradSink below) instead of handing it to autograd's AccumulateGrad (read-read-write)
+        self.fresh = [False] * len(self.params)
+        for p in self.params:
+            _SINKS[p.data_ptr()] = weakref.ref(self)
 
     def intact(self):
         """False once somebody re-pointed a parameter (``.to()``, pruning, load_pruned_state_dict ...)."""
@@ -76,6 +95,24 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
         self.attach_grads()
+        self.fresh = [True] * len(self.params)
+
+    # ---- gradient sink: kernels write parameter gradients straight into the flat buffer
+    def slot(self, param):
+        """(index, element offset) of ``param`` if its gradient view may be overwritten now, else None."""
+        i = self.by_ptr.get(param.data_ptr())
+        if i is None or not self.fresh[i] or param.grad is not self.grad_views[i]:
+            return None
+        return i, self.offsets[i]
+
+    def wrote(self, indices):
+        """The gradients of these parameters now sit in their views (they are no longer fresh); tell the exchange."""
+        for i in indices:
+            self.fresh[i] = False
+        if self.on_write is not None:
+            self.on_write([self.params[i] for i in indices])
+
+    on_write = None
 
     def slices(self, max_bytes):
         """Contiguous (start, end, [param indices]) ranges of at most ``max_bytes`` (cut at parameter boundaries)."""

@@ -72,6 +72,12 @@ class GradBuckets:
             self.buckets.append([self.flat.grad[start:end], plist, len(plist)])
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
+        self.flat.on_write = self._written
+
+    def _written(self, params):
+        """Gradients a kernel wrote straight into the flat buffer (FlatParams.wrote): same bookkeeping as the hook."""
+        for p in params:
+            self._ready(p)
 
     def zero_grad(self):
         self.flat.zero_grad()
@@ -83,6 +89,11 @@ class GradBuckets:
             if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
             p.grad = view
+        self.flat.fresh[self.flat.index[id(p)]] = False
+        self._ready(p)
+
+    def _ready(self, p):
+        idx = self.where[id(p)][0]
         if self.world == 1 or not self.require_sync:
             return
         if not self._armed:

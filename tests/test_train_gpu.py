@@ -32,9 +32,10 @@ def _synth_net(name, cuda):
 
 # rel-L2 of the 16-bit autocast forward against the reference class's f32 output on the same weights and input
 # (tests/golden/e2e_e{8,6}_synth.npz): ~2.5x the values measured on MI355X (gpurun_out/test_measured.jsonl:
-# E8 4.7e-2 / 7.6e-3, E6 1.08e-1 / 2.5e-2 for bf16 / f16 -- 22 layers of 2^-9 resp. 2^-12 rounding on random weights).
-# The tight criterion is the second one: no worse than the vendor libraries (MIOpen / hipBLASLt conv modules under
-# the same autocast) at the same precision.
+# E8 4.7e-2 / 7.6e-3, E6 1.08e-1 / 2.5e-2 for bf16 / f16 -- 22 layers of 2^-9 resp. 2^-12 storage rounding on random
+# weights; the torch conv modules on MIOpen / hipBLASLt under the same autocast measured 5.7e-2 / 1.5e-2 and
+# 1.37e-1 / 3.8e-2, i.e. the fused path is the more accurate one).  The kernels themselves are pinned per layer in
+# test_convstack_gpu.py (3e-3 bf16 / 5e-4 f16 against a rounding-aware f64 reference).
 AUTOCAST_TOL = {("e2e_e8_synth", torch.bfloat16): 0.12, ("e2e_e8_synth", torch.float16): 0.02,
                 ("e2e_e6_synth", torch.bfloat16): 0.27, ("e2e_e6_synth", torch.float16): 0.06}
 
@@ -44,45 +45,40 @@ AUTOCAST_TOL = {("e2e_e8_synth", torch.bfloat16): 0.12, ("e2e_e8_synth", torch.f
 def test_autocast_forward_vs_reference_output(cuda, name, dtype):
     """E8 / E6 under bf16 and fp16 autocast (every activation and GEMM operand 16-bit, f32 accumulate, Mamba
     recurrence in f32) against the f32 output of the reference class.  north_star's 1e-4 is an f32 statement
-    (test_model_gpu.py); this pins what the 16-bit training modes cost on the full-width models, and holds the fused
-    kernels to the error the torch conv modules make at the same precision."""
+    (test_model_gpu.py); this pins what the 16-bit training modes cost on the full-width models."""
     net, g, meta = _synth_net(name, cuda)
     net.eval()
     _, noisy = synth.waveform(2, meta["L"], seed=meta["wave_seed"])
-    errs = {}
     with torch.no_grad():
-        for fused in (True, False):
-            net.use_fused_convs = fused
-            with torch.autocast("cuda", dtype=dtype):
-                y = net(noisy.to(cuda))
-            assert y.dtype == torch.float32
-            errs[fused] = record(f"autocast_fwd[{name}-{dtype}-fused{int(fused)}]", rel_l2(y, g["out"]))
-        net.use_fused_convs = True
-        assert errs[True] < AUTOCAST_TOL[(name, dtype)]
-        assert errs[True] < 1.5 * errs[False] + 1e-3
+        with torch.autocast("cuda", dtype=dtype):
+            y = net(noisy.to(cuda))
+        assert y.dtype == torch.float32
+        assert record(f"autocast_fwd[{name}-{dtype}]", rel_l2(y, g["out"])) < AUTOCAST_TOL[(name, dtype)]
         if dtype == torch.float16:             # torch.autocast("cuda") with no dtype IS fp16: the reference's call
-            with torch.autocast("cuda", dtype=dtype):
-                y = net(noisy.to(cuda))
             with torch.autocast("cuda"):
                 y2 = net(noisy.to(cuda))
             assert torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_autocast_gradients_vs_f32(cuda, dtype):
-    """Backward under autocast on E8: parameter gradients against the f32 run of the same model and batch.  Through 16
-    ReLU layers a 16-bit forward flips the gates whose pre-activation lies within one rounding step of zero, which
-    moves an end-to-end gradient by tens of percent in rel-L2 whatever the kernels do (f32 vs f32 implementations:
-    0.3-1.5 %, test_model_gpu.py) -- so the yardstick is the same model with its conv layers on MIOpen / hipBLASLt
-    under the same autocast: the fused path must not be further from the f32 gradient than that."""
-    net, g, meta = _synth_net("e2e_e8_synth", cuda)
+@pytest.mark.parametrize("name", ["e2e_e8_synth", "e2e_e6_synth"])
+def test_autocast_gradients_vs_reference(cuda, name, dtype):
+    """Backward under autocast on E8 / E6 against gradients the reference class produced (f32, golden).
+    * The last decoder layer's transposed-conv weight sits behind no ReLU: its gradient dW = dy^T g depends on the
+      forward activations only, so it carries the forward's 16-bit error and nothing else -> bound = the forward bound.
+    * Every other gradient passes ReLU gates; a 16-bit forward flips the gates whose pre-activation lies within one
+      rounding step of zero, which moves an end-to-end gradient by tens of percent in rel-L2 whatever the kernels do
+      (f32 vs f32 implementations: 0.3-1.5 %, test_model_gpu.py; measured here 0.77 bf16 / 0.32 f16, and 1.24 / 0.40 with
+      the conv layers on MIOpen / hipBLASLt).  They are held to finiteness and to the direction of the f32 gradient."""
+    net, g, meta = _synth_net(name, cuda)
     net.train()
     clean, noisy = synth.waveform(2, meta["L"], seed=meta["wave_seed"])
     clean, noisy = clean.to(cuda), noisy.to(cuda)
+    E = meta["cfg"]["encoder_n_layers"]
+    last = f"decoder.{E - 1}.2.weight"
     grads = {}
-    for tag, ac, fused in (("f32", None, True), ("lo", dtype, True), ("lib", dtype, False)):
+    for tag, ac in (("f32", None), ("lo", dtype)):
         net.zero_grad(set_to_none=True)
-        net.use_fused_convs = fused
         if ac is None:
             y = net(noisy)
         else:
@@ -90,14 +86,16 @@ def test_autocast_gradients_vs_f32(cuda, dtype):
                 y = net(noisy)
         scale = 1024.0 if ac == torch.float16 else 1.0          # keep fp16 activation gradients out of the subnormals
         ((y * clean).sum() * scale).backward()
+        named = dict(net.named_parameters())
         grads[tag] = torch.cat([p.grad.reshape(-1) / scale for p in net.parameters()])
-    net.use_fused_convs = True
+        grads[tag + "_last"] = named[last].grad.detach().flatten()[:4096] / scale
     assert torch.isfinite(grads["lo"]).all()
-    err = record(f"autocast_grad[e8-{dtype}].fused", rel_l2(grads["lo"], grads["f32"]))
-    lib = record(f"autocast_grad[e8-{dtype}].lib", rel_l2(grads["lib"], grads["f32"]))
-    assert err < 1.3 * lib + 0.02
+    want = torch.from_numpy(g["grad:" + last])
+    assert rel_l2(grads["f32_last"], want) < 1e-5
+    assert record(f"autocast_grad_last[{name}-{dtype}]", rel_l2(grads["lo_last"], want)) < AUTOCAST_TOL[(name, dtype)]
+    record(f"autocast_grad_all[{name}-{dtype}].rel", rel_l2(grads["lo"], grads["f32"]))
     cos = torch.nn.functional.cosine_similarity(grads["lo"].double(), grads["f32"].double(), dim=0).item()
-    assert record(f"autocast_grad[e8-{dtype}].cos", cos) > 0.5
+    assert record(f"autocast_grad_all[{name}-{dtype}].cos", cos) > 0.5
 
 
 def test_train_step_fp16_autocast_e8(cuda):
@@ -225,6 +223,32 @@ def test_gradient_accumulation_equals_one_big_batch(cuda):
     assert abs(float(l1) - float(l2)) < 1e-6 * abs(float(l1))
     assert rel_l2(two.buckets.flat.grad, one.buckets.flat.grad) < 1e-5
     assert rel_l2(two.buckets.flat.data, one.buckets.flat.data) < 1e-6
+
+
+def test_gradient_sink_equals_autograd_accumulation(cuda, monkeypatch):
+    """Kernels that write parameter gradients straight into the flat gradient buffer (convstack.grad_sink: the conv
+    stacks' batched un-pack, the 1x1 bottleneck convs, the Mamba projections) against the same backward with every
+    gradient routed through autograd's AccumulateGrad: bit-identical buffers; a second backward without zero_grad
+    accumulates."""
+    from cleanumamba_amd.network import convstack as cs
+    from cleanumamba_amd.training.train_step import TrainStep
+    clean, noisy = synth.waveform(2, 8000, seed=4)
+    clean, noisy = clean.to(cuda), noisy.to(cuda)
+    grads = {}
+    for sink in (True, False):
+        monkeypatch.setattr(cs, "_GRAD_SINK", sink)
+        net = _net442(cuda)
+        step = TrainStep(net, optimization={"n_iters": 100}, use_graph=False)
+        step.zero_grad()
+        step.micro_step(clean, noisy)
+        flat = step.buckets.flat
+        if sink:
+            assert sum(not f for f in flat.fresh) == len(flat.params)      # every gradient arrived, by either route
+        grads[sink] = flat.grad.clone()
+        step.micro_step(clean, noisy)                                      # no zero_grad: accumulates on both routes
+        assert rel_l2(flat.grad, 2 * grads[sink]) < 1e-6
+    assert torch.equal(grads[True], grads[False])
+    assert float(grads[True].abs().sum()) > 0
 
 
 def _free_port():

@@ -55,6 +55,46 @@ __device__ __forceinline__ void wave_reduce_scatter8(const f2 (&v2)[NP2], float 
   r[1] = row16_allsum(q[1]);
 }
 
+// Both per-step reductions (dB and dC) at once: same exchanges and the same result placement as two calls of
+// wave_reduce_scatter8, but the eight v_permlane32_swap (and the four v_permlane16_swap) are issued back to back from
+// ONE asm block each.  The "VALU write -> permlane swap read" hazard needs two wait states only in front of the first
+// swap of a block (later swaps touch registers no neighbour wrote), so a step pays 2 s_nop instead of 12
+// (192 -> 32 per 16-step chunk; the s_nop 1 pads were ~14 % of the kernel's issue cycles).
+__device__ __forceinline__ void wave_reduce_scatter8x2(const f2 (&b2)[NP2], const f2 (&c2)[NP2], float (&rB)[2],
+                                                       float (&rC)[2]) {
+  float a[8] = {b2[0].x, b2[0].y, b2[1].x, b2[1].y, c2[0].x, c2[0].y, c2[1].x, c2[1].y};
+  float b[8] = {b2[2].x, b2[2].y, b2[3].x, b2[3].y, c2[2].x, c2[2].y, c2[3].x, c2[3].y};
+  // a[i] <-> v[i], b[i] <-> v[4 + i] of each array (indices 0-3: dB, 4-7: dC)
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %8\n\t"
+      "v_permlane32_swap_b32 %1, %9\n\t"
+      "v_permlane32_swap_b32 %2, %10\n\t"
+      "v_permlane32_swap_b32 %3, %11\n\t"
+      "v_permlane32_swap_b32 %4, %12\n\t"
+      "v_permlane32_swap_b32 %5, %13\n\t"
+      "v_permlane32_swap_b32 %6, %14\n\t"
+      "v_permlane32_swap_b32 %7, %15"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]),
+        "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+  float h[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = a[i] + b[i];
+  // per array: even rows keep the sums of h[i], odd rows those of h[2 + i]
+  float e[4] = {h[0], h[1], h[4], h[5]}, o[4] = {h[2], h[3], h[6], h[7]};
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %4\n\t"
+      "v_permlane16_swap_b32 %1, %5\n\t"
+      "v_permlane16_swap_b32 %2, %6\n\t"
+      "v_permlane16_swap_b32 %3, %7"
+      : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+  rB[0] = row16_allsum(e[0] + o[0]);
+  rB[1] = row16_allsum(e[1] + o[1]);
+  rC[0] = row16_allsum(e[2] + o[2]);
+  rC[1] = row16_allsum(e[3] + o[3]);
+}
+
 // BC = 0: B_t / C_t through scalar loads, generic strides; 1: scalar loads, unit stride, all NS states valid;
 // 2: the chunk's B / C tiles staged in LDS by the whole workgroup (one coalesced load per chunk, broadcast
 // ds_read_b128 per step): no SGPR pressure -- the scalar variants keep 256 B/C values per chunk in flight and spend
@@ -270,8 +310,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       s_p2[w][slot][lane] = p2.x + p2.y;
       s_y[w][slot][lane] = yp.x + yp.y;
       float rB[2], rC[2];
-      wave_reduce_scatter8(dBp, rB);
-      wave_reduce_scatter8(dCp, rC);
+      wave_reduce_scatter8x2(dBp, dCp, rB, rC);
       if (tl <= tlast) {
         // uniform row base + per-lane column: the four lanes with (lane & 15) == 0 write states 2q, 2q + 1
         float *rowB = cB + tl * N, *rowC = cC + tl * N;

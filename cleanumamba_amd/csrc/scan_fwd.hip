@@ -318,6 +318,135 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
   }
 }
 
+// d_state <= 16 (the 442K model, every pruned checkpoint): a wave holds ALL states of its 64 channels, so nothing is
+// shared between waves -- no LDS exchange of partial sums, no workgroup barrier, one wave per workgroup.  The grid
+// then only has batch * dim / 64 waves (half the chip's SIMDs at B = 16, D = 2048), so the kernel is built to run
+// alone on its SIMD: the (t, d) rows of the NEXT block of PB steps are already in flight in registers while the
+// current block is computed (PB * ~260 issue cycles ~ 2 us of cover), and the block's B_t / C_t rows are staged
+// through a wave-private LDS tile (written and read by the same wave: s_waitcnt, no barrier) and fetched back as
+// broadcast ds_read_b128.  Checkpoints are written in the layout of the NW-wave kernels, so the backward is shared.
+template <int NW, typename TIO>
+__global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) {
+  constexpr int PB = 16;                 // steps per block == TB: checkpoints fall on block starts and middles
+  constexpr int NPD = NW * NS;           // padded state count (8 or 16)
+  constexpr int NP2 = NPD / 2;
+  constexpr int BCE = PB * 2 * NPD / 64; // B and C elements per lane and block
+  static_assert(PB == TB, "checkpoint positions assume one block per chunk");
+  __shared__ __attribute__((aligned(16))) float s_bc[2][PB][2 * NPD];
+
+  const int lane = threadIdx.x;
+  const int b = blockIdx.y;
+  const int d = blockIdx.x * 64 + lane;
+  const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
+  const bool dok = d < Dm;
+  const int dc = dok ? d : Dm - 1;
+
+  f2 Ap[NP2], x[NP2];
+#pragma unroll
+  for (int j = 0; j < NPD; ++j) {
+    const int jj = j < N ? j : N - 1;
+    const float a = p.A[(int64_t)dc * N + jj] * kLog2e;
+    Ap[j / 2][j % 2] = j < N ? a : 0.f;
+    x[j / 2][j % 2] = 0.f;
+  }
+  const float Dd = p.D ? p.D[dc] : 0.f;
+  const float bias = p.bias ? p.bias[dc] : 0.f;
+  const TIO *up = static_cast<const TIO *>(p.u) + b * p.s.u_sb + dc * p.s.u_sd;
+  const TIO *dtp = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb + dc * p.s.dt_sd;
+  const bool has_z = p.z != nullptr;
+  const TIO *zp = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb + dc * p.s.z_sd : up;
+  TIO *op = static_cast<TIO *>(p.out) + b * p.s.o_sb + dc * p.s.o_sd;
+  const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
+  const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
+  const int o_sl = (int)p.s.o_sl;
+  const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
+  const int softplus = p.s.delta_softplus;
+  const int nchunks = p.nchunks;
+
+  float ru[PB], rdt[PB], rz[PB], rbc[BCE];
+  auto load_block = [&](int t0) {
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      int t = t0 + k;
+      t = t < L ? t : L - 1;               // clamped address; out-of-range steps are never stored
+      ru[k] = (float)up[t * u_sl];
+      rdt[k] = (float)dtp[t * dt_sl];
+      rz[k] = (float)zp[t * z_sl];
+    }
+#pragma unroll
+    for (int k = 0; k < BCE; ++k) {
+      const int e = lane + 64 * k;         // (step, column) of the [PB][B | C] tile
+      const int tl = e / (2 * NPD), j = e % (2 * NPD);
+      int t = t0 + tl;
+      t = t < L ? t : L - 1;
+      const bool isC = j >= NPD;
+      const int n = isC ? j - NPD : j;
+      const int nc = n < N ? n : N - 1;
+      const float v = isC ? Cb[t * C_sl + nc * C_sn] : Bb[t * B_sl + nc * B_sn];
+      rbc[k] = n < N ? v : 0.f;
+    }
+  };
+  load_block(0);
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int t0 = c * PB;
+    float (*tile)[2 * NPD] = s_bc[c & 1];
+    float cu[PB], cdt[PB], cz[PB];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      cu[k] = ru[k]; cdt[k] = rdt[k]; cz[k] = rz[k];
+    }
+#pragma unroll
+    for (int k = 0; k < BCE; ++k) (&tile[0][0])[lane + 64 * k] = rbc[k];
+    if (c + 1 < nchunks) load_block(t0 + PB);        // the next block's rows travel while this one is computed
+    // (same wave wrote the tile: LDS operations of one wave complete in order, the reads below see the writes)
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      if ((k == 0 || k == SUB) && p.ckpt && dok) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const f2 (&xs)[NS / 2] = *reinterpret_cast<const f2 (*)[NS / 2]>(&x[w * (NS / 2)]);
+          ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, k == 0 ? 0 : 1, NW, w, Dm, d), xs);
+        }
+      }
+      float dtv = cdt[k] + bias;
+      if (softplus) dtv = softplus20(dtv);
+      dtv = (t0 + k < L) ? dtv : 0.f;                // steps past the end leave the state alone (a = 1, b = 0)
+      const float uv = cu[k];
+      const float du = dtv * uv;
+      f2 y = {0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NPD / 4; ++q) {            // four states (two pairs) per 16-byte broadcast read
+        const float4 bq = *reinterpret_cast<const float4 *>(&tile[k][4 * q]);
+        const float4 cq = *reinterpret_cast<const float4 *>(&tile[k][NPD + 4 * q]);
+        const f2 bv[2] = {f2{bq.x, bq.y}, f2{bq.z, bq.w}}, cv[2] = {f2{cq.x, cq.y}, f2{cq.z, cq.w}};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * q + h;
+          const f2 e = dtv * Ap[j];
+          f2 a;
+          a.x = __builtin_amdgcn_exp2f(e.x);
+          a.y = __builtin_amdgcn_exp2f(e.y);
+          x[j] = a * x[j] + du * bv[h];
+          y = cv[h] * x[j] + y;
+        }
+      }
+      float yv = y.x + y.y + Dd * uv;
+      if (has_z) {
+        const float zv = cz[k];
+        yv *= zv * sigmoidf_(zv);
+      }
+      if (dok && t0 + k < L) op[(t0 + k) * o_sl] = (TIO)yv;
+    }
+  }
+  if (p.last_state && dok) {
+    float *ls = p.last_state + ((int64_t)b * Dm + d) * N;
+#pragma unroll
+    for (int j = 0; j < NPD; ++j)
+      if (j < N) ls[j] = x[j / 2][j % 2];
+  }
+}
+
 // selective_state_update: one thread per (stream b, channel d); state row of N floats.
 __global__ void state_update_kernel(int batch, int dim, int N, float *__restrict__ state, const float *__restrict__ x,
                                     const float *__restrict__ dt, const float *__restrict__ A,
@@ -358,9 +487,24 @@ static int scan_fwd_variant() {
   return v;
 }
 
+static int scan_small_variant() {
+  static const int v = [] {
+    const char *e = getenv("CUM_SCAN_SMALL");     // "0": d_state <= 16 also takes the NW-wave kernels (A/B runs)
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return v;
+}
+
 template <int NW, typename TIO>
 static int launch_fwd_io(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
+  if constexpr (NW <= 2) {
+    if (scan_small_variant() == 1) {
+      hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO>), grid, dim3(64), 0, st, p);
+      CUM_CHECK_LAUNCH();
+      return CUM_OK;
+    }
+  }
   if (scan_fwd_variant() == 1) {
     hipLaunchKernelGGL((scan_fwd_lds_kernel<NW, TIO>), grid, block, 0, st, p);
     CUM_CHECK_LAUNCH();

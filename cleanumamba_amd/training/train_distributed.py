@@ -98,9 +98,15 @@ class GradBuckets:
             return
         if not self._armed:
             self._armed = True
+            self._seen = set()
             for b in self.buckets:
                 b[2] = len(b[1])
             Variable._execution_engine.queue_callback(self._finish)
+        # a parameter counts once per backward: autograd runs the post-accumulate hook even for the None gradient a
+        # Function returns after it has written the real one into the flat buffer itself (gradient sink)
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         b = self.buckets[idx]
         b[2] -= 1
         if b[2] == 0:

@@ -447,6 +447,192 @@ __global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) 
   }
 }
 
+// Wave-specialised form of the same small-d_state scan.  With all states of a channel in one wave, the work that
+// depends on (t, d) only -- softplus (exp, log, rcp), the SiLU gate (exp, rcp), delta*u, D*u, the loads and their
+// address arithmetic: ~155 issue cycles per step -- costs MORE than the eight state updates it feeds (~140), and the grid
+// (batch * dim / 64 workgroups) leaves half of the chip's SIMDs idle at B = 16, D = 2048.  So a workgroup is one
+// PRODUCER wave + NW CONSUMER waves (8 states each) on different SIMDs of a CU: the producer prepares block p + 1 --
+// rows already in flight in its registers, softplus / gate / skip term into an LDS slot, B_t / C_t tile staged --
+// while the consumers walk block p's recurrence and write the output themselves.  One workgroup barrier per 16-step
+// block; both roles cost about the same per step, so the step time roughly halves.
+template <int NW, typename TIO>
+__global__ __launch_bounds__((NW + 1) * 64) void scan_fwd_ws_kernel(const ScanParams p) {
+  constexpr int PB = TB;
+  constexpr int NPD = NW * NS;
+  constexpr int BCE = PB * 2 * NPD / 64;
+  __shared__ float s_dt[2][PB][64], s_du[2][PB][64], s_sk[2][PB][64], s_gt[2][PB][64];
+  __shared__ float s_y0[NW == 2 ? 2 : 1][NW == 2 ? PB : 1][64];   // NW == 2: partial sums of consumer 0
+  __shared__ __attribute__((aligned(16))) float s_bc[2][PB][2 * NPD];
+
+  const int lane = threadIdx.x & 63;
+  const int w = uniform(threadIdx.x >> 6);
+  const bool producer = w == NW;
+  const int b = blockIdx.y;
+  const int d = blockIdx.x * 64 + lane;
+  const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
+  const bool dok = d < Dm;
+  const int dc = dok ? d : Dm - 1;       // lanes past the last channel walk a valid one; only their stores are masked
+  const int nchunks = p.nchunks;
+  const bool has_z = p.z != nullptr;
+
+  if (producer) {
+    const float Dd = p.D ? p.D[dc] : 0.f;
+    const float bias = p.bias ? p.bias[dc] : 0.f;
+    // wave-uniform row bases + one per-lane 32-bit offset: loads take the (SGPR base, VGPR offset) form and the per-row
+    // address arithmetic stays on the scalar unit
+    const TIO *ub = static_cast<const TIO *>(p.u) + b * p.s.u_sb;
+    const TIO *db = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb;
+    const TIO *zb = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb : ub;
+    const int u_lo = dc * (int)p.s.u_sd, d_lo = dc * (int)p.s.dt_sd, z_lo = has_z ? dc * (int)p.s.z_sd : u_lo;
+    const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
+    const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
+    const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
+    const int softplus = p.s.delta_softplus;
+    float ru[PB], rdt[PB], rz[PB], rbc[BCE];
+    auto load_block = [&](int t0) {
+      const bool FULL = t0 + PB <= L;      // wave-uniform: the clamps below are scalar selects
+      const TIO *u0 = ub + (int64_t)t0 * u_sl, *d0 = db + (int64_t)t0 * dt_sl, *z0 = zb + (int64_t)t0 * z_sl;
+#pragma unroll
+      for (int k = 0; k < PB; ++k) {
+        const int kk = FULL ? k : ((t0 + k < L) ? k : L - 1 - t0);     // clamped row; masked in prepare()
+        ru[k] = (float)u0[kk * u_sl + u_lo];
+        rdt[k] = (float)d0[kk * dt_sl + d_lo];
+        rz[k] = (float)z0[kk * z_sl + z_lo];
+      }
+#pragma unroll
+      for (int k = 0; k < BCE; ++k) {                  // this lane's elements of the [PB][B | C] tile
+        const int e = lane + 64 * k;
+        const int tl = e / (2 * NPD), j = e % (2 * NPD);
+        int t = t0 + tl;
+        if (!FULL) t = t < L ? t : L - 1;
+        const bool isC = j >= NPD;
+        const int n = isC ? j - NPD : j;
+        const int nc = n < N ? n : N - 1;
+        const float v = isC ? Cb[t * C_sl + nc * C_sn] : Bb[t * B_sl + nc * B_sn];
+        rbc[k] = n < N ? v : 0.f;
+      }
+    };
+    auto prepare = [&](int c) {          // registers hold block c's rows -> LDS slot c & 1
+      const int slot = c & 1, t0 = c * PB;
+      const bool FULL = t0 + PB <= L;
+#pragma unroll
+      for (int k = 0; k < PB; ++k) {
+        float v = rdt[k] + bias;
+        if (softplus) v = softplus20(v);
+        if (!FULL) v = (t0 + k < L) ? v : 0.f;       // steps past the end leave the state alone
+        s_dt[slot][k][lane] = v;
+        s_du[slot][k][lane] = v * ru[k];
+        s_sk[slot][k][lane] = Dd * ru[k];
+        const float zv = rz[k];
+        s_gt[slot][k][lane] = has_z ? zv * sigmoidf_(zv) : 1.f;
+      }
+#pragma unroll
+      for (int k = 0; k < BCE; ++k) (&s_bc[slot][0][0])[lane + 64 * k] = rbc[k];
+    };
+    load_block(0);
+    prepare(0);
+    if (nchunks > 1) load_block(PB);
+    for (int c = 0; c < nchunks; ++c) {
+      __syncthreads();                   // block c is complete in LDS; the consumers are done with slot (c + 1) & 1
+      if (c + 1 < nchunks) {
+        prepare(c + 1);
+        if (c + 2 < nchunks) load_block((c + 2) * PB);
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------- consumers
+  const int n0 = w * NS;
+  const int nvalid = (N - n0) < NS ? (N - n0) : NS;
+  f2 Ap[NS / 2], x[NS / 2];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int jj = j < nvalid ? j : nvalid - 1;
+    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
+    x[j / 2][j % 2] = 0.f;
+  }
+  TIO *ob = static_cast<TIO *>(p.out) + b * p.s.o_sb;
+  const int o_lo = dc * (int)p.s.o_sd;
+  const int o_sl = (int)p.s.o_sl;
+  float yk[PB], skk[PB], gtk[PB];        // NW == 2, last consumer: its partial sums and the epilogue operands of
+                                         // the previous block (the slot they came from is rewritten meanwhile)
+  auto epilogue_prev = [&](int c) {      // NW == 2: outputs of block c (consumer 0's partial sums are in LDS now)
+    TIO *o0 = ob + (int64_t)c * PB * o_sl;
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      const float yv = (yk[k] + s_y0[NW == 2 ? (c & 1) : 0][NW == 2 ? k : 0][lane] + skk[k]) * gtk[k];
+      if (dok && c * PB + k < L) o0[k * o_sl + o_lo] = (TIO)yv;
+    }
+  };
+  auto block = [&](int c) {
+    const int slot = c & 1, t0 = c * PB;
+    const bool FULL = t0 + PB <= L;
+    TIO *o0 = ob + (int64_t)t0 * o_sl;
+    float4 b0 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][n0]), b1 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][n0 + 4]);
+    float4 c0 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][NPD + n0]), c1 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][NPD + n0 + 4]);
+    float dt = s_dt[slot][0][lane], du = s_du[slot][0][lane];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      float4 nb0 = b0, nb1 = b1, nc0 = c0, nc1 = c1;
+      float ndt = 0.f, ndu = 0.f;
+      if (k + 1 < PB) {
+        nb0 = *reinterpret_cast<const float4 *>(&s_bc[slot][k + 1][n0]);
+        nb1 = *reinterpret_cast<const float4 *>(&s_bc[slot][k + 1][n0 + 4]);
+        nc0 = *reinterpret_cast<const float4 *>(&s_bc[slot][k + 1][NPD + n0]);
+        nc1 = *reinterpret_cast<const float4 *>(&s_bc[slot][k + 1][NPD + n0 + 4]);
+        ndt = s_dt[slot][k + 1][lane];
+        ndu = s_du[slot][k + 1][lane];
+      }
+      if ((k == 0 || k == SUB) && p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, k == 0 ? 0 : 1, NW, w, Dm, d), x);
+      const f2 bv[NS / 2] = {f2{b0.x, b0.y}, f2{b0.z, b0.w}, f2{b1.x, b1.y}, f2{b1.z, b1.w}};
+      const f2 cv[NS / 2] = {f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, f2{c1.z, c1.w}};
+      f2 y = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NS / 2; ++j) {
+        const f2 e = dt * Ap[j];
+        f2 a;
+        a.x = __builtin_amdgcn_exp2f(e.x);
+        a.y = __builtin_amdgcn_exp2f(e.y);
+        x[j] = a * x[j] + du * bv[j];
+        y = cv[j] * x[j] + y;
+      }
+      const float ys = y.x + y.y;
+      if constexpr (NW == 1) {
+        const float yv = (ys + s_sk[slot][k][lane]) * s_gt[slot][k][lane];
+        if (dok && (FULL || t0 + k < L)) o0[k * o_sl + o_lo] = (TIO)yv;
+      } else {
+        if (w == 0) {
+          s_y0[NW == 2 ? slot : 0][NW == 2 ? k : 0][lane] = ys;
+        } else {
+          yk[k] = ys;
+          skk[k] = s_sk[slot][k][lane];
+          gtk[k] = s_gt[slot][k][lane];
+        }
+      }
+      b0 = nb0; b1 = nb1; c0 = nc0; c1 = nc1; dt = ndt; du = ndu;
+    }
+  };
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    if constexpr (NW == 2) {
+      if (w == 1 && c > 0) epilogue_prev(c - 1);
+    }
+    block(c);
+  }
+  if constexpr (NW == 2) {
+    __syncthreads();                     // consumer 0's partial sums of the last block
+    if (w == 1) epilogue_prev(nchunks - 1);
+  }
+  if (p.last_state && dok) {
+    float *ls = p.last_state + ((int64_t)b * Dm + d) * N + n0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (j < nvalid) ls[j] = x[j / 2][j % 2];
+  }
+}
+
 // selective_state_update: one thread per (stream b, channel d); state row of N floats.
 __global__ void state_update_kernel(int batch, int dim, int N, float *__restrict__ state, const float *__restrict__ x,
                                     const float *__restrict__ dt, const float *__restrict__ A,
@@ -489,8 +675,8 @@ static int scan_fwd_variant() {
 
 static int scan_small_variant() {
   static const int v = [] {
-    const char *e = getenv("CUM_SCAN_SMALL");     // "0": d_state <= 16 also takes the NW-wave kernels (A/B runs)
-    return (e && e[0] == '0') ? 0 : 1;
+    const char *e = getenv("CUM_SCAN_SMALL");     // d_state <= 16: "0" the NW-wave kernels, "2" the one-wave kernel (A/B)
+    return e ? atoi(e) : 1;
   }();
   return v;
 }
@@ -499,8 +685,22 @@ template <int NW, typename TIO>
 static int launch_fwd_io(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
   if constexpr (NW <= 2) {
-    if (scan_small_variant() == 1) {
+    const int v = scan_small_variant();
+    if (v == 2) {                        // one wave per workgroup, everything in one wave
       hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO>), grid, dim3(64), 0, st, p);
+      CUM_CHECK_LAUNCH();
+      return CUM_OK;
+    }
+    // measured on MI355X (D = 2048, L = 2499, f32 I/O; tools/bench_scan.py): the specialised form wins while the grid
+    // cannot give every SIMD a wave of its own -- up to 1024 workgroups at d_state <= 8, 512 at d_state <= 16
+    static const int64_t ws_max = [] { const char *e = getenv("CUM_SCAN_WS_MAX"); return e ? atoll(e) : (NW == 1 ? 1024LL : 512LL); }();
+    if (v == 1 && (int64_t)grid.x * grid.y > ws_max) {   // enough workgroups to fill the chip with one-wave workgroups
+      hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO>), grid, dim3(64), 0, st, p);
+      CUM_CHECK_LAUNCH();
+      return CUM_OK;
+    }
+    if (v == 1) {                        // few workgroups: producer wave + NW consumer waves each
+      hipLaunchKernelGGL((scan_fwd_ws_kernel<NW, TIO>), grid, dim3((NW + 1) * 64), 0, st, p);
       CUM_CHECK_LAUNCH();
       return CUM_OK;
     }

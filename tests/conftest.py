@@ -41,6 +41,11 @@ def load_ckpt(name):
 def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    # The torch-module conv path (model.use_fused_convs = False, the cached streaming hop) is only an independent
+    # cross-check in these tests.  On some boxes of the pool MIOpen aborts the process inside small ConvTranspose1d
+    # problems (seen three times this round, always in torch/nn/modules/conv.py under conv_transpose1d), which would take
+    # the rest of the suite with it: the cross-check runs on ATen's native GEMM-based convolutions instead.
+    torch.backends.cudnn.enabled = False
     return torch.device("cuda:0")
 
 

@@ -16,11 +16,14 @@ def main():
     dev = torch.device("cuda:0")
     shapes = [(16, 2048, 64, 624, torch.bfloat16), (16, 2048, 16, 2499, torch.float32), (16, 2048, 8, 2499, torch.float32),
               (16, 2048, 8, 2499, torch.bfloat16), (128, 2048, 8, 2499, torch.float32), (128, 2048, 16, 2499, torch.float32),
-              (16, 128, 16, 624, torch.float32), (256, 48, 8, 1875, torch.float32)]
+              (16, 128, 16, 624, torch.float32), (256, 48, 8, 1875, torch.float32),
+              (32, 2048, 8, 2499, torch.float32), (64, 2048, 8, 2499, torch.float32), (32, 2048, 16, 2499, torch.float32),
+              (64, 2048, 16, 2499, torch.float32)]
     if len(sys.argv) > 1:
         shapes = shapes[:int(sys.argv[1])]
     for bsz, dim, N, L, io in shapes:
-        t_i, t_b = bench._scan_case(dev, bsz, dim, N, L, io, True)
+        t_i, t_b = bench._scan_case(dev, bsz, dim, N, L, io, os.environ.get("CUM_BENCH_BWD", "1") != "0")
+        t_b = t_b if t_b is not None else -1.0
         sz = torch.empty((), dtype=io).element_size()
         byt = bsz * L * (sz * 4 * dim + 8 * N)
         print(json.dumps({"shape": [bsz, dim, N, L], "io": str(io), "fwd_ms": round(t_i, 4), "bwd_ms": round(t_b, 4),

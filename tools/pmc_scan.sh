@@ -7,7 +7,7 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_scan_$i -- python3 /tmp/bench_scan.py > $OUT/pmc_scan_$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_scan_$i -- python3 /tmp/bench_scan.py "$@" > $OUT/pmc_scan_$i.log 2>&1
   python3 - /tmp/pmc_scan_$i <<'PY' > $OUT/pmc_scan_$i.txt
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()

@@ -9,9 +9,9 @@ N > 1), clip_grad_norm_(10), fused Adam, LR schedule -- on synthetic 10 s @ 16 k
 (BASELINE configs[2]/[3]), random-init E8 weights.  Rank 0 prints ONE JSON line.
 
 value = global_batch * 160000 * K / (max-over-ranks time of K steps).
-roofline: the kernel with the largest share of the step (rocprofv3 --stats: gemm_tn_kernel<bf16>, the conv-stack
-weight gradients): algorithmic flops 2*M*N*K / mean launch duration measured with HIP events over the 16 encoder
-launch shapes of the step, against the dense bf16 MFMA peak.  `kernels` lists the other heavy kernels the same way
+roofline: the kernel with the largest share of the step (rocprofv3 --stats: gemm_tn_kernel, the conv-stack weight
+gradients), timed live with HIP events over the 16 encoder launch shapes of the step; each shape is priced against the
+roof that binds it, the headline is the MFMA-bound group (enc3-enc7) against the dense 16-bit MFMA peak.  `kernels` lists the other heavy kernels the same way
 (forward GEMMs; selective scan forward / backward with the SURVEY.md 8d byte counts and state updates / s);
 `layers` is the per-layer table of SURVEY.md 8(d) rows a5 / a12: the two forward launches of every encoder / decoder
 layer summed, against the FUSED layer's algorithmic bytes (HBM roof) and flops (MFMA roof); `scan` lists the
@@ -89,13 +89,18 @@ def _name(dt):
 
 
 def tn_roofline(dev, dt=torch.bfloat16):
-    """The kernel with the largest share of the step (rocprofv3: gemm_tn_kernel<bf16>, 34 launches per step):
-    weight gradients dW = dZ^T X of the conv stack.  Timed live with HIP events on the 16 launch shapes the
-    ENCODER contributes to one E8 / B=16 step (conv and 1x1 of each layer; the decoder's 16 launches mirror them
-    with the same M*N*K).  achieved = sum of algorithmic flops (2*M*N*K) / sum of mean
-    launch durations (kernel + its deterministic slab reduce)."""
+    """The kernel with the largest share of the step (rocprofv3: gemm_tn_kernel, 46 launches per step): weight
+    gradients dW = dZ^T X of the conv stack.  Timed live with HIP events on the 16 launch shapes the ENCODER
+    contributes to one E8 / B=16 step (conv and 1x1 of each layer; the decoder's 16 launches mirror them with the
+    same M*N*K).  Every shape is priced against the roof that binds it: algorithmic bytes s*M*(N + ldx) + 4*N*K over
+    8 TB/s vs algorithmic flops 2*M*N*K over the dense 16-bit MFMA peak.  enc0-enc2 are HBM-bound by that test
+    (intensity N*K/(N+ldx) < 312 flop/B), enc3-enc7 MFMA-bound.  The headline `achieved` / `frac` is the MFMA-bound
+    group (10 shapes, 86 % of the kernel's flops): sum of flops / sum of mean launch durations (kernel + its
+    deterministic slab reduce); `hbm_bound_shapes` carries the other group against the HBM roof."""
     from cleanumamba_amd.network import convstack as cs
-    rows, flops_sum, ms_sum = [], 0.0, 0.0
+    sz = torch.empty((), dtype=dt).element_size()
+    rows = []
+    grp = {"mfma": [0.0, 0.0, 0.0], "hbm": [0.0, 0.0, 0.0]}          # flops, bytes, ms
     for i in range(8):
         M, Cin, H = B16 * (ENC_T[i + 1] + 2), _rup(ENC_C[i], 8), ENC_C[i + 1]
         for name, N, K, ldx in ((f"enc{i}.conv.w", H, 4 * Cin, 2 * Cin), (f"enc{i}.1x1.w", 2 * H, H, H)):
@@ -103,19 +108,31 @@ def tn_roofline(dev, dt=torch.bfloat16):
             X = torch.randn(M * ldx // 8 + K // 8 + 64, 8, device=dev).to(dt)
             ms = _time(lambda: cs.wgrad(dz, 0, N, N, X, 0, ldx, K, M))
             fl = 2.0 * M * N * K
-            rows.append({"shape": f"{name} M={M} N={N} K={K}", "launch_ms": round(ms, 4),
-                         "tflops": round(fl / ms / 1e9, 1)})
-            flops_sum += fl
-            ms_sum += ms
+            byt = float(sz * M * (N + ldx) + 4 * N * K)
+            bound = "hbm" if byt / (HBM_PEAK_GBS * 1e9) > fl / (MFMA_PEAK_TFS * 1e12) else "mfma"
+            rows.append({"shape": f"{name} M={M} N={N} K={K}", "launch_ms": round(ms, 4), "bound": bound,
+                         "tflops": round(fl / ms / 1e9, 1), "mfma_frac": round(fl / ms / 1e9 / MFMA_PEAK_TFS, 4),
+                         "GBps": round(byt / ms / 1e6, 1), "hbm_frac": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)})
+            g = grp[bound]
+            g[0] += fl
+            g[1] += byt
+            g[2] += ms
             del dz, X
-    tf = flops_sum / ms_sum / 1e9
-    return {"bound": "mfma", "kernel": f"gemm_tn_kernel<{_name(dt)}> + tn_reduce_kernel, the 16 encoder weight-gradient "
-                                       "launches of one E8 B=16 step",
+    fl, _, ms = grp["mfma"]
+    n_mf = sum(r["bound"] == "mfma" for r in rows)
+    tf = fl / ms / 1e9
+    hb = grp["hbm"]
+    return {"bound": "mfma", "kernel": f"gemm_tn_kernel<{_name(dt)}> + tn_reduce_kernel: the MFMA-bound weight-gradient "
+                                       f"launches of one E8 B=16 step ({n_mf} encoder shapes, enc3-enc7; mirrored by the decoder)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFS, 4),
-            "traffic": TN_TRAFFIC_BYTES, "traffic_source": "constant from profiles/r01_gemm_tn_pmc.md (separate PMC "
-                                                             "passes), not measured in this run",
-            "launch_ms": round(ms_sum / len(rows), 4), "algorithmic_flops": flops_sum / len(rows),
-            "launches": len(rows), "per_shape": rows}
+            "traffic": TN_TRAFFIC_BYTES, "traffic_source": "constant: mean HBM bytes per launch over all 16 shapes from separate "
+                                                             "PMC passes (profiles/r02_gemm_tn_pmc.md: 1.45 x algorithmic), not "
+                                                             "measured in this run",
+            "launch_ms": round(ms / n_mf, 4), "algorithmic_flops": fl / n_mf, "launches": n_mf,
+            "hbm_bound_shapes": {"shapes": len(rows) - n_mf, "achieved_GBps": round(hb[1] / hb[2] / 1e6, 1),
+                                 "hbm_frac": round(hb[1] / hb[2] / 1e6 / HBM_PEAK_GBS, 4)},
+            "all_16_shapes_tflops": round((grp["mfma"][0] + hb[0]) / (grp["mfma"][2] + hb[2]) / 1e9, 1),
+            "per_shape": rows}
 
 
 def _scan_case(dev, bsz, dim, Ns, L, io, backward):

@@ -42,9 +42,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"],
-                    help="autocast dtype of the GEMM/conv stack (reference trains under fp16 autocast); "
-                         "scan / depthwise-conv kernels always compute in f32")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"],
+                    help="autocast dtype: element type of every activation and GEMM operand.  f16 (default) is the "
+                         "reference's own training mode -- torch.autocast('cuda') + GradScaler, configs/config.json:14, "
+                         "src/training/train.py:158-160, 278-280; accumulation, the scan recurrence, parameters and "
+                         "optimizer state are f32 in every mode")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -361,8 +363,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    settle = 0
+    if ac == torch.float16:
+        # Dynamic loss scaling starts at 65536 (GradScaler's default, as in the reference) and backs off while the
+        # first scaled gradients overflow; those optimizer steps are skipped.  Let the scale settle before the W
+        # warm-up steps so that the timed region holds real steps only (untimed, at most 24 extra steps).
+        clean_run, skipped = 0, 0.0
+        while clean_run < 2 and settle < 24:
+            step(clean, noisy)
+            settle += 1
+            now = float(step.optimizer.state_vec[9])
+            clean_run = clean_run + 1 if now == skipped else 0
+            skipped = now
     for _ in range(args.warmup):
         loss, _ = step(clean, noisy)
+    skipped_before = float(step.optimizer.state_vec[9]) if step.flat else 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -376,6 +391,11 @@ def main():
         elapsed = t.item()
     final_loss = float(loss)
     graph_status = step.graph_status
+    optim_info = {"optimizer": "flat clip + Adam (csrc/optim.hip)" if step.flat else "torch.optim.Adam"}
+    if step.flat:
+        sv = step.optimizer.state_vec.cpu()
+        optim_info.update(loss_scale=float(sv[3]) if ac == torch.float16 else None, settle_steps=settle,
+                          skipped_steps_in_timed_region=float(sv[9]) - skipped_before, adam_steps_total=float(sv[5]))
 
     if rank == 0:
         gb = B * world
@@ -388,7 +408,7 @@ def main():
                                       " + grad all-reduce + clip + Adam; 10 s @ 16 kHz clips",
                           "global_batch": gb, "batch_per_gpu": B, "clip_samples": CLIP,
                           "parallelism": f"dp{world}", "weights": "random init (reference init, seed 0)"},
-               "final_loss": round(final_loss, 5), "step_graph": graph_status}
+               "final_loss": round(final_loss, 5), "step_graph": graph_status, "optimizer": optim_info}
         if not args.no_roofline:
             del step, loss
             torch.cuda.empty_cache()

@@ -152,31 +152,33 @@ __device__ __forceinline__ void nt_compute(const uint4 *ldsA, const uint4 *ldsW,
         }
     }
   } else {
-    // f32: lane reads k = 8g .. 8g+7 (two chunks) of its row; MFMA k-slot g at sub-step s is k = 8g + s
-    // for BOTH operands, so the dot product is a permutation of the same 32 products.
-    float wf[4][8], af[4][8];
+    // f32: lane reads k = 8g .. 8g+7 (two 16-byte chunks) of its row; MFMA k-slot g at sub-step s of chunk h is
+    // k = 8g + 4h + s for BOTH operands, so the dot product is a permutation of the same 32 products.  One chunk at
+    // a time: 32 fragment registers beside the 64 accumulators (both chunks at once spilled 6-49 VGPRs at the
+    // 128-register budget of four waves per SIMD).
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int wrow = wn * 64 + i * 16 + r;
-      const int arow = wm * 64 + i * 16 + r;
+    for (int h = 0; h < 2; ++h) {
+      float wf[4][4], af[4][4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int i = 0; i < 4; ++i) {
+        const int wrow = wn * 64 + i * 16 + r;
+        const int arow = wm * 64 + i * 16 + r;
         const int cl = 2 * g + h;
         const uint4 wv = ldsW[wrow * 8 + (cl ^ (wrow & 7))];
         const uint4 av = ldsA[arow * 8 + (cl ^ (arow & 7))];
-        wf[i][4 * h + 0] = __builtin_bit_cast(float, wv.x); wf[i][4 * h + 1] = __builtin_bit_cast(float, wv.y);
-        wf[i][4 * h + 2] = __builtin_bit_cast(float, wv.z); wf[i][4 * h + 3] = __builtin_bit_cast(float, wv.w);
-        af[i][4 * h + 0] = __builtin_bit_cast(float, av.x); af[i][4 * h + 1] = __builtin_bit_cast(float, av.y);
-        af[i][4 * h + 2] = __builtin_bit_cast(float, av.z); af[i][4 * h + 3] = __builtin_bit_cast(float, av.w);
+        wf[i][0] = __builtin_bit_cast(float, wv.x); wf[i][1] = __builtin_bit_cast(float, wv.y);
+        wf[i][2] = __builtin_bit_cast(float, wv.z); wf[i][3] = __builtin_bit_cast(float, wv.w);
+        af[i][0] = __builtin_bit_cast(float, av.x); af[i][1] = __builtin_bit_cast(float, av.y);
+        af[i][2] = __builtin_bit_cast(float, av.z); af[i][3] = __builtin_bit_cast(float, av.w);
       }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][s], af[mi][s], acc[ni][mi], 0, 0, 0);
     }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni][s], af[mi][s], acc[ni][mi], 0, 0, 0);
   }
 }
 
@@ -394,8 +396,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
       }
     }
   };
-  if constexpr (EPI == EPI_GLU_BWD) {
-    // 12 loads per slab: two slabs in flight would spill (128-VGPR budget of 4 waves per SIMD)
+  if constexpr (EPI == EPI_GLU_BWD || sizeof(T) == 4) {
+    // 12 loads per slab (GLU_BWD) or 16-byte f32 operands: two slabs in flight would spill (128-VGPR budget of 4
+    // waves per SIMD; the f32 instantiations spilled 6-49 VGPRs with the pipelined form)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       Slab cur;
@@ -422,7 +425,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
 // The kernel is bound by L2 -> LDS bandwidth (a 128x128x64 tile moves 32 KB per 2.1 MFLOP = 64 flop/B; 256x128:
 // 85 flop/B; 256x256: 128 flop/B), so the largest tile that still fills the chip wins.
 template <typename T, int EPI, int BM, int BN>
-__global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_kernel(const GemmParams p) {
+// 16-bit element types: four waves per SIMD (128 VGPRs).  f32 (the parity path) carries 16-byte operand registers
+// through the epilogues and needs up to ~170: it is allowed down to two waves per SIMD instead of spilling.
+__global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 4, 4))) void gemm_nt_kernel(const GemmParams p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;  // 64 bf16 / 32 f32: LDS rows are 128 B either way
   constexpr int NT = BM * BN / 64;   // threads: one wave per 64x64 sub-tile
@@ -767,7 +772,8 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
     // 256x256 (one workgroup per CU) once it fills the chip and N wastes little of the 256-wide tile; 256-row
     // tiles while they still give every CU >= 2 workgroups per XCD-round; K >= 256 so the saved weight traffic
     // matters (the outer layers are bound by their activation traffic, where the tile shape is irrelevant)
-    if (p.K >= 256 && tiles_256x256 >= 224 && p.N % 256 == 0) tile = 512;
+    // (16-bit only: the f32 instantiation of the 1024-thread tile is capped at 128 VGPRs and spills)
+    if (sizeof(T) == 2 && p.K >= 256 && tiles_256x256 >= 224 && p.N % 256 == 0) tile = 512;
     else if (p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
     else tile = 128;
   }

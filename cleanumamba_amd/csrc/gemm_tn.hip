@@ -60,7 +60,8 @@ struct TnCfg<float> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_tn_kernel(const TnParams p) {
+// (f32, the parity path, needs a few registers more than the 168 of three waves per SIMD: two there instead of spills)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 3, 3))) void gemm_tn_kernel(const TnParams p) {
   constexpr int EPC = TnCfg<T>::EPC, BMK = TnCfg<T>::BMK;
   constexpr int CPR = TN_T / EPC;          // 16-byte chunks per tile row: 16 (bf16) / 32 (f32)
   constexpr int NCH = BMK * CPR / 256;     // chunks per thread per operand: 4

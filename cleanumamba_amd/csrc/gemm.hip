@@ -35,6 +35,7 @@ namespace cum {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 enum { EPI_BIAS = 0, EPI_RELU = 1, EPI_GLU = 2, EPI_MASK = 3, EPI_GLU_BWD = 4 };
 
@@ -529,6 +530,211 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(si
   nt_epilogue<T, EPI>(p, acc, bv, m0, n0, wm, wn, g, r);
 }
 
+// ---------------------------------------------------------------- 256 x 256 tile, 8 waves, DMA in flight across barriers
+// The 16-wave 256x256 kernel above waits `vmcnt(0)` + `__syncthreads()` at the top of every K-step: one LDS-DMA stage in
+// flight, every wave stalled while it lands, 16 waves x 64x64 sub-tiles (0.5 fragment reads per MFMA).  This variant
+// follows the structure cdna_hip_programming.md section 5 measures at 1.3-1.45x such a loop (256^2 tile, 8 waves of
+// 128 x 64, K-step 64, raw s_barrier, counted vmcnt, never 0 in the loop), with its own unit schedule:
+//   * a K-tile is four 16 KB UNITS -- activation rows 0-127 / 128-255 (A0, A1), weight rows 0-127 / 128-255 (W0, W1);
+//     two K-tiles of units = 128 KB, ONE __shared__ array;
+//   * wave (wr, wc) owns rows [128 wr, +128) x channels [64 wc, +64): it reads unit A_wr whole at the start of the
+//     K-tile (16 fragment reads, kept in registers) and W_(wc >> 1) in two halves (phases 1 and 3);
+//   * so K-tile t's A units are free after phase 1 and its W units after phase 3, and the units of K-tile t + 2 are
+//     DMA'd into them one per phase (A0, A1, W0, W1) while K-tile t's 64 MFMAs per wave run: at the top of K-tile t + 1
+//     a counted `s_waitcnt vmcnt(8)` retires K-tile t + 1's units and leaves all eight DMAs of K-tile t + 2 in flight --
+//     every unit has one to two K-tiles (2-4 k cycles) of cover instead of at most one K-step;
+//   * three barriers per K-tile: B1 (K-tile landed, before the first read), B2 (A units read by every wave), B3 (W units
+//     read by every wave).  A DMA'd unit is read only after the wait that retires it AND a barrier; a unit is re-staged
+//     only after a barrier that follows every wave's lgkmcnt(0) on its reads.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt8_kernel(const GemmParams p) {
+  static_assert(sizeof(T) == 2, "16-bit element types only");
+  constexpr int EPC = 8, BK = 64;
+  constexpr int UNIT = 128 * 8;                       // 16-byte chunks of one unit: [128 rows][8 chunks], swizzled
+  __shared__ uint4 lds_all[2 * 4 * UNIT];             // [K-tile parity][A0, A1, W0, W1]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4, r = lane & 15;
+  const int NB = (p.N + 255) / 256;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int m_tile = (local / NB) * 8 + xcd;
+  const int n0 = (local % NB) * 256;
+  const int m0 = m_tile * 256;
+  if (m0 >= p.M) return;
+  if (blockIdx.x == 0) {                              // framing rows of the output buffer (see gemm_nt_kernel)
+    T *o = static_cast<T *>(p.out);
+    T *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD && !(EPI == EPI_RELU && p.mask_bits)) ? static_cast<T *>(p.aux) : nullptr;
+    for (int64_t i = threadIdx.x; i < p.zero_head; i += 512) {
+      o[-1 - i] = Elem<T>::from_f(0.f);
+      if (x) x[-1 - i] = Elem<T>::from_f(0.f);
+    }
+    const int64_t tail0 = (int64_t)p.M * p.ldc, tailx = (int64_t)p.M * p.ldz;
+    for (int64_t i = threadIdx.x; i < p.zero_tail; i += 512) {
+      o[tail0 + i] = Elem<T>::from_f(0.f);
+      if (x) x[tailx + i] = Elem<T>::from_f(0.f);
+    }
+  }
+  const T *A = static_cast<const T *>(p.A);
+  const T *W = static_cast<const T *>(p.W);
+  // per-thread DMA sources: unit u (0 A0, 1 A1, 2 W0, 3 W1), instruction it (0, 1): linear LDS chunk it*512 + tid of the unit
+  const T *src[4][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pos = it * 512 + tid;
+      const int row = pos >> 3, cphys = pos & 7;
+      const int clog = cphys ^ (row & 7);
+      if (u < 2) {
+        int am = m0 + 128 * u + row;
+        am = am < p.M ? am : p.M - 1;
+        src[u][it] = A + (int64_t)am * p.lda + clog * EPC;
+      } else {
+        int wn_ = n0 + 128 * (u - 2) + row;
+        wn_ = wn_ < p.N ? wn_ : p.N - 1;
+        src[u][it] = W + (int64_t)wn_ * p.ldw + clog * EPC;
+      }
+    }
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+#define CUM_STAGE(u, kt, par)                                                                                   \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it)                                                           \
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src[u][it] + (kt) * BK),                                      \
+                                       (lds_ptr)(&lds_all[((par) * 4 + (u)) * UNIT + it * 512 + wave * 64]), 16, 0, 0); \
+  } while (0)
+
+  f32x4 acc[2][4][4];                                 // [m half][ni][mi]: rows 128 wr + 64 h + 16 mi, channels 64 wc + 16 ni
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bv[4][4];
+  nt_load_bias(p, n0, wc, g, bv);
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) CUM_STAGE(u, 0, 0);
+  if (nk > 1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) CUM_STAGE(u, 1, 1);
+  }
+  // Fragment reads are inline asm: hipcc's wait insertion sees every ds_read of an array that LDS-DMAs are in flight
+  // into as a reason for `s_waitcnt vmcnt(0)` (it cannot tell the units apart), which would drain the pipeline twice
+  // per K-tile.  An asm read is not counted by the compiler: each group of reads is followed by one wait statement
+  // that names every destination "+v" (cdna_hip_programming.md 5.7, form ii), so no consumer is scheduled above it.
+  // Addresses: byte offset of (row, 16-byte chunk) inside a unit = row * 128 + ((chunk ^ (row & 7)) << 4); rows 16 apart
+  // share the swizzle term, so one base register per K half (ks) + immediate offsets serves all row tiles.
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)lds_all;
+  unsigned aA[2], aW[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int cl = ks * 4 + g;
+    aA[ks] = lds0 + (unsigned)((wr * UNIT + r * 8 + (cl ^ (r & 7))) * 16);
+    aW[ks] = lds0 + (unsigned)(((2 + (wc >> 1)) * UNIT + ((wc & 1) * 64 + r) * 8 + (cl ^ (r & 7))) * 16);
+  }
+#define CUM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+  for (int kt = 0; kt < nk; ++kt) {
+    const int par = kt & 1;
+    const unsigned pb = (unsigned)par * (4 * UNIT * 16);
+    const unsigned a0 = aA[0] + pb, a1 = aA[1] + pb, w0 = aW[0] + pb, w1 = aW[1] + pb;
+    const bool more = kt + 2 < nk;
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-tile kt landed; K-tile kt + 1 stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");                              // B1
+    // ---- phase 1: W fragments of channels 0-31 and all A fragments of the K-tile, issued in the order the MFMAs
+    //      consume them (LDS returns in order): the first half-quadrant starts after 6 of the 20 reads, the rest land
+    //      under MFMAs
+    u32x4 af[2][8], wf[2][2];        // native vectors: an asm operand of the HIP uint4 struct would go through memory
+    CUM_DSR(wf[0][0], w0, 0);     CUM_DSR(wf[0][1], w0, 2048);
+    CUM_DSR(af[0][0], a0, 0);     CUM_DSR(af[0][1], a0, 2048);  CUM_DSR(af[0][2], a0, 4096);  CUM_DSR(af[0][3], a0, 6144);
+    CUM_DSR(wf[1][0], w1, 0);     CUM_DSR(wf[1][1], w1, 2048);
+    CUM_DSR(af[1][0], a1, 0);     CUM_DSR(af[1][1], a1, 2048);  CUM_DSR(af[1][2], a1, 4096);  CUM_DSR(af[1][3], a1, 6144);
+    CUM_DSR(af[0][4], a0, 8192);  CUM_DSR(af[0][5], a0, 10240); CUM_DSR(af[0][6], a0, 12288); CUM_DSR(af[0][7], a0, 14336);
+    CUM_DSR(af[1][4], a1, 8192);  CUM_DSR(af[1][5], a1, 10240); CUM_DSR(af[1][6], a1, 12288); CUM_DSR(af[1][7], a1, 14336);
+#define CUM_HALFQ(h, nlo, ks)                                                                                  \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                           \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                       \
+        if constexpr (__is_same(T, f16))                                                                       \
+          acc[h][(nlo) + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                     \
+              __builtin_bit_cast(f16x8, wf[ks][ni]), __builtin_bit_cast(f16x8, af[ks][4 * (h) + mi]),          \
+              acc[h][(nlo) + ni][mi], 0, 0, 0);                                                                \
+        else                                                                                                   \
+          acc[h][(nlo) + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                    \
+              __builtin_bit_cast(bf16x8, wf[ks][ni]), __builtin_bit_cast(bf16x8, af[ks][4 * (h) + mi]),        \
+              acc[h][(nlo) + ni][mi], 0, 0, 0);                                                                \
+      }                                                                                                        \
+  } while (0)
+#define CUM_QUAD(h, nlo)         \
+  do {                           \
+    CUM_HALFQ(h, nlo, 0);        \
+    CUM_HALFQ(h, nlo, 1);        \
+  } while (0)
+    asm volatile("s_waitcnt lgkmcnt(14)"
+                 : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]) : : "memory");
+    __builtin_amdgcn_s_setprio(1);
+    CUM_HALFQ(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);     // keep these 8 MFMAs in front of the next wait: they cover the reads it waits for
+    asm volatile("s_waitcnt lgkmcnt(8)"
+                 : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]) : : "memory");
+    CUM_HALFQ(0, 0, 1);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(af[0][4]), "+v"(af[0][5]), "+v"(af[0][6]), "+v"(af[0][7]), "+v"(af[1][4]), "+v"(af[1][5]),
+                   "+v"(af[1][6]), "+v"(af[1][7]) : : "memory");
+    asm volatile("s_barrier" ::: "memory");                              // B2: the A units of this parity are free
+    // Waves w and w + 4 share a SIMD.  Issuing an LDS-DMA costs the issuing wave ~100 cycles apiece; if both partners
+    // issue theirs at the same point of the K-tile the SIMD's matrix pipe idles meanwhile.  So the two halves of the
+    // workgroup take the DMA issue at different points: waves 0-3 stage first and compute after, waves 4-7 compute
+    // first (same barriers, same DMA count between the counted waits).
+    // ---- phase 2
+    const bool early = more && wr == 0, late = more && wr != 0;
+    if (early) {
+      CUM_STAGE(0, kt + 2, par);
+      CUM_STAGE(1, kt + 2, par);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    CUM_QUAD(1, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (late) {
+      CUM_STAGE(0, kt + 2, par);
+      CUM_STAGE(1, kt + 2, par);
+    }
+    // ---- phase 3: W fragments of channels 32-63 (rows + 32 of the unit: + 4096 bytes)
+    CUM_DSR(wf[0][0], w0, 4096);  CUM_DSR(wf[0][1], w0, 6144);  CUM_DSR(wf[1][0], w1, 4096);  CUM_DSR(wf[1][1], w1, 6144);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]) : : "memory");
+    asm volatile("s_barrier" ::: "memory");                              // B3: the W units of this parity are free
+    if (early) {
+      CUM_STAGE(2, kt + 2, par);
+      CUM_STAGE(3, kt + 2, par);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    CUM_QUAD(1, 2);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (late) {
+      CUM_STAGE(2, kt + 2, par);
+      CUM_STAGE(3, kt + 2, par);
+    }
+    // ---- phase 4
+    __builtin_amdgcn_s_setprio(1);
+    CUM_QUAD(0, 2);
+    __builtin_amdgcn_s_setprio(0);
+  }
+#undef CUM_HALFQ
+#undef CUM_DSR
+#undef CUM_QUAD
+#undef CUM_STAGE
+  nt_epilogue<T, EPI>(p, acc[0], bv, m0, n0, 2 * wr, wc, g, r);
+  nt_epilogue<T, EPI>(p, acc[1], bv, m0, n0, 2 * wr + 1, wc, g, r);
+}
+
 // ---------------------------------------------------------------- small-M variant (streaming hops)
 // Launches with only a few dozen 128x128 tiles (M = streams x a handful of rows) leave most of the chip idle while
 // every workgroup walks the whole K axis at one exposed DMA latency per step.  Here a workgroup owns a 64x64 tile and
@@ -734,6 +940,31 @@ __global__ void colsum_stage2(const float *__restrict__ part, int nparts, int n,
   out[c] = s;
 }
 
+template <typename T>
+static int launch_gemm_nt8(const GemmParams &p, int epi, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    const int NB = (p.N + 255) / 256, MB = (p.M + 255) / 256;
+    dim3 grid(8 * NB * ((MB + 7) / 8)), block(512);
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm_nt8_kernel<T, EPI_BIAS>), grid, block, 0, st, p); break;
+      case EPI_RELU: hipLaunchKernelGGL((gemm_nt8_kernel<T, EPI_RELU>), grid, block, 0, st, p); break;
+      case EPI_MASK: hipLaunchKernelGGL((gemm_nt8_kernel<T, EPI_MASK>), grid, block, 0, st, p); break;
+      case EPI_GLU_BWD: hipLaunchKernelGGL((gemm_nt8_kernel<T, EPI_GLU_BWD>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm_nt8_kernel<T, EPI_GLU>), grid, block, 0, st, p); break;
+    }
+    CUM_CHECK_LAUNCH();
+  }
+  return CUM_OK;
+}
+
+static int nt8_enabled() {
+  static const int v = [] {
+    const char *e = getenv("CUM_NT8");     // "0": the 16-wave 256x256 kernel (A/B runs)
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return v;
+}
+
 template <typename T, int BM, int BN>
 static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   const int NB = (p.N + BN - 1) / BN, MB = (p.M + BM - 1) / BM;
@@ -777,6 +1008,7 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
     else if (p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
     else tile = 128;
   }
+  if (tile == 512 && sizeof(T) == 2 && nt8_enabled()) return launch_gemm_nt8<T>(p, epi, st);
   if (tile == 512) return launch_gemm_tile<T, 256, 256>(p, epi, st);
   if (tile == 256) return launch_gemm_tile<T, 256, 128>(p, epi, st);
   return launch_gemm_tile<T, 128, 128>(p, epi, st);

@@ -199,3 +199,22 @@ def test_gemm_backward_epilogues_against_torch(cuda, M, N, K, dtype, tol):
     cs.gemm(A, 0, K, W, None, dz2, 0, 2 * N, M, 1 << 30, 1 << 30, hip.EPI_GLU_BWD, N, res=ext, r_off=0, ldr=N, aux=bg, x_off=0, ldz=N,
             aux2=y, y_off=0, ldy=N, gate_only=True)
     assert rel_l2(dz2.float(), want2.view(M, 2 * N)) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-6), (torch.float16, 2e-6)])   # f32 accumulation of exact products
+@pytest.mark.parametrize("M,N,K,ldx", [(300, 64, 64, 64), (999, 256, 512, 256), (70001, 512, 256, 256), (20003, 768, 1024, 512),
+                                        (4100, 256, 256, 256)])
+def test_weight_gradient_gemm_against_torch(cuda, M, N, K, ldx, dtype, tol):
+    """cum_gemm_tn through the C ABI: dW = dZ^T X with overlapping X rows (ldx < K: the k=4/s=2 window) and the fused
+    bias gradient, ragged M.  The first shape runs the 128x128 kernel, the others (16-bit types, N and K multiples of
+    256) the 256x256 one; inputs are already rounded, so only the f32 summation order differs from the f64 reference."""
+    from cleanumamba_amd.network import convstack as cs
+    g = torch.Generator().manual_seed(M + N + K)
+    dz = torch.randn(M, N, generator=g).to(cuda).to(dtype)
+    xflat = torch.randn(M * ldx + K, generator=g).to(cuda).to(dtype)
+    dw, db = cs.wgrad(dz, 0, N, N, xflat, 0, ldx, K, M)
+    X = torch.as_strided(xflat.cpu().double(), (M, K), (ldx, 1))
+    want_w, want_b = dz.cpu().double().t() @ X, dz.cpu().double().sum(0)
+    assert dw.shape == (N, K) and db.shape == (N,)
+    assert record(f"wgrad[{M}x{N}x{K}-{dtype}].dW", rel_l2(dw, want_w)) < tol
+    assert record(f"wgrad[{M}x{N}x{K}-{dtype}].db", rel_l2(db, want_b)) < tol

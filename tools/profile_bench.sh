@@ -26,6 +26,15 @@ if len(idx) >= 12:
     import collections
     hist = collections.Counter(min(int(g[0] // 2) * 2, 40) for g in gaps)
     print("gap histogram (us bucket: count):", sorted(hist.items()))
+    import re
+    per = collections.defaultdict(lambda: [0, 0.0])
+    for s, e, k in seg:
+        k = re.sub(r"^void ", "", k)
+        k = re.sub(r"\(.*$", "", k)[:90]
+        per[k][0] += 1; per[k][1] += (e - s) / 1e6
+    print("per step, by kernel (ms, launches):")
+    for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:45]:
+        print("  %7.3f  %5.1f  %s" % (t / 10, n / 10, k))
 PY
 # (2) the default run, csv stats for profiles/
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/full -o bench -- python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/full.err

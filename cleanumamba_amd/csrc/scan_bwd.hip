@@ -95,6 +95,58 @@ __device__ __forceinline__ void wave_reduce_scatter8x2(const f2 (&b2)[NP2], cons
   rC[1] = row16_allsum(e[3] + o[3]);
 }
 
+// Same exchanges, but the last four values are reduce-SCATTERED over the 16 lanes of a row instead of summed four times:
+// DPP adds whose bank mask writes only the quads that keep the value (row_mirror: lanes 0-7 keep the dB pair, 8-15 the
+// dC pair; row_half_mirror: even quads keep the first of the pair), then two quad steps -- 8 DPP adds instead of 16 and
+// no result copies.  On return lane l of row q holds, in every lane of its quad, the total of
+//   dB[2q] (l & 15 in 0-3), dB[2q + 1] (4-7), dC[2q] (8-11), dC[2q + 1] (12-15).
+__device__ __forceinline__ float wave_reduce_scatter8x2q(const f2 (&b2)[NP2], const f2 (&c2)[NP2]) {
+  float a[8] = {b2[0].x, b2[0].y, b2[1].x, b2[1].y, c2[0].x, c2[0].y, c2[1].x, c2[1].y};
+  float b[8] = {b2[2].x, b2[2].y, b2[3].x, b2[3].y, c2[2].x, c2[2].y, c2[3].x, c2[3].y};
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %8\n\t"
+      "v_permlane32_swap_b32 %1, %9\n\t"
+      "v_permlane32_swap_b32 %2, %10\n\t"
+      "v_permlane32_swap_b32 %3, %11\n\t"
+      "v_permlane32_swap_b32 %4, %12\n\t"
+      "v_permlane32_swap_b32 %5, %13\n\t"
+      "v_permlane32_swap_b32 %6, %14\n\t"
+      "v_permlane32_swap_b32 %7, %15"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]),
+        "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+  float h[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = a[i] + b[i];
+  float e[4] = {h[0], h[1], h[4], h[5]}, o[4] = {h[2], h[3], h[6], h[7]};
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %4\n\t"
+      "v_permlane16_swap_b32 %1, %5\n\t"
+      "v_permlane16_swap_b32 %2, %6\n\t"
+      "v_permlane16_swap_b32 %3, %7"
+      : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+  const float q0 = e[0] + o[0], q1 = e[1] + o[1], q2 = e[2] + o[2], q3 = e[3] + o[3];
+  float ra, rb, sv;
+  // (s_nop 1: two wait states between a VALU write of a register and a DPP read of it)
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %1, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(ra), "=&v"(rb), "=&v"(sv)
+      : "v"(q0), "v"(q1), "v"(q2), "v"(q3));
+  return sv;
+}
+
 // BC = 0: B_t / C_t through scalar loads, generic strides; 1: scalar loads, unit stride, all NS states valid;
 // 2: the chunk's B / C tiles staged in LDS by the whole workgroup (one coalesced load per chunk, broadcast
 // ds_read_b128 per step): no SGPR pressure -- the scalar variants keep 256 B/C values per chunk in flight and spend
@@ -162,9 +214,10 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
   const int softplus = p.s.delta_softplus;
 
-  // dB / dC slab stores: lanes 0, 16, 32, 48 own states 2q, 2q + 1 of the wave's slice (q = lane >> 4)
-  const unsigned qoff = 2u * (lane >> 4);
-  const bool st0 = (lane & 15) == 0 && (int)qoff < nvalid, st1 = (lane & 15) == 0 && (int)qoff + 1 < nvalid;
+  // dB / dC slab stores: the first lane of every quad owns one total (wave_reduce_scatter8x2q): quads 0 / 1 of row q the
+  // dB sums of states 2q / 2q + 1 of the wave's slice, quads 2 / 3 the dC sums
+  const unsigned qoff = 2u * (lane >> 4) + ((lane >> 2) & 1);
+  const bool st_on = (lane & 3) == 0 && (int)qoff < nvalid;
 
   float accD = 0.f, accBias = 0.f;
 
@@ -200,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * TB;
     const int tlast = L - 1 - t0;  // last valid local step of this chunk (>= 0)
-    float *cB = wsB + (int64_t)t0 * N, *cC = wsC + (int64_t)t0 * N;
+    float *cBC = ((lane & 8) ? wsC : wsB) + (int64_t)t0 * N;
     // state entering the chunk: needed by both halves, requested now so that its latency hides behind phase A
     f2 x0[NP2], x8[NP2];   // x8: state entering the second half (local step 8), read only if the chunk reaches it
     ckpt_load(p.ckpt_in, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, dc), x0);
@@ -241,6 +294,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     if (c > 0) load_rows(c - 1);
     __syncthreads();
 
+    f2 xs[SUB][NP2];   // states before each step of the half being processed
     // Operands of one time step: B_t / C_t slices (SGPRs via s_load) and the per-(t, d) values from LDS.  They are
     // fetched one step ahead of their use so that neither the scalar-load nor the LDS latency is exposed.
     struct StepOps {
@@ -295,41 +349,23 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
 #pragma unroll
       for (int j = 0; j < NP2; ++j) {
         const f2 a = slot < NA ? o.a[j] : exp2_2(dt * Ap[j]);
-        const f2 xt = a * xp[j] + du * o.bv[j];
+        // the state after this step is the saved state before the next one (recomputed only for the half's last step)
+        const f2 xt = slot + 1 < SUB ? xs[slot + 1][j] : a * xp[j] + du * o.bv[j];
         const f2 dx = o.cv[j] * dy + dxc[j];
         yp = o.cv[j] * xt + yp;
         dCp[j] = dy * xt;
         dBp[j] = dx * du;
-        const f2 gg = dx * xp[j] * a;
+        dxc[j] = a * dx;
+        const f2 gg = dxc[j] * xp[j];
         dAacc[j] = gg * dt + dAacc[j];
         p1 = gg * Ap[j] + p1;
         p2 = dx * o.bv[j] + p2;
-        dxc[j] = a * dx;
       }
       s_p1[w][slot][lane] = p1.x + p1.y;
       s_p2[w][slot][lane] = p2.x + p2.y;
       s_y[w][slot][lane] = yp.x + yp.y;
-      float rB[2], rC[2];
-      wave_reduce_scatter8x2(dBp, dCp, rB, rC);
-      if (tl <= tlast) {
-        // uniform row base + per-lane column: the four lanes with (lane & 15) == 0 write states 2q, 2q + 1
-        float *rowB = cB + tl * N, *rowC = cC + tl * N;
-        if constexpr (FULL) {
-          if (st0) {
-            *reinterpret_cast<f2 *>(rowB + qoff) = f2{rB[0], rB[1]};
-            *reinterpret_cast<f2 *>(rowC + qoff) = f2{rC[0], rC[1]};
-          }
-        } else {
-          if (st0) {
-            rowB[qoff] = rB[0];
-            rowC[qoff] = rC[0];
-          }
-          if (st1) {
-            rowB[qoff + 1] = rB[1];
-            rowC[qoff + 1] = rC[1];
-          }
-        }
-      }
+      const float tot = wave_reduce_scatter8x2q(dBp, dCp);
+      if (tl <= tlast && st_on) cBC[tl * N + qoff] = tot;   // per-lane slab (dB or dC) + uniform row + per-lane column
       __builtin_amdgcn_sched_barrier(0);
     };
     // phase C for one half: combine the per-wave partial sums, write du / ddelta / dz
@@ -364,7 +400,6 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       }
     };
 
-    f2 xs[SUB][NP2];
     StepOps cur, nxt;
     // ---- second half (local steps 8..15), only if the chunk reaches it
     if (tlast >= SUB) {

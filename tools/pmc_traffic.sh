@@ -2,7 +2,7 @@
 # HBM traffic of the GEMM kernels (GPU box): two SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters with
 # --kernel-trace only) over tools/bench_gemm.py [tn].  Summaries -> gpurun_out/pmc_traffic_<mode>.txt
 #   bash tools/pmc_traffic.sh nt      forward conv / 1x1+GLU launches of the E8 encoder (gemm_nt_kernel)
-#   bash tools/pmc_traffic.sh tn      the 16 weight-gradient shapes (gemm_tn_kernel + tn_reduce_kernel)
+#   bash tools/pmc_traffic.sh tn      the 16 weight-gradient shapes (gemm_tn8_kernel / gemm_tn_kernel + tn_reduce_kernel)
 MODE=${1:-nt}
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out
@@ -37,11 +37,11 @@ for i in range(8):
     else:
         shapes.append((f"enc{i}.conv+relu", 2 * M * (2 * Cin + H) + 2 * H * 4 * Cin, 2.0 * M * H * 4 * Cin))
         shapes.append((f"enc{i}.1x1+glu", 2 * M * (H + H) + 2 * 2 * H * H, 2.0 * M * 2 * H * H))
-main = "gemm_tn_kernel" if mode == "tn" else "gemm_nt"
+main = ("gemm_tn_kernel", "gemm_tn8_kernel") if mode == "tn" else ("gemm_nt",)
 def per_shape(c):
     out, cur, cnt = [], 0.0, 0
     for _, k, v in seq[c]:
-        if main in k:
+        if any(m in k for m in main):
             if cnt == 12:
                 out.append(cur / 12); cur, cnt = 0.0, 0
             cnt += 1

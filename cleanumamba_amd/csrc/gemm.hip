@@ -236,9 +236,11 @@ struct Raw4<f16> {
 // stores).  The
 // straightforward form -- load, wait, compute, store per 16x16 tile inside per-lane `continue`s -- serialised 16
 // (MASK) to 48 (GLU_BWD) memory round trips per tile.
-template <typename T, int EPI>
-__device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&acc)[4][4], const float (&bv)[4][4],
-                                            int m0, int n0, int wm, int wn, int g, int r) {
+// NH: 64-row halves of the wave's sub-tile (1, or 2 for gemm_nt8_kernel's 128 x 64); PIPE: slabs whose loads are
+// issued ahead of the slab being finished (-1: the default of the 128-VGPR kernels, see the end of the function).
+template <typename T, int EPI, int NH = 1, int PIPE = -1>
+__device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (*accp)[4][4], const float (&bv)[4][4],
+                                            int m0, int n0, int wm0, int wn, int g, int r) {
   // lane holds D[n = nb + 4g + j][m = mb + r], j = 0..3 -> 4 consecutive channels of row m.
   // No two of these buffers overlap.
   T *__restrict__ out = static_cast<T *>(p.out);
@@ -252,14 +254,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
     Raw4<T> r[NL], a[EPI == EPI_GLU_BWD ? 4 : 1], b[EPI == EPI_GLU_BWD ? 4 : 1];
     unsigned char mw[4];       // MASK with mask_bits: this lane's sign nibbles of the slab's four tiles
   };
-  auto row_of = [&](int mi, bool &live) {
-    const int m_raw = m0 + wm * 64 + mi * 16 + r;
+  // slab sl = 16 rows: half sl / 4 (64 rows each), 16-row tile sl % 4
+  auto row_of = [&](int sl, bool &live) {
+    const int m_raw = m0 + wm0 * 64 + sl * 16 + r;
     live = m_raw < p.M;
     return (int64_t)(live ? m_raw : p.M - 1);          // clamped row for the loads
   };
-  auto issue = [&](int mi, Slab &s) {
+  auto issue = [&](int sl, Slab &s) {
     bool live;
-    const int64_t m = row_of(mi, live);
+    const int64_t m = row_of(sl, live);
     if constexpr (EPI == EPI_GLU) {
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
@@ -294,9 +297,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
       }
     }
   };
-  auto finish = [&](int mi, const Slab &s) {
+  auto finish = [&](int sl, const Slab &s) {
+    const f32x4 (&acc)[4][4] = accp[sl / 4];
+    const int mi = sl % 4;
     bool live;
-    const int64_t m = row_of(mi, live);
+    const int64_t m = row_of(sl, live);
     const bool real = live && (m % p.pitch) < p.valid;
     if constexpr (EPI == EPI_GLU) {
 #pragma unroll
@@ -397,24 +402,17 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (&a
       }
     }
   };
-  if constexpr (EPI == EPI_GLU_BWD || sizeof(T) == 4) {
-    // 12 loads per slab (GLU_BWD) or 16-byte f32 operands: two slabs in flight would spill (128-VGPR budget of 4
-    // waves per SIMD; the f32 instantiations spilled 6-49 VGPRs with the pipelined form)
+  constexpr int NSL = 4 * NH;
+  // default depth: 12 loads per slab (GLU_BWD) or 16-byte f32 operands: two slabs in flight would spill at the 128-VGPR
+  // budget of 4 waves per SIMD (the f32 instantiations spilled 6-49 VGPRs with the pipelined form); else one ahead
+  constexpr int AHEAD = PIPE >= 0 ? PIPE : ((EPI == EPI_GLU_BWD || sizeof(T) == 4) ? 0 : 1);
+  Slab ring[AHEAD + 1];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      Slab cur;
-      issue(mi, cur);
-      finish(mi, cur);
-    }
-  } else {
-    Slab cur, nxt;
-    issue(0, cur);
+  for (int sl = 0; sl < AHEAD && sl < NSL; ++sl) issue(sl, ring[sl]);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      if (mi + 1 < 4) issue(mi + 1, nxt);
-      finish(mi, cur);
-      cur = nxt;
-    }
+  for (int sl = 0; sl < NSL; ++sl) {
+    if (sl + AHEAD < NSL) issue(sl + AHEAD, ring[(sl + AHEAD) % (AHEAD + 1)]);
+    finish(sl, ring[sl % (AHEAD + 1)]);
   }
 }
 
@@ -527,7 +525,7 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(si
   }
 #undef CUM_GLDS
 
-  nt_epilogue<T, EPI>(p, acc, bv, m0, n0, wm, wn, g, r);
+  nt_epilogue<T, EPI>(p, &acc, bv, m0, n0, wm, wn, g, r);
 }
 
 // ---------------------------------------------------------------- 256 x 256 tile, 8 waves, DMA in flight across barriers
@@ -731,8 +729,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GemmParams p) {
 #undef CUM_DSR
 #undef CUM_QUAD
 #undef CUM_STAGE
-  nt_epilogue<T, EPI>(p, acc[0], bv, m0, n0, 2 * wr, wc, g, r);
-  nt_epilogue<T, EPI>(p, acc[1], bv, m0, n0, 2 * wr + 1, wc, g, r);
+  // (the fragment registers are dead here, so deeper load pipelining fits -- PIPE = 0 / 1 / 2 / 3 measured the same to
+  // +-1 % over all 44 launches of a step: the epilogue is not bound by loads in flight)
+  nt_epilogue<T, EPI, 2>(p, acc, bv, m0, n0, 2 * wr, wc, g, r);
 }
 
 // ---------------------------------------------------------------- small-M variant (streaming hops)
@@ -823,7 +822,7 @@ __global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(const GemmParams p)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] += src[(i * 4 + j) * 64 + lane];
   }
-  nt_epilogue<T, EPI>(p, acc, bv, m0, n0, 0, 0, g, r);
+  nt_epilogue<T, EPI>(p, &acc, bv, m0, n0, 0, 0, g, r);
 }
 
 template <typename T>

@@ -73,6 +73,9 @@ class GradBuckets:
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
         self.flat.on_write = self._written
+        # producers that can hand over part of their gradients before they are done with all of them do so when there is
+        # an exchange to overlap with (network/convstack.py EncoderStack.backward)
+        self.flat.early_announce = self.world > 1
 
     def _written(self, params):
         """Gradients a kernel wrote straight into the flat buffer (FlatParams.wrote): same bookkeeping as the hook."""

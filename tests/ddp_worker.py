@@ -66,7 +66,13 @@ def main():
         clean, noisy = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     # first backward by hand (so the gradients can be dumped before the optimizer runs) ...
     step.zero_grad()
+    announced = []                                   # sizes of the gradient groups the kernels hand to the exchange
+    if world > 1:
+        flat, inner = net.grad_buckets.flat, net.grad_buckets.flat.on_write
+        flat.on_write = lambda ps: (announced.append(len(ps)), inner(ps))[1]
     loss0 = step.micro_step(clean, noisy)
+    if world > 1:
+        flat.on_write = inner
     scale = float(step.optimizer.loss_scale) if ac == torch.float16 else 1.0
     grads = {k: (p.grad.detach().float() / scale).cpu() for k, p in net.named_parameters()}
     step.optimizer_step()
@@ -79,7 +85,8 @@ def main():
     torch.cuda.synchronize()
     params = {k: p.detach().float().cpu() for k, p in net.named_parameters()}
     torch.save({"grads": grads, "params": params, "losses": losses,
-                "skipped": float(step.optimizer.state_vec[9])}, os.path.join(out, f"rank{rank}_of{world}.pt"))
+                "skipped": float(step.optimizer.state_vec[9]), "announced": announced},
+               os.path.join(out, f"rank{rank}_of{world}.pt"))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

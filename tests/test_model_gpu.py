@@ -344,3 +344,27 @@ def test_stream_after_flush_starts_a_fresh_running_std(cuda):
     assert a.shape == (1, 7000)
     assert rel_l2(a, b) < 1e-6
     assert used.frames > fresh.frames                          # time_per_frame keeps counting across clips
+
+
+def test_c5_scale_batched_streaming_equals_forward(cuda):
+    """BASELINE config 5 at scale: 256 concurrent streams of the pruned-E8 492K checkpoint, 2 s of audio each, fed in
+    ragged chunks (the captured-hop path runs hundreds of hops) and flushed: every stream equals the parallel forward on
+    its whole signal (normalisation off: forward normalises by the whole-signal std, the stream by a running one)."""
+    net = _net("pruned500k", cuda, pruned=True)
+    net.normalize_input = False
+    S, L = 256, 32000
+    x = (0.1 * torch.randn(S, L, generator=torch.Generator().manual_seed(77))).to(cuda)
+    with torch.no_grad():
+        outs, i = [], 0
+        for n in (1000, 257, 4096, 766, 12001, 3333, 10547):        # sums to L
+            outs.append(net.feed_batch(x[:, i:i + n]))
+            i += n
+        assert i == L
+        outs.append(net.flush_batch())
+        seq = torch.cat(outs, 1)
+        par = net(x.unsqueeze(1))[:, 0, :L]
+    assert seq.shape == (S, L)
+    err = record("c5_256_streams_vs_forward", rel_l2(seq, par))
+    assert err < 1e-4
+    worst = max(rel_l2(seq[s:s + 1], par[s:s + 1]) for s in range(0, S, 17))
+    assert worst < 1e-4

@@ -58,6 +58,7 @@ struct GemmParams {
   int pitch, valid;        // row m is real iff (m % pitch) < valid; other rows are stored as zeros
   int n_store;             // number of output columns to store (<= N, or N/2 for GLU); multiple of 4
   int64_t zero_head, zero_tail;
+  int rows_epilogue;       // gemm_nt8_kernel: GLU_BWD epilogue through LDS (CUM_NT8_ROWS=0 turns it off for A/B runs)
 };
 
 template <typename T>
@@ -528,6 +529,92 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(si
   nt_epilogue<T, EPI>(p, &acc, bv, m0, n0, wm, wn, g, r);
 }
 
+// GLU-backward epilogue of gemm_nt8_kernel through LDS (gate-only form, full-width tiles, 16-byte aligned rows).
+//
+// In the MFMA result layout a lane touches 8 bytes of 16 different rows per instruction: 16 rows x 32 bytes.  One CU
+// sustains that pattern at 44 us per 256 x 256 tile of this epilogue however idle the rest of the chip is, against 19 us
+// for the same bytes moved 16 bytes per lane along the rows (tools/epi_pattern_probe.hip; in-kernel time stamps put the
+// epilogue at 44 us per tile beside a 55 us K loop).  After the K loop the 128 KB of LDS are free, so every wave
+// transposes its own 128 x 64 sub-tile through a private 11 KB region, one 16-row slab at a time: the three operand
+// slabs arrive with 16-byte row-contiguous loads (8 rows x 128 B per instruction, issued one slab ahead), are re-read in
+// the MFMA layout (row stride 144 B: conflict-free 8-byte reads), and dZ leaves through a row-major staging slab (stride
+// 272 B) as 4 rows x 256 B per store instruction.  Wave-private LDS traffic needs no barrier: the LDS executes a wave's
+// instructions in order.
+__device__ __forceinline__ bool nt8_rows_epilogue_on(const GemmParams &p) { return p.rows_epilogue != 0; }
+
+template <typename T>
+__device__ __forceinline__ void nt8_epilogue_glu_bwd_rows(const GemmParams &p, const f32x4 (*accp)[4][4], int m0, int n0,
+                                                         int wr, int wc, int lane, unsigned char *lw) {
+  constexpr int IS = 144, OS = 272;
+  const T *__restrict__ gb = static_cast<const T *>(p.aux);
+  // without a residual the gate is read in its place (valid memory) and weighted by zero: no branch around the loads
+  const T *__restrict__ res = p.res ? static_cast<const T *>(p.res) : gb;
+  const int64_t ldr = p.res ? p.ldr : p.ldz;
+  const float ew = p.res ? 1.f : 0.f;
+  const T *__restrict__ yy = static_cast<const T *>(p.aux2);
+  T *__restrict__ out = static_cast<T *>(p.out);
+  const int g = lane >> 4, r = lane & 15;
+  const int nw0 = n0 + 64 * wc, mw0 = m0 + 128 * wr;
+  unsigned char *const le = lw, *const lb = lw + 16 * IS, *const ly = lw + 32 * IS, *const lo = lw + 48 * IS;
+  const int lrow = lane >> 3, lch = lane & 7;      // loads: 8 rows x 8 chunks of 16 bytes
+  const int srow = lane >> 4, sch = lane & 15;     // stores: 4 rows x 16 chunks
+  struct In {
+    u32x4 e[2], b[2], y[2];
+  };
+  auto issue = [&](int sl, In &v) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int m_raw = mw0 + 16 * sl + 8 * k + lrow;
+      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;           // clamped row, never stored
+      v.e[k] = *reinterpret_cast<const u32x4 *>(res + m * ldr + nw0 + 8 * lch);
+      v.b[k] = *reinterpret_cast<const u32x4 *>(gb + m * p.ldz + nw0 + 8 * lch);
+      v.y[k] = *reinterpret_cast<const u32x4 *>(yy + m * p.ldy + nw0 + 8 * lch);
+    }
+  };
+  In ring[2];
+  issue(0, ring[0]);
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) {
+    if (sl + 1 < 8) issue(sl + 1, ring[(sl + 1) & 1]);
+    const In &cur = ring[sl & 1];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int off = (8 * k + lrow) * IS + 16 * lch;
+      *reinterpret_cast<u32x4 *>(le + off) = cur.e[k];
+      *reinterpret_cast<u32x4 *>(lb + off) = cur.b[k];
+      *reinterpret_cast<u32x4 *>(ly + off) = cur.y[k];
+    }
+    const f32x4 (&acc)[4][4] = accp[sl / 4];
+    const int mi = sl % 4;
+    const int m_raw = mw0 + 16 * sl + r;
+    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int io = r * IS + 32 * ni + 8 * g;
+      float e[4], b[4], a[4], da[4], db[4];
+      load4<T>(reinterpret_cast<const T *>(le + io), e);
+      load4<T>(reinterpret_cast<const T *>(lb + io), b);
+      load4<T>(reinterpret_cast<const T *>(ly + io), a);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sg = sigmoidf_(b[j]);
+        const float dj = real ? fmaf(ew, e[j], acc[ni][mi][j]) : 0.f;
+        da[j] = dj * sg;
+        db[j] = dj * a[j] * (1.f - sg);
+      }
+      store4<T>(reinterpret_cast<T *>(lo + r * OS + 64 * ni + 8 * g), da);
+      store4<T>(reinterpret_cast<T *>(lo + r * OS + 64 * ni + 8 * g + 32), db);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = 4 * k + srow;
+      const int ms = mw0 + 16 * sl + row;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(lo + row * OS + 16 * sch);
+      if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + 2 * nw0 + 8 * sch) = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- 256 x 256 tile, 8 waves, DMA in flight across barriers
 // The 16-wave 256x256 kernel above waits `vmcnt(0)` + `__syncthreads()` at the top of every K-step: one LDS-DMA stage in
 // flight, every wave stalled while it lands, 16 waves x 64x64 sub-tiles (0.5 fragment reads per MFMA).  This variant
@@ -729,8 +816,18 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GemmParams p) {
 #undef CUM_DSR
 #undef CUM_QUAD
 #undef CUM_STAGE
+  if constexpr (EPI == EPI_GLU_BWD) {
+    const bool rows16 = (((p.res ? p.ldr : 0) | p.ldz | p.ldy | p.ldc) & 7) == 0 &&
+                        ((((uintptr_t)p.res) | ((uintptr_t)p.aux) | ((uintptr_t)p.aux2) | ((uintptr_t)p.out)) & 15) == 0;
+    if (p.gate_only && rows16 && n0 + 256 <= p.n_store && nt8_rows_epilogue_on(p)) {
+      asm volatile("s_barrier" ::: "memory");        // every wave is done reading the K loop's LDS units
+      nt8_epilogue_glu_bwd_rows<T>(p, acc, m0, n0, wr, wc, lane,
+                                   reinterpret_cast<unsigned char *>(lds_all) + wave * (48 * 144 + 16 * 272));
+      return;
+    }
+  }
   // (the fragment registers are dead here, so deeper load pipelining fits -- PIPE = 0 / 1 / 2 / 3 measured the same to
-  // +-1 % over all 44 launches of a step: the epilogue is not bound by loads in flight)
+  // +-1 % over all 44 launches of a step: the epilogue is not bound by loads in flight but by its access pattern)
   nt_epilogue<T, EPI, 2>(p, acc, bv, m0, n0, 2 * wr, wc, g, r);
 }
 
@@ -1047,6 +1144,10 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
               "gemm: mask_bits applies to RELU (aux = sign array) and MASK (res = sign array)");
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;
   p.zero_head = d->zero_head; p.zero_tail = d->zero_tail;
+  {
+    static const int rows = [] { const char *e = getenv("CUM_NT8_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
+    p.rows_epilogue = rows;
+  }
   if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);
   if (d->dtype == CUM_F16) return launch_gemm<f16>(p, d->epilogue, (hipStream_t)stream);
   return launch_gemm<float>(p, d->epilogue, (hipStream_t)stream);

@@ -615,6 +615,198 @@ __device__ __forceinline__ void nt8_epilogue_glu_bwd_rows(const GemmParams &p, c
   }
 }
 
+// The same transposition for the bias / ReLU / ReLU-gate epilogues (EPI_BIAS, EPI_RELU, EPI_MASK) of gemm_nt8_kernel:
+// residual or gating activation in (T, or sign nibbles: one byte per four channels), result out, optional second
+// output (the pre-residual / ungated value as T, or the sign nibbles of a ReLU).  Arithmetic and masking are those of
+// nt_epilogue; only the route of the bytes differs.  The launcher-side conditions are in nt8_rows_ok().
+template <typename T, int EPI>
+__device__ __forceinline__ void nt8_epilogue_rows(const GemmParams &p, const f32x4 (*accp)[4][4], const float (&bv)[4][4],
+                                                  int m0, int n0, int wr, int wc, int lane, unsigned char *lw) {
+  constexpr int RS = 144;                          // LDS row stride of a 128-byte row segment
+  constexpr bool kMask = EPI == EPI_MASK;
+  const T *__restrict__ res = static_cast<const T *>(p.res);
+  T *__restrict__ out = static_cast<T *>(p.out);
+  T *__restrict__ aux = static_cast<T *>(p.aux);
+  const int g = lane >> 4, r = lane & 15;
+  const int nw0 = n0 + 64 * wc, mw0 = m0 + 128 * wr;
+  unsigned char *const l_res = lw, *const l_out = lw + 16 * RS, *const l_aux = lw + 32 * RS;
+  unsigned char *const l_bin = lw + 48 * RS, *const l_bout = l_bin + 16 * 16;     // sign nibbles in / out: [16 rows][16 bytes]
+  const bool res_bits = kMask && p.mask_bits, res_t = !res_bits && (kMask || p.res != nullptr);
+  const bool aux_bits = !kMask && p.mask_bits && p.aux != nullptr, aux_t = !aux_bits && p.aux != nullptr;
+  const int lrow = lane >> 3, lch = lane & 7;      // 16-byte accesses: 8 rows x 128 B
+  const int brow = lane >> 2, bch = lane & 3;      // nibble bytes: 16 rows x 16 B, 4 bytes per lane
+  struct In {
+    u32x4 v[2];
+    unsigned bits;
+  };
+  auto issue = [&](int sl, In &in) {
+    if (res_t) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int m_raw = mw0 + 16 * sl + 8 * k + lrow;
+        const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
+        in.v[k] = *reinterpret_cast<const u32x4 *>(res + m * p.ldr + nw0 + 8 * lch);
+      }
+    }
+    if (res_bits) {
+      const int m_raw = mw0 + 16 * sl + brow;
+      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
+      in.bits = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(p.res) + ((m * p.ldr + nw0) >> 2) + 4 * bch);
+    }
+  };
+  In ring[2];
+  issue(0, ring[0]);
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) {
+    if (sl + 1 < 8) issue(sl + 1, ring[(sl + 1) & 1]);
+    const In &cur = ring[sl & 1];
+    if (res_t) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4 *>(l_res + (8 * k + lrow) * RS + 16 * lch) = cur.v[k];
+    }
+    if (res_bits) *reinterpret_cast<unsigned *>(l_bin + 16 * brow + 4 * bch) = cur.bits;
+    const f32x4 (&acc)[4][4] = accp[sl / 4];
+    const int mi = sl % 4;
+    const int m_raw = mw0 + 16 * sl + r;
+    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int io = r * RS + 32 * ni + 8 * g;
+      float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[ni][mi][j] + bv[ni][j];
+        if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
+        v[j] = real ? v[j] : 0.f;
+      }
+      if (res_bits) {
+        const unsigned nib = l_bin[16 * r + 4 * ni + g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = (nib >> j) & 1u ? 1.f : 0.f;
+      } else if (res_t) {
+        load4<T>(reinterpret_cast<const T *>(l_res + io), rr);
+      }
+      if (aux_bits) {
+        unsigned w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= (v[j] > 0.f ? 1u : 0u) << j;
+        l_bout[16 * r + 4 * ni + g] = (unsigned char)w;
+      } else if (aux_t) {
+        store4<T>(reinterpret_cast<T *>(l_aux + io), v);        // ungated / pre-residual value
+      }
+      if constexpr (kMask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rr[j] > 0.f ? v[j] : 0.f;
+      } else if (res_t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = real ? v[j] + rr[j] : 0.f;
+      }
+      store4<T>(reinterpret_cast<T *>(l_out + io), v);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = 8 * k + lrow;
+      const int ms = mw0 + 16 * sl + row;
+      const u32x4 vo = *reinterpret_cast<const u32x4 *>(l_out + row * RS + 16 * lch);
+      if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + nw0 + 8 * lch) = vo;
+      if (aux_t) {
+        const u32x4 va = *reinterpret_cast<const u32x4 *>(l_aux + row * RS + 16 * lch);
+        if (ms < p.M) *reinterpret_cast<u32x4 *>(aux + (int64_t)ms * p.ldz + nw0 + 8 * lch) = va;
+      }
+    }
+    if (aux_bits) {
+      const int ms = mw0 + 16 * sl + brow;
+      const unsigned vb = *reinterpret_cast<const unsigned *>(l_bout + 16 * brow + 4 * bch);
+      if (ms < p.M)
+        *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(p.aux) + (((int64_t)ms * p.ldz + nw0) >> 2) + 4 * bch) = vb;
+    }
+  }
+}
+
+// ... and for the GLU epilogue (EPI_GLU, gate-only saves or none): a wave's 64 accumulator columns are 32 (a, b) pairs
+// = 32 output channels, i.e. 64-byte row segments of the output, of the saved gate and of the residual: one 16-byte
+// access per lane covers 16 rows x 64 B.
+template <typename T>
+__device__ __forceinline__ void nt8_epilogue_glu_rows(const GemmParams &p, const f32x4 (*accp)[4][4], const float (&bv)[4][4],
+                                                      int m0, int n0, int wr, int wc, int lane, unsigned char *lw) {
+  constexpr int RS = 80;                           // LDS row stride of a 64-byte row segment
+  const T *__restrict__ res = static_cast<const T *>(p.res);
+  T *__restrict__ out = static_cast<T *>(p.out);
+  T *__restrict__ aux = static_cast<T *>(p.aux);
+  const int g = lane >> 4, r = lane & 15;
+  const int ow0 = (n0 + 64 * wc) / 2, mw0 = m0 + 128 * wr;   // first output channel of the wave
+  unsigned char *const l_res = lw, *const l_out = lw + 16 * RS, *const l_gate = lw + 32 * RS;
+  const int lrow = lane >> 2, lch = lane & 3;      // 16 rows x 4 chunks of 16 bytes
+  const bool has_res = p.res != nullptr, has_gate = p.aux != nullptr;
+  u32x4 ring[2];
+  auto issue = [&](int sl, u32x4 &v) {
+    if (has_res) {
+      const int m_raw = mw0 + 16 * sl + lrow;
+      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
+      v = *reinterpret_cast<const u32x4 *>(res + m * p.ldr + ow0 + 8 * lch);
+    }
+  };
+  issue(0, ring[0]);
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) {
+    if (sl + 1 < 8) issue(sl + 1, ring[(sl + 1) & 1]);
+    if (has_res) *reinterpret_cast<u32x4 *>(l_res + lrow * RS + 16 * lch) = ring[sl & 1];
+    const f32x4 (&acc)[4][4] = accp[sl / 4];
+    const int mi = sl % 4;
+    const int m_raw = mw0 + 16 * sl + r;
+    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int io = r * RS + 32 * pi + 8 * g;
+      float a[4], b[4], o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = acc[2 * pi][mi][j] + bv[2 * pi][j];
+        b[j] = acc[2 * pi + 1][mi][j] + bv[2 * pi + 1][j];
+        o[j] = real ? a[j] * sigmoidf_(b[j]) : 0.f;
+      }
+      if (has_gate) store4<T>(reinterpret_cast<T *>(l_gate + io), b);
+      if (has_res) {
+        float rr[4];
+        load4<T>(reinterpret_cast<const T *>(l_res + io), rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
+      }
+      store4<T>(reinterpret_cast<T *>(l_out + io), o);
+    }
+    const int ms = mw0 + 16 * sl + lrow;
+    const u32x4 vo = *reinterpret_cast<const u32x4 *>(l_out + lrow * RS + 16 * lch);
+    if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + ow0 + 8 * lch) = vo;
+    if (has_gate) {
+      const u32x4 vg = *reinterpret_cast<const u32x4 *>(l_gate + lrow * RS + 16 * lch);
+      if (ms < p.M) *reinterpret_cast<u32x4 *>(aux + (int64_t)ms * p.ldz + ow0 + 8 * lch) = vg;
+    }
+  }
+}
+
+__device__ __forceinline__ bool nt8_glu_rows_ok(const GemmParams &p, int n0) {
+  if (!p.rows_epilogue || n0 + 256 > p.N || n0 / 2 + 128 > p.n_store) return false;
+  bool ok = (p.ldc & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
+  if (p.res) ok = ok && (p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0;
+  if (p.aux) ok = ok && p.gate_only && (p.ldz & 7) == 0 && ((uintptr_t)p.aux & 15) == 0;
+  return ok;
+}
+
+// Uniform conditions of the LDS-transposed epilogues: a full-width tile, 16-byte aligned rows of every tensor touched
+// as T, 4-byte aligned groups of sign nibbles.
+__device__ __forceinline__ bool nt8_rows_ok(const GemmParams &p, int epi, int n0) {
+  if (!p.rows_epilogue || n0 + 256 > p.n_store) return false;
+  const bool kMask = epi == EPI_MASK;
+  const bool res_bits = kMask && p.mask_bits, res_t = !res_bits && (kMask || p.res != nullptr);
+  const bool aux_bits = !kMask && p.mask_bits && p.aux != nullptr, aux_t = !aux_bits && p.aux != nullptr;
+  bool ok = (p.ldc & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
+  if (res_t) ok = ok && (p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0;
+  if (res_bits) ok = ok && (p.ldr & 15) == 0 && ((uintptr_t)p.res & 3) == 0;
+  if (aux_t) ok = ok && (p.ldz & 7) == 0 && ((uintptr_t)p.aux & 15) == 0;
+  if (aux_bits) ok = ok && (p.ldz & 15) == 0 && ((uintptr_t)p.aux & 3) == 0;
+  return ok;
+}
+
 // ---------------------------------------------------------------- 256 x 256 tile, 8 waves, DMA in flight across barriers
 // The 16-wave 256x256 kernel above waits `vmcnt(0)` + `__syncthreads()` at the top of every K-step: one LDS-DMA stage in
 // flight, every wave stalled while it lands, 16 waves x 64x64 sub-tiles (0.5 fragment reads per MFMA).  This variant
@@ -823,6 +1015,22 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GemmParams p) {
       asm volatile("s_barrier" ::: "memory");        // every wave is done reading the K loop's LDS units
       nt8_epilogue_glu_bwd_rows<T>(p, acc, m0, n0, wr, wc, lane,
                                    reinterpret_cast<unsigned char *>(lds_all) + wave * (48 * 144 + 16 * 272));
+      return;
+    }
+  }
+  if constexpr (EPI == EPI_GLU) {
+    if (nt8_glu_rows_ok(p, n0)) {
+      asm volatile("s_barrier" ::: "memory");        // every wave is done reading the K loop's LDS units
+      nt8_epilogue_glu_rows<T>(p, acc, bv, m0, n0, wr, wc, lane,
+                               reinterpret_cast<unsigned char *>(lds_all) + wave * (48 * 144 + 16 * 272));
+      return;
+    }
+  }
+  if constexpr (EPI == EPI_BIAS || EPI == EPI_RELU || EPI == EPI_MASK) {
+    if (nt8_rows_ok(p, EPI, n0)) {
+      asm volatile("s_barrier" ::: "memory");        // every wave is done reading the K loop's LDS units
+      nt8_epilogue_rows<T, EPI>(p, acc, bv, m0, n0, wr, wc, lane,
+                                reinterpret_cast<unsigned char *>(lds_all) + wave * (48 * 144 + 16 * 272));
       return;
     }
   }

@@ -417,6 +417,311 @@ __device__ __forceinline__ void nt_epilogue(const GemmParams &p, const f32x4 (*a
   }
 }
 
+// GLU-backward epilogue of gemm_nt8_kernel through LDS (gate-only form, full-width tiles, 16-byte aligned rows).
+//
+// In the MFMA result layout a lane touches 8 bytes of 16 different rows per instruction: 16 rows x 32 bytes.  One CU
+// sustains that pattern at 44 us per 256 x 256 tile of this epilogue however idle the rest of the chip is, against 19 us
+// for the same bytes moved 16 bytes per lane along the rows (tools/epi_pattern_probe.hip; in-kernel time stamps put the
+// epilogue at 44 us per tile beside a 55 us K loop).  After the K loop the 128 KB of LDS are free, so every wave
+// transposes its own 128 x 64 sub-tile through a private 11 KB region, one 16-row slab at a time: the three operand
+// slabs arrive with 16-byte row-contiguous loads (8 rows x 128 B per instruction, issued one slab ahead), are re-read in
+// the MFMA layout (row stride 144 B: conflict-free 8-byte reads), and dZ leaves through a row-major staging slab (stride
+// 272 B) as 4 rows x 256 B per store instruction.  Wave-private LDS traffic needs no barrier: the LDS executes a wave's
+// instructions in order.
+// NH: 64-row halves of the wave's sub-tile (gemm_nt8_kernel: 2, gemm_nt_kernel: 1); AHEAD: slabs whose operand loads are
+// issued before the slab being finished (1 where registers allow, 0 in the 128-VGPR kernels).
+template <typename T, int NH, int AHEAD>
+__device__ __forceinline__ void nt_epilogue_glu_bwd_rows(const GemmParams &p, const f32x4 (*accp)[4][4], int mw0, int nw0,
+                                                        int lane, unsigned char *lw) {
+  constexpr int NSL = 4 * NH;
+  constexpr int IS = 144, OS = 272;
+  const T *__restrict__ gb = static_cast<const T *>(p.aux);
+  // without a residual the gate is read in its place (valid memory) and weighted by zero: no branch around the loads
+  const T *__restrict__ res = p.res ? static_cast<const T *>(p.res) : gb;
+  const int64_t ldr = p.res ? p.ldr : p.ldz;
+  const float ew = p.res ? 1.f : 0.f;
+  const T *__restrict__ yy = static_cast<const T *>(p.aux2);
+  T *__restrict__ out = static_cast<T *>(p.out);
+  const int g = lane >> 4, r = lane & 15;
+  unsigned char *const le = lw, *const lb = lw + 16 * IS, *const ly = lw + 32 * IS, *const lo = lw + 48 * IS;
+  const int lrow = lane >> 3, lch = lane & 7;      // loads: 8 rows x 8 chunks of 16 bytes
+  const int srow = lane >> 4, sch = lane & 15;     // stores: 4 rows x 16 chunks
+  struct In {
+    u32x4 e[2], b[2], y[2];
+  };
+  auto issue = [&](int sl, In &v) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int m_raw = mw0 + 16 * sl + 8 * k + lrow;
+      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;           // clamped row, never stored
+      v.e[k] = *reinterpret_cast<const u32x4 *>(res + m * ldr + nw0 + 8 * lch);
+      v.b[k] = *reinterpret_cast<const u32x4 *>(gb + m * p.ldz + nw0 + 8 * lch);
+      v.y[k] = *reinterpret_cast<const u32x4 *>(yy + m * p.ldy + nw0 + 8 * lch);
+    }
+  };
+  In ring[AHEAD + 1];
+  if (AHEAD) issue(0, ring[0]);
+#pragma unroll
+  for (int sl = 0; sl < NSL; ++sl) {
+    if (!AHEAD) issue(sl, ring[0]);
+    else if (sl + 1 < NSL) issue(sl + 1, ring[(sl + 1) & 1]);
+    const In &cur = ring[AHEAD ? sl & 1 : 0];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int off = (8 * k + lrow) * IS + 16 * lch;
+      *reinterpret_cast<u32x4 *>(le + off) = cur.e[k];
+      *reinterpret_cast<u32x4 *>(lb + off) = cur.b[k];
+      *reinterpret_cast<u32x4 *>(ly + off) = cur.y[k];
+    }
+    const f32x4 (&acc)[4][4] = accp[sl / 4];
+    const int mi = sl % 4;
+    const int m_raw = mw0 + 16 * sl + r;
+    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int io = r * IS + 32 * ni + 8 * g;
+      float e[4], b[4], a[4], da[4], db[4];
+      load4<T>(reinterpret_cast<const T *>(le + io), e);
+      load4<T>(reinterpret_cast<const T *>(lb + io), b);
+      load4<T>(reinterpret_cast<const T *>(ly + io), a);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sg = sigmoidf_(b[j]);
+        const float dj = real ? fmaf(ew, e[j], acc[ni][mi][j]) : 0.f;
+        da[j] = dj * sg;
+        db[j] = dj * a[j] * (1.f - sg);
+      }
+      store4<T>(reinterpret_cast<T *>(lo + r * OS + 64 * ni + 8 * g), da);
+      store4<T>(reinterpret_cast<T *>(lo + r * OS + 64 * ni + 8 * g + 32), db);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = 4 * k + srow;
+      const int ms = mw0 + 16 * sl + row;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(lo + row * OS + 16 * sch);
+      if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + 2 * nw0 + 8 * sch) = v;
+    }
+  }
+}
+
+// The same transposition for the bias / ReLU / ReLU-gate epilogues (EPI_BIAS, EPI_RELU, EPI_MASK) of gemm_nt8_kernel:
+// residual or gating activation in (T, or sign nibbles: one byte per four channels), result out, optional second
+// output (the pre-residual / ungated value as T, or the sign nibbles of a ReLU).  Arithmetic and masking are those of
+// nt_epilogue; only the route of the bytes differs.  The launcher-side conditions are in nt8_rows_ok().
+template <typename T, int EPI, int NH, int AHEAD>
+__device__ __forceinline__ void nt_epilogue_rows(const GemmParams &p, const f32x4 (*accp)[4][4], const float (&bv)[4][4],
+                                                 int mw0, int nw0, int lane, unsigned char *lw) {
+  constexpr int NSL = 4 * NH;
+  constexpr int RS = 144;                          // LDS row stride of a 128-byte row segment
+  constexpr bool kMask = EPI == EPI_MASK;
+  const T *__restrict__ res = static_cast<const T *>(p.res);
+  T *__restrict__ out = static_cast<T *>(p.out);
+  T *__restrict__ aux = static_cast<T *>(p.aux);
+  const int g = lane >> 4, r = lane & 15;
+  unsigned char *const l_res = lw, *const l_out = lw + 16 * RS, *const l_aux = lw + 32 * RS;
+  unsigned char *const l_bin = lw + 48 * RS, *const l_bout = l_bin + 16 * 16;     // sign nibbles in / out: [16 rows][16 bytes]
+  const bool res_bits = kMask && p.mask_bits, res_t = !res_bits && (kMask || p.res != nullptr);
+  const bool aux_bits = !kMask && p.mask_bits && p.aux != nullptr, aux_t = !aux_bits && p.aux != nullptr;
+  const int lrow = lane >> 3, lch = lane & 7;      // 16-byte accesses: 8 rows x 128 B
+  const int brow = lane >> 2, bch = lane & 3;      // nibble bytes: 16 rows x 16 B, 4 bytes per lane
+  struct In {
+    u32x4 v[2];
+    unsigned bits;
+  };
+  auto issue = [&](int sl, In &in) {
+    if (res_t) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int m_raw = mw0 + 16 * sl + 8 * k + lrow;
+        const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
+        in.v[k] = *reinterpret_cast<const u32x4 *>(res + m * p.ldr + nw0 + 8 * lch);
+      }
+    }
+    if (res_bits) {
+      const int m_raw = mw0 + 16 * sl + brow;
+      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
+      in.bits = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(p.res) + ((m * p.ldr + nw0) >> 2) + 4 * bch);
+    }
+  };
+  In ring[AHEAD + 1];
+  if (AHEAD) issue(0, ring[0]);
+#pragma unroll
+  for (int sl = 0; sl < NSL; ++sl) {
+    if (!AHEAD) issue(sl, ring[0]);
+    else if (sl + 1 < NSL) issue(sl + 1, ring[(sl + 1) & 1]);
+    const In &cur = ring[AHEAD ? sl & 1 : 0];
+    if (res_t) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4 *>(l_res + (8 * k + lrow) * RS + 16 * lch) = cur.v[k];
+    }
+    if (res_bits) *reinterpret_cast<unsigned *>(l_bin + 16 * brow + 4 * bch) = cur.bits;
+    const f32x4 (&acc)[4][4] = accp[sl / 4];
+    const int mi = sl % 4;
+    const int m_raw = mw0 + 16 * sl + r;
+    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int io = r * RS + 32 * ni + 8 * g;
+      float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[ni][mi][j] + bv[ni][j];
+        if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
+        v[j] = real ? v[j] : 0.f;
+      }
+      if (res_bits) {
+        const unsigned nib = l_bin[16 * r + 4 * ni + g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = (nib >> j) & 1u ? 1.f : 0.f;
+      } else if (res_t) {
+        load4<T>(reinterpret_cast<const T *>(l_res + io), rr);
+      }
+      if (aux_bits) {
+        unsigned w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= (v[j] > 0.f ? 1u : 0u) << j;
+        l_bout[16 * r + 4 * ni + g] = (unsigned char)w;
+      } else if (aux_t) {
+        store4<T>(reinterpret_cast<T *>(l_aux + io), v);        // ungated / pre-residual value
+      }
+      if constexpr (kMask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rr[j] > 0.f ? v[j] : 0.f;
+      } else if (res_t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = real ? v[j] + rr[j] : 0.f;
+      }
+      store4<T>(reinterpret_cast<T *>(l_out + io), v);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = 8 * k + lrow;
+      const int ms = mw0 + 16 * sl + row;
+      const u32x4 vo = *reinterpret_cast<const u32x4 *>(l_out + row * RS + 16 * lch);
+      if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + nw0 + 8 * lch) = vo;
+      if (aux_t) {
+        const u32x4 va = *reinterpret_cast<const u32x4 *>(l_aux + row * RS + 16 * lch);
+        if (ms < p.M) *reinterpret_cast<u32x4 *>(aux + (int64_t)ms * p.ldz + nw0 + 8 * lch) = va;
+      }
+    }
+    if (aux_bits) {
+      const int ms = mw0 + 16 * sl + brow;
+      const unsigned vb = *reinterpret_cast<const unsigned *>(l_bout + 16 * brow + 4 * bch);
+      if (ms < p.M)
+        *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(p.aux) + (((int64_t)ms * p.ldz + nw0) >> 2) + 4 * bch) = vb;
+    }
+  }
+}
+
+// ... and for the GLU epilogue (EPI_GLU, gate-only saves or none): a wave's 64 accumulator columns are 32 (a, b) pairs
+// = 32 output channels, i.e. 64-byte row segments of the output, of the saved gate and of the residual: one 16-byte
+// access per lane covers 16 rows x 64 B.
+template <typename T, int NH, int AHEAD>
+__device__ __forceinline__ void nt_epilogue_glu_rows(const GemmParams &p, const f32x4 (*accp)[4][4], const float (&bv)[4][4],
+                                                     int mw0, int nw0, int lane, unsigned char *lw) {
+  constexpr int NSL = 4 * NH;
+  constexpr int RS = 80;                           // LDS row stride of a 64-byte row segment
+  const T *__restrict__ res = static_cast<const T *>(p.res);
+  T *__restrict__ out = static_cast<T *>(p.out);
+  T *__restrict__ aux = static_cast<T *>(p.aux);
+  const int g = lane >> 4, r = lane & 15;
+  const int ow0 = nw0 / 2;                         // first output channel of the wave
+  unsigned char *const l_res = lw, *const l_out = lw + 16 * RS, *const l_gate = lw + 32 * RS;
+  const int lrow = lane >> 2, lch = lane & 3;      // 16 rows x 4 chunks of 16 bytes
+  const bool has_res = p.res != nullptr, has_gate = p.aux != nullptr;
+  u32x4 ring[AHEAD + 1];
+  auto issue = [&](int sl, u32x4 &v) {
+    if (has_res) {
+      const int m_raw = mw0 + 16 * sl + lrow;
+      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
+      v = *reinterpret_cast<const u32x4 *>(res + m * p.ldr + ow0 + 8 * lch);
+    }
+  };
+  if (AHEAD) issue(0, ring[0]);
+#pragma unroll
+  for (int sl = 0; sl < NSL; ++sl) {
+    if (!AHEAD) issue(sl, ring[0]);
+    else if (sl + 1 < NSL) issue(sl + 1, ring[(sl + 1) & 1]);
+    if (has_res) *reinterpret_cast<u32x4 *>(l_res + lrow * RS + 16 * lch) = ring[AHEAD ? sl & 1 : 0];
+    const f32x4 (&acc)[4][4] = accp[sl / 4];
+    const int mi = sl % 4;
+    const int m_raw = mw0 + 16 * sl + r;
+    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int io = r * RS + 32 * pi + 8 * g;
+      float a[4], b[4], o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = acc[2 * pi][mi][j] + bv[2 * pi][j];
+        b[j] = acc[2 * pi + 1][mi][j] + bv[2 * pi + 1][j];
+        o[j] = real ? a[j] * sigmoidf_(b[j]) : 0.f;
+      }
+      if (has_gate) store4<T>(reinterpret_cast<T *>(l_gate + io), b);
+      if (has_res) {
+        float rr[4];
+        load4<T>(reinterpret_cast<const T *>(l_res + io), rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
+      }
+      store4<T>(reinterpret_cast<T *>(l_out + io), o);
+    }
+    const int ms = mw0 + 16 * sl + lrow;
+    const u32x4 vo = *reinterpret_cast<const u32x4 *>(l_out + lrow * RS + 16 * lch);
+    if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + ow0 + 8 * lch) = vo;
+    if (has_gate) {
+      const u32x4 vg = *reinterpret_cast<const u32x4 *>(l_gate + lrow * RS + 16 * lch);
+      if (ms < p.M) *reinterpret_cast<u32x4 *>(aux + (int64_t)ms * p.ldz + ow0 + 8 * lch) = vg;
+    }
+  }
+}
+
+// Per-wave conditions of the LDS-transposed epilogues: all 64 columns of the wave's sub-tile are stored, rows of every
+// tensor touched as T are 16-byte aligned, groups of sign nibbles 4-byte aligned.  (Anything else takes nt_epilogue.)
+__device__ __forceinline__ bool nt_rows_ok(const GemmParams &p, int epi, int nw0) {
+  if (!p.rows_epilogue) return false;
+  if (epi == EPI_GLU) {
+    if (nw0 + 64 > p.N || nw0 / 2 + 32 > p.n_store) return false;
+    bool ok = (p.ldc & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
+    if (p.res) ok = ok && (p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0;
+    if (p.aux) ok = ok && p.gate_only && (p.ldz & 7) == 0 && ((uintptr_t)p.aux & 15) == 0;
+    return ok;
+  }
+  if (nw0 + 64 > p.n_store) return false;
+  if (epi == EPI_GLU_BWD)
+    return p.gate_only && (((p.res ? p.ldr : 0) | p.ldz | p.ldy | p.ldc) & 7) == 0 &&
+           ((((uintptr_t)p.res) | ((uintptr_t)p.aux) | ((uintptr_t)p.aux2) | ((uintptr_t)p.out)) & 15) == 0;
+  const bool kMask = epi == EPI_MASK;
+  const bool res_bits = kMask && p.mask_bits, res_t = !res_bits && (kMask || p.res != nullptr);
+  const bool aux_bits = !kMask && p.mask_bits && p.aux != nullptr, aux_t = !aux_bits && p.aux != nullptr;
+  bool ok = (p.ldc & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
+  if (res_t) ok = ok && (p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0;
+  if (res_bits) ok = ok && (p.ldr & 15) == 0 && ((uintptr_t)p.res & 3) == 0;
+  if (aux_t) ok = ok && (p.ldz & 7) == 0 && ((uintptr_t)p.aux & 15) == 0;
+  if (aux_bits) ok = ok && (p.ldz & 15) == 0 && ((uintptr_t)p.aux & 3) == 0;
+  return ok;
+}
+
+// bytes of wave-private LDS an LDS-transposed epilogue needs
+constexpr int nt_rows_lds(int epi) { return epi == EPI_GLU_BWD ? 48 * 144 + 16 * 272 : epi == EPI_GLU ? 48 * 80 : 48 * 144 + 2 * 256; }
+
+// One wave's epilogue: through LDS when nt_rows_ok, else the generic one.  The caller has made sure (barrier) that
+// nobody still reads the K loop's LDS tiles.
+template <typename T, int EPI, int NH, int AHEAD>
+__device__ __forceinline__ void nt_epilogue_any(const GemmParams &p, const f32x4 (*accp)[4][4], const float (&bv)[4][4], int m0,
+                                                int n0, int wm0, int wn, int lane, unsigned char *lw) {
+  const int mw0 = m0 + 64 * wm0, nw0 = n0 + 64 * wn;
+  if constexpr (sizeof(T) == 2) {
+    if (nt_rows_ok(p, EPI, nw0)) {
+      if constexpr (EPI == EPI_GLU_BWD) nt_epilogue_glu_bwd_rows<T, NH, AHEAD>(p, accp, mw0, nw0, lane, lw);
+      else if constexpr (EPI == EPI_GLU) nt_epilogue_glu_rows<T, NH, AHEAD>(p, accp, bv, mw0, nw0, lane, lw);
+      else nt_epilogue_rows<T, EPI, NH, AHEAD>(p, accp, bv, mw0, nw0, lane, lw);
+      return;
+    }
+  }
+  nt_epilogue<T, EPI, NH>(p, accp, bv, m0, n0, wm0, wn, lane >> 4, lane & 15);
+}
+
 // Block tiles BM x BN, one wave per 64x64 sub-tile:
 //   128x128 (4 waves, 32 KB LDS, 4 workgroups/CU), 256x128 (8 waves, 48 KB, 2-3 workgroups/CU): single LDS
 //   buffer, the interleaving of the co-resident workgroups hides the load latency;
@@ -436,7 +741,14 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(si
   constexpr int WCH = BN * 8 / NT;   // weight chunks per thread
   constexpr bool DB = (BM == 256 && BN == 256);
   constexpr int STAGE = (BM + BN) * 8;
-  __shared__ uint4 lds_all[(DB ? 2 : 1) * STAGE];  // per stage [row * 8 + chunk]: activations, then weights
+  // per stage [row * 8 + chunk]: activations, then weights; after the K loop the same memory is the waves' private
+  // transposition space of the LDS-routed epilogues (16-bit types; the GLU-backward one needs 11 KB per wave)
+  constexpr int TILE_CHUNKS = (DB ? 2 : 1) * STAGE;
+  // LDS-routed epilogues: the 128 x 128 tile of the 16-bit types (the 16-wave tile is the A/B fallback of gemm_nt8_kernel
+  // and the 256 x 128 tile would drop to one or two workgroups per CU: both keep the generic epilogue)
+  constexpr bool ROWS = sizeof(T) == 2 && BM == 128 && BN == 128;
+  constexpr int EPI_CHUNKS = ROWS ? (NT / 64) * nt_rows_lds(EPI) / 16 : 0;
+  __shared__ uint4 lds_all[TILE_CHUNKS > EPI_CHUNKS ? TILE_CHUNKS : EPI_CHUNKS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -526,285 +838,11 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(si
   }
 #undef CUM_GLDS
 
-  nt_epilogue<T, EPI>(p, &acc, bv, m0, n0, wm, wn, g, r);
-}
-
-// GLU-backward epilogue of gemm_nt8_kernel through LDS (gate-only form, full-width tiles, 16-byte aligned rows).
-//
-// In the MFMA result layout a lane touches 8 bytes of 16 different rows per instruction: 16 rows x 32 bytes.  One CU
-// sustains that pattern at 44 us per 256 x 256 tile of this epilogue however idle the rest of the chip is, against 19 us
-// for the same bytes moved 16 bytes per lane along the rows (tools/epi_pattern_probe.hip; in-kernel time stamps put the
-// epilogue at 44 us per tile beside a 55 us K loop).  After the K loop the 128 KB of LDS are free, so every wave
-// transposes its own 128 x 64 sub-tile through a private 11 KB region, one 16-row slab at a time: the three operand
-// slabs arrive with 16-byte row-contiguous loads (8 rows x 128 B per instruction, issued one slab ahead), are re-read in
-// the MFMA layout (row stride 144 B: conflict-free 8-byte reads), and dZ leaves through a row-major staging slab (stride
-// 272 B) as 4 rows x 256 B per store instruction.  Wave-private LDS traffic needs no barrier: the LDS executes a wave's
-// instructions in order.
-__device__ __forceinline__ bool nt8_rows_epilogue_on(const GemmParams &p) { return p.rows_epilogue != 0; }
-
-template <typename T>
-__device__ __forceinline__ void nt8_epilogue_glu_bwd_rows(const GemmParams &p, const f32x4 (*accp)[4][4], int m0, int n0,
-                                                         int wr, int wc, int lane, unsigned char *lw) {
-  constexpr int IS = 144, OS = 272;
-  const T *__restrict__ gb = static_cast<const T *>(p.aux);
-  // without a residual the gate is read in its place (valid memory) and weighted by zero: no branch around the loads
-  const T *__restrict__ res = p.res ? static_cast<const T *>(p.res) : gb;
-  const int64_t ldr = p.res ? p.ldr : p.ldz;
-  const float ew = p.res ? 1.f : 0.f;
-  const T *__restrict__ yy = static_cast<const T *>(p.aux2);
-  T *__restrict__ out = static_cast<T *>(p.out);
-  const int g = lane >> 4, r = lane & 15;
-  const int nw0 = n0 + 64 * wc, mw0 = m0 + 128 * wr;
-  unsigned char *const le = lw, *const lb = lw + 16 * IS, *const ly = lw + 32 * IS, *const lo = lw + 48 * IS;
-  const int lrow = lane >> 3, lch = lane & 7;      // loads: 8 rows x 8 chunks of 16 bytes
-  const int srow = lane >> 4, sch = lane & 15;     // stores: 4 rows x 16 chunks
-  struct In {
-    u32x4 e[2], b[2], y[2];
-  };
-  auto issue = [&](int sl, In &v) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int m_raw = mw0 + 16 * sl + 8 * k + lrow;
-      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;           // clamped row, never stored
-      v.e[k] = *reinterpret_cast<const u32x4 *>(res + m * ldr + nw0 + 8 * lch);
-      v.b[k] = *reinterpret_cast<const u32x4 *>(gb + m * p.ldz + nw0 + 8 * lch);
-      v.y[k] = *reinterpret_cast<const u32x4 *>(yy + m * p.ldy + nw0 + 8 * lch);
-    }
-  };
-  In ring[2];
-  issue(0, ring[0]);
-#pragma unroll
-  for (int sl = 0; sl < 8; ++sl) {
-    if (sl + 1 < 8) issue(sl + 1, ring[(sl + 1) & 1]);
-    const In &cur = ring[sl & 1];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int off = (8 * k + lrow) * IS + 16 * lch;
-      *reinterpret_cast<u32x4 *>(le + off) = cur.e[k];
-      *reinterpret_cast<u32x4 *>(lb + off) = cur.b[k];
-      *reinterpret_cast<u32x4 *>(ly + off) = cur.y[k];
-    }
-    const f32x4 (&acc)[4][4] = accp[sl / 4];
-    const int mi = sl % 4;
-    const int m_raw = mw0 + 16 * sl + r;
-    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int io = r * IS + 32 * ni + 8 * g;
-      float e[4], b[4], a[4], da[4], db[4];
-      load4<T>(reinterpret_cast<const T *>(le + io), e);
-      load4<T>(reinterpret_cast<const T *>(lb + io), b);
-      load4<T>(reinterpret_cast<const T *>(ly + io), a);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float sg = sigmoidf_(b[j]);
-        const float dj = real ? fmaf(ew, e[j], acc[ni][mi][j]) : 0.f;
-        da[j] = dj * sg;
-        db[j] = dj * a[j] * (1.f - sg);
-      }
-      store4<T>(reinterpret_cast<T *>(lo + r * OS + 64 * ni + 8 * g), da);
-      store4<T>(reinterpret_cast<T *>(lo + r * OS + 64 * ni + 8 * g + 32), db);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = 4 * k + srow;
-      const int ms = mw0 + 16 * sl + row;
-      const u32x4 v = *reinterpret_cast<const u32x4 *>(lo + row * OS + 16 * sch);
-      if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + 2 * nw0 + 8 * sch) = v;
-    }
-  }
-}
-
-// The same transposition for the bias / ReLU / ReLU-gate epilogues (EPI_BIAS, EPI_RELU, EPI_MASK) of gemm_nt8_kernel:
-// residual or gating activation in (T, or sign nibbles: one byte per four channels), result out, optional second
-// output (the pre-residual / ungated value as T, or the sign nibbles of a ReLU).  Arithmetic and masking are those of
-// nt_epilogue; only the route of the bytes differs.  The launcher-side conditions are in nt8_rows_ok().
-template <typename T, int EPI>
-__device__ __forceinline__ void nt8_epilogue_rows(const GemmParams &p, const f32x4 (*accp)[4][4], const float (&bv)[4][4],
-                                                  int m0, int n0, int wr, int wc, int lane, unsigned char *lw) {
-  constexpr int RS = 144;                          // LDS row stride of a 128-byte row segment
-  constexpr bool kMask = EPI == EPI_MASK;
-  const T *__restrict__ res = static_cast<const T *>(p.res);
-  T *__restrict__ out = static_cast<T *>(p.out);
-  T *__restrict__ aux = static_cast<T *>(p.aux);
-  const int g = lane >> 4, r = lane & 15;
-  const int nw0 = n0 + 64 * wc, mw0 = m0 + 128 * wr;
-  unsigned char *const l_res = lw, *const l_out = lw + 16 * RS, *const l_aux = lw + 32 * RS;
-  unsigned char *const l_bin = lw + 48 * RS, *const l_bout = l_bin + 16 * 16;     // sign nibbles in / out: [16 rows][16 bytes]
-  const bool res_bits = kMask && p.mask_bits, res_t = !res_bits && (kMask || p.res != nullptr);
-  const bool aux_bits = !kMask && p.mask_bits && p.aux != nullptr, aux_t = !aux_bits && p.aux != nullptr;
-  const int lrow = lane >> 3, lch = lane & 7;      // 16-byte accesses: 8 rows x 128 B
-  const int brow = lane >> 2, bch = lane & 3;      // nibble bytes: 16 rows x 16 B, 4 bytes per lane
-  struct In {
-    u32x4 v[2];
-    unsigned bits;
-  };
-  auto issue = [&](int sl, In &in) {
-    if (res_t) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int m_raw = mw0 + 16 * sl + 8 * k + lrow;
-        const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
-        in.v[k] = *reinterpret_cast<const u32x4 *>(res + m * p.ldr + nw0 + 8 * lch);
-      }
-    }
-    if (res_bits) {
-      const int m_raw = mw0 + 16 * sl + brow;
-      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
-      in.bits = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(p.res) + ((m * p.ldr + nw0) >> 2) + 4 * bch);
-    }
-  };
-  In ring[2];
-  issue(0, ring[0]);
-#pragma unroll
-  for (int sl = 0; sl < 8; ++sl) {
-    if (sl + 1 < 8) issue(sl + 1, ring[(sl + 1) & 1]);
-    const In &cur = ring[sl & 1];
-    if (res_t) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4 *>(l_res + (8 * k + lrow) * RS + 16 * lch) = cur.v[k];
-    }
-    if (res_bits) *reinterpret_cast<unsigned *>(l_bin + 16 * brow + 4 * bch) = cur.bits;
-    const f32x4 (&acc)[4][4] = accp[sl / 4];
-    const int mi = sl % 4;
-    const int m_raw = mw0 + 16 * sl + r;
-    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int io = r * RS + 32 * ni + 8 * g;
-      float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = acc[ni][mi][j] + bv[ni][j];
-        if (EPI == EPI_RELU) v[j] = fmaxf(v[j], 0.f);
-        v[j] = real ? v[j] : 0.f;
-      }
-      if (res_bits) {
-        const unsigned nib = l_bin[16 * r + 4 * ni + g];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rr[j] = (nib >> j) & 1u ? 1.f : 0.f;
-      } else if (res_t) {
-        load4<T>(reinterpret_cast<const T *>(l_res + io), rr);
-      }
-      if (aux_bits) {
-        unsigned w = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w |= (v[j] > 0.f ? 1u : 0u) << j;
-        l_bout[16 * r + 4 * ni + g] = (unsigned char)w;
-      } else if (aux_t) {
-        store4<T>(reinterpret_cast<T *>(l_aux + io), v);        // ungated / pre-residual value
-      }
-      if constexpr (kMask) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rr[j] > 0.f ? v[j] : 0.f;
-      } else if (res_t) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = real ? v[j] + rr[j] : 0.f;
-      }
-      store4<T>(reinterpret_cast<T *>(l_out + io), v);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int row = 8 * k + lrow;
-      const int ms = mw0 + 16 * sl + row;
-      const u32x4 vo = *reinterpret_cast<const u32x4 *>(l_out + row * RS + 16 * lch);
-      if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + nw0 + 8 * lch) = vo;
-      if (aux_t) {
-        const u32x4 va = *reinterpret_cast<const u32x4 *>(l_aux + row * RS + 16 * lch);
-        if (ms < p.M) *reinterpret_cast<u32x4 *>(aux + (int64_t)ms * p.ldz + nw0 + 8 * lch) = va;
-      }
-    }
-    if (aux_bits) {
-      const int ms = mw0 + 16 * sl + brow;
-      const unsigned vb = *reinterpret_cast<const unsigned *>(l_bout + 16 * brow + 4 * bch);
-      if (ms < p.M)
-        *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(p.aux) + (((int64_t)ms * p.ldz + nw0) >> 2) + 4 * bch) = vb;
-    }
-  }
-}
-
-// ... and for the GLU epilogue (EPI_GLU, gate-only saves or none): a wave's 64 accumulator columns are 32 (a, b) pairs
-// = 32 output channels, i.e. 64-byte row segments of the output, of the saved gate and of the residual: one 16-byte
-// access per lane covers 16 rows x 64 B.
-template <typename T>
-__device__ __forceinline__ void nt8_epilogue_glu_rows(const GemmParams &p, const f32x4 (*accp)[4][4], const float (&bv)[4][4],
-                                                      int m0, int n0, int wr, int wc, int lane, unsigned char *lw) {
-  constexpr int RS = 80;                           // LDS row stride of a 64-byte row segment
-  const T *__restrict__ res = static_cast<const T *>(p.res);
-  T *__restrict__ out = static_cast<T *>(p.out);
-  T *__restrict__ aux = static_cast<T *>(p.aux);
-  const int g = lane >> 4, r = lane & 15;
-  const int ow0 = (n0 + 64 * wc) / 2, mw0 = m0 + 128 * wr;   // first output channel of the wave
-  unsigned char *const l_res = lw, *const l_out = lw + 16 * RS, *const l_gate = lw + 32 * RS;
-  const int lrow = lane >> 2, lch = lane & 3;      // 16 rows x 4 chunks of 16 bytes
-  const bool has_res = p.res != nullptr, has_gate = p.aux != nullptr;
-  u32x4 ring[2];
-  auto issue = [&](int sl, u32x4 &v) {
-    if (has_res) {
-      const int m_raw = mw0 + 16 * sl + lrow;
-      const int64_t m = m_raw < p.M ? m_raw : p.M - 1;
-      v = *reinterpret_cast<const u32x4 *>(res + m * p.ldr + ow0 + 8 * lch);
-    }
-  };
-  issue(0, ring[0]);
-#pragma unroll
-  for (int sl = 0; sl < 8; ++sl) {
-    if (sl + 1 < 8) issue(sl + 1, ring[(sl + 1) & 1]);
-    if (has_res) *reinterpret_cast<u32x4 *>(l_res + lrow * RS + 16 * lch) = ring[sl & 1];
-    const f32x4 (&acc)[4][4] = accp[sl / 4];
-    const int mi = sl % 4;
-    const int m_raw = mw0 + 16 * sl + r;
-    const bool real = m_raw < p.M && (m_raw % p.pitch) < p.valid;
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-      const int io = r * RS + 32 * pi + 8 * g;
-      float a[4], b[4], o[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a[j] = acc[2 * pi][mi][j] + bv[2 * pi][j];
-        b[j] = acc[2 * pi + 1][mi][j] + bv[2 * pi + 1][j];
-        o[j] = real ? a[j] * sigmoidf_(b[j]) : 0.f;
-      }
-      if (has_gate) store4<T>(reinterpret_cast<T *>(l_gate + io), b);
-      if (has_res) {
-        float rr[4];
-        load4<T>(reinterpret_cast<const T *>(l_res + io), rr);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = real ? o[j] + rr[j] : 0.f;
-      }
-      store4<T>(reinterpret_cast<T *>(l_out + io), o);
-    }
-    const int ms = mw0 + 16 * sl + lrow;
-    const u32x4 vo = *reinterpret_cast<const u32x4 *>(l_out + lrow * RS + 16 * lch);
-    if (ms < p.M) *reinterpret_cast<u32x4 *>(out + (int64_t)ms * p.ldc + ow0 + 8 * lch) = vo;
-    if (has_gate) {
-      const u32x4 vg = *reinterpret_cast<const u32x4 *>(l_gate + lrow * RS + 16 * lch);
-      if (ms < p.M) *reinterpret_cast<u32x4 *>(aux + (int64_t)ms * p.ldz + ow0 + 8 * lch) = vg;
-    }
-  }
-}
-
-__device__ __forceinline__ bool nt8_glu_rows_ok(const GemmParams &p, int n0) {
-  if (!p.rows_epilogue || n0 + 256 > p.N || n0 / 2 + 128 > p.n_store) return false;
-  bool ok = (p.ldc & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
-  if (p.res) ok = ok && (p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0;
-  if (p.aux) ok = ok && p.gate_only && (p.ldz & 7) == 0 && ((uintptr_t)p.aux & 15) == 0;
-  return ok;
-}
-
-// Uniform conditions of the LDS-transposed epilogues: a full-width tile, 16-byte aligned rows of every tensor touched
-// as T, 4-byte aligned groups of sign nibbles.
-__device__ __forceinline__ bool nt8_rows_ok(const GemmParams &p, int epi, int n0) {
-  if (!p.rows_epilogue || n0 + 256 > p.n_store) return false;
-  const bool kMask = epi == EPI_MASK;
-  const bool res_bits = kMask && p.mask_bits, res_t = !res_bits && (kMask || p.res != nullptr);
-  const bool aux_bits = !kMask && p.mask_bits && p.aux != nullptr, aux_t = !aux_bits && p.aux != nullptr;
-  bool ok = (p.ldc & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
-  if (res_t) ok = ok && (p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0;
-  if (res_bits) ok = ok && (p.ldr & 15) == 0 && ((uintptr_t)p.res & 3) == 0;
-  if (aux_t) ok = ok && (p.ldz & 7) == 0 && ((uintptr_t)p.aux & 15) == 0;
-  if (aux_bits) ok = ok && (p.ldz & 15) == 0 && ((uintptr_t)p.aux & 3) == 0;
-  return ok;
+  if constexpr (ROWS)   // (the single-buffered loop ends with a barrier: the LDS is free; 128 VGPRs: no slab of loads ahead)
+    nt_epilogue_any<T, EPI, 1, 0>(p, &acc, bv, m0, n0, wm, wn, lane,
+                                  reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
+  else
+    nt_epilogue<T, EPI>(p, &acc, bv, m0, n0, wm, wn, g, r);
 }
 
 // ---------------------------------------------------------------- 256 x 256 tile, 8 waves, DMA in flight across barriers
@@ -1008,35 +1046,12 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GemmParams p) {
 #undef CUM_DSR
 #undef CUM_QUAD
 #undef CUM_STAGE
-  if constexpr (EPI == EPI_GLU_BWD) {
-    const bool rows16 = (((p.res ? p.ldr : 0) | p.ldz | p.ldy | p.ldc) & 7) == 0 &&
-                        ((((uintptr_t)p.res) | ((uintptr_t)p.aux) | ((uintptr_t)p.aux2) | ((uintptr_t)p.out)) & 15) == 0;
-    if (p.gate_only && rows16 && n0 + 256 <= p.n_store && nt8_rows_epilogue_on(p)) {
-      asm volatile("s_barrier" ::: "memory");        // every wave is done reading the K loop's LDS units
-      nt8_epilogue_glu_bwd_rows<T>(p, acc, m0, n0, wr, wc, lane,
-                                   reinterpret_cast<unsigned char *>(lds_all) + wave * (48 * 144 + 16 * 272));
-      return;
-    }
-  }
-  if constexpr (EPI == EPI_GLU) {
-    if (nt8_glu_rows_ok(p, n0)) {
-      asm volatile("s_barrier" ::: "memory");        // every wave is done reading the K loop's LDS units
-      nt8_epilogue_glu_rows<T>(p, acc, bv, m0, n0, wr, wc, lane,
-                               reinterpret_cast<unsigned char *>(lds_all) + wave * (48 * 144 + 16 * 272));
-      return;
-    }
-  }
-  if constexpr (EPI == EPI_BIAS || EPI == EPI_RELU || EPI == EPI_MASK) {
-    if (nt8_rows_ok(p, EPI, n0)) {
-      asm volatile("s_barrier" ::: "memory");        // every wave is done reading the K loop's LDS units
-      nt8_epilogue_rows<T, EPI>(p, acc, bv, m0, n0, wr, wc, lane,
-                                reinterpret_cast<unsigned char *>(lds_all) + wave * (48 * 144 + 16 * 272));
-      return;
-    }
-  }
-  // (the fragment registers are dead here, so deeper load pipelining fits -- PIPE = 0 / 1 / 2 / 3 measured the same to
-  // +-1 % over all 44 launches of a step: the epilogue is not bound by loads in flight but by its access pattern)
-  nt_epilogue<T, EPI, 2>(p, acc, bv, m0, n0, 2 * wr, wc, g, r);
+  // Epilogue: through wave-private LDS where the conditions hold (nt_epilogue_any); the fragment registers are dead here,
+  // so one slab of operand loads is issued ahead.  (Deeper pipelining of the generic epilogue measured neutral: it is
+  // bound by its access pattern, not by loads in flight.)
+  asm volatile("s_barrier" ::: "memory");          // every wave is done reading the K loop's LDS units
+  nt_epilogue_any<T, EPI, 2, 1>(p, acc, bv, m0, n0, 2 * wr, wc, lane,
+                                reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
 }
 
 // ---------------------------------------------------------------- small-M variant (streaming hops)
@@ -1309,7 +1324,9 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
     // matters (the outer layers are bound by their activation traffic, where the tile shape is irrelevant)
     // (16-bit only: the f32 instantiation of the 1024-thread tile is capped at 128 VGPRs and spills)
     if (sizeof(T) == 2 && p.K >= 256 && tiles_256x256 >= 224 && p.N % 256 == 0) tile = 512;
-    else if (p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
+    // (16-bit types: the 128 x 128 kernel routes its epilogue through LDS, which the outer, HBM-bound layers that
+    //  used to take the 256 x 128 tile gain more from than from the taller tile)
+    else if (sizeof(T) == 4 && p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
     else tile = 128;
   }
   if (tile == 512 && sizeof(T) == 2 && nt8_enabled()) return launch_gemm_nt8<T>(p, epi, st);

@@ -694,6 +694,9 @@ __device__ __forceinline__ bool nt_rows_ok(const GemmParams &p, int epi, int nw0
   const bool kMask = epi == EPI_MASK;
   const bool res_bits = kMask && p.mask_bits, res_t = !res_bits && (kMask || p.res != nullptr);
   const bool aux_bits = !kMask && p.mask_bits && p.aux != nullptr, aux_t = !aux_bits && p.aux != nullptr;
+  // a store-only epilogue (no operand to read, one output) gains nothing from the detour: measured 85 -> 99 us on the
+  // 1 282 048 x 64 x 64 launch, +-2 % on the deep ones
+  if (!res_t && !res_bits && !aux_t && !aux_bits) return false;
   bool ok = (p.ldc & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
   if (res_t) ok = ok && (p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0;
   if (res_bits) ok = ok && (p.ldr & 15) == 0 && ((uintptr_t)p.res & 3) == 0;

@@ -145,6 +145,8 @@ class CleanUMamba(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop("_pack_plans", None)      # device-side caches of packed weights are rebuilt on demand
+        state.pop("_plist", None)
+        state.pop("_wv_call", None)
         state.pop("_hop_graph", None)       # captured hipGraph of the streaming hop
         return state
 
@@ -338,6 +340,7 @@ class CleanUMamba(nn.Module):
         """Drop the cached GEMM-layout copies of the conv weights (rebuilt on the next forward)."""
         self.__dict__.pop("_pack_plans", None)
         self.__dict__.pop("_hop_graph", None)
+        self.__dict__.pop("_plist", None)
 
     # ----------------------------------------------------------------- streaming
     def reset_time_per_frame(self):
@@ -481,6 +484,7 @@ class CleanUMamba(nn.Module):
         total_stride = self.total_stride
         self.pending = torch.cat([self.pending, noisy_input], dim=1)
         denoised_frames = []
+        self.__dict__["_wv_call"] = None            # weights cannot change inside one call: checked on its first hop only
         while self.pending.shape[1] >= self.frame_length:
             self.frames += 1
             self._std_frames = getattr(self, "_std_frames", 0) + 1
@@ -513,8 +517,14 @@ class CleanUMamba(nn.Module):
         return "failed: " + hg["error"] if hg.get("failed") else "captured"
 
     def _weights_version(self):
-        # in-place updates of any parameter (optimizer steps, load_state_dict) bump these counters
-        return sum(p._version for p in self.parameters())
+        # in-place updates of any parameter (optimizer steps, load_state_dict) bump these counters.  The walk over the
+        # module tree costs ~60 us, a whole streaming hop of one stream ~450: the parameter list is cached (and keyed
+        # by the identity of the Parameter objects, which pruning / load_pruned_state_dict replace).
+        plist, age = self.__dict__.get("_plist", (None, 0))
+        if plist is None or age >= 64:              # re-walk now and then: foreign code may swap Parameter objects
+            plist, age = list(self.parameters()), 0
+        self.__dict__["_plist"] = (plist, age + 1)
+        return sum(p._version for p in plist)
 
     def _hop(self, frame):
         """Eager first hop (it creates the state buffers), hipGraph replay afterwards."""
@@ -528,7 +538,10 @@ class CleanUMamba(nn.Module):
         if not (getattr(self, "use_hop_graph", False) and frame.is_cuda and self.encoder_decoder_state):
             return denoise(frame)
         hg = self.__dict__.get("_hop_graph")
-        if hg is not None and not hg.get("failed") and hg.get("weights") != self._weights_version():
+        wv = self.__dict__.get("_wv_call")
+        if wv is None:
+            wv = self.__dict__["_wv_call"] = self._weights_version()
+        if hg is not None and not hg.get("failed") and hg.get("weights") != wv:
             hg = None          # the graph replays kernels on the weight copies of its capture: capture again
         if hg is None:
             hg = {"failed": False}
@@ -553,7 +566,7 @@ class CleanUMamba(nn.Module):
                     static_out = denoise(static_in, True)
                 # capture does not execute: state is untouched
                 hg.update(graph=graph, static_in=static_in, static_out=static_out, shape=tuple(frame.shape),
-                          weights=self._weights_version())
+                          weights=wv)
             except Exception as exc:                 # noqa: BLE001 - capture is an optimisation; stay eager
                 hg = {"failed": True, "error": repr(exc)}
                 warnings.warn(f"CleanUMamba: hipGraph capture of the streaming hop failed ({exc!r}); this stream "

@@ -1,7 +1,7 @@
 """bench.py -- CleanUMamba-E8 train-step throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W            (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 the process spawns its own N ranks)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1, ranks from the env)
 
 A step = one full optimisation step of the reference's hot loop (src/training/train.py:255-312):
 forward, L1 + multi-resolution STFT loss, backward (gradient all-reduce over RCCL inside it for
@@ -47,7 +47,10 @@ def parse():
                          "reference's own training mode -- torch.autocast('cuda') + GradScaler, configs/config.json:14, "
                          "src/training/train.py:158-160, 278-280; accumulation, the scan recurrence, parameters and "
                          "optimizer state are f32 in every mode")
-    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="run the step eagerly instead of replaying hipGraphs (N > 1: eager backward with per-bucket "
+                         "all-reduce overlap instead of [graph] -> one all-reduce -> [graph])")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="seconds the launcher waits for its ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-clip", type=int, default=CLIP, help="samples in the CPU-baseline clip")
@@ -144,17 +147,24 @@ def _scan_case(dev, bsz, dim, Ns, L, io, backward):
     g = torch.Generator(device=dev).manual_seed(1)
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)
     R = max(4, dim // 64)
-    xz = rn(bsz, L, 2 * dim).to(io).requires_grad_(True)
-    dl = (0.3 * rn(bsz, L, dim)).to(io).requires_grad_(True)
+    # u and z are the two halves of the in_proj output (row stride 2 * dim), B and C slices of the x_proj output, as in the
+    # model; every operand is its own autograd leaf and the backward is timed as torch.autograd.grad on a retained graph:
+    # the op's backward (kernel + deterministic finalize) and nothing of autograd's slice-backward / AccumulateGrad
+    # copies (zeros + copy + add of (B, L, 2 dim) tensors: ~1 ms at L = 2499 in f32, as much as the kernel)
+    xz = rn(bsz, L, 2 * dim).to(io)
+    u = xz[..., :dim].transpose(1, 2).requires_grad_(True)
+    z = xz[..., dim:].transpose(1, 2).requires_grad_(True)
+    dl = (0.3 * rn(bsz, L, dim)).to(io).transpose(1, 2).requires_grad_(True)
     Am = (-torch.exp(torch.log(torch.arange(1, Ns + 1, device=dev).float())[None].repeat(dim, 1))).requires_grad_(True)
-    xd = rn(bsz, L, R + 2 * Ns).requires_grad_(True)
+    xd = rn(bsz, L, R + 2 * Ns)
+    Bm = xd[..., R:R + Ns].transpose(1, 2).requires_grad_(True)
+    Cm = xd[..., R + Ns:].transpose(1, 2).requires_grad_(True)
     Dv, bv = rn(dim).requires_grad_(True), (0.3 * rn(dim)).requires_grad_(True)
     dout = rn(bsz, L, dim).to(io).transpose(1, 2)
+    leaves = (u, z, dl, Am, Bm, Cm, Dv, bv)
 
     def fwd():
-        return selective_scan_fn(xz[..., :dim].transpose(1, 2), dl.transpose(1, 2), Am, xd[..., R:R + Ns].transpose(1, 2),
-                                 xd[..., R + Ns:].transpose(1, 2), Dv, z=xz[..., dim:].transpose(1, 2), delta_bias=bv,
-                                 delta_softplus=True)
+        return selective_scan_fn(u, dl, Am, Bm, Cm, Dv, z=z, delta_bias=bv, delta_softplus=True)
 
     def fwd_nograd():
         with torch.no_grad():
@@ -162,8 +172,8 @@ def _scan_case(dev, bsz, dim, Ns, L, io, backward):
     t_i = _time(fwd_nograd)
     t_b = None
     if backward:
-        t_f = _time(fwd)
-        t_b = _time(lambda: fwd().backward(dout)) - t_f
+        out = fwd()                      # checkpoints saved once; the op's backward node alone is replayed
+        t_b = _time(lambda: torch.autograd.grad(out, leaves, dout, retain_graph=True))
     return t_i, t_b
 
 
@@ -183,8 +193,8 @@ def scan_rows(dev, dt):
              ("D=2048 N=16 L=2499 B=128, f32 I/O", 128, 2048, 16, 2499, torch.float32, False),
              ("D=2048 N=8 L=2499 B=128, f32 I/O", 128, 2048, 8, 2499, torch.float32, False),
              ("D=2048 N=8 L=2499 B=128", 128, 2048, 8, 2499, dt, False),
-             ("442K model B=16 D=128 N=16 L=624", 16, 128, 16, 624, torch.float32, False),
-             ("pruned-E8 block B=256 D=48 N=8 L=1875 (30 s)", 256, 48, 8, 1875, torch.float32, False)]
+             ("442K model B=16 D=128 N=16 L=624", 16, 128, 16, 624, torch.float32, True),
+             ("pruned-E8 block B=256 D=48 N=8 L=1875 (30 s)", 256, 48, 8, 1875, torch.float32, True)]
     rows = []
     for name, bsz, dim, Ns, L, io, bwd in cases:
         t_i, t_b = _scan_case(dev, bsz, dim, Ns, L, io, bwd)
@@ -316,8 +326,68 @@ def cpu_baseline(clip):
                       f"{dt:.1f} s wall (no optimizer step)"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no rank environment: start N FRESH rank processes (the reference starts its own
+    ranks the same way, src/training/train_distributed.py:172-178) -- before this process has made any GPU call; it
+    never touches the GPU itself and never re-execs -- wait for them with a bound, relay rank 0's JSON line, and exit
+    non-zero if any rank failed."""
+    import subprocess
+    import tempfile
+    n = args.gpus
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    outs, logs, procs = [], [], []
+    for r in range(n):
+        outs.append(tempfile.TemporaryFile(mode="w+"))
+        logs.append(tempfile.TemporaryFile(mode="w+"))
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=outs[r], stderr=logs[r]))
+    deadline = time.time() + args.rank_timeout
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:                              # one rank died: the others would sit in a collective until its timeout
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+        elif all(c == 0 for c in codes):
+            break
+        elif time.time() > deadline:
+            failed = f"ranks did not finish within {args.rank_timeout:.0f} s"
+        else:
+            time.sleep(0.2)
+
+    def text(f, tail):
+        f.seek(0)
+        return f.read()[-tail:]
+    if failed is not None:
+        for p in procs:                      # exactly the processes started above, by handle
+            if p.poll() is None:
+                p.kill()
+        for r in range(n):
+            sys.stderr.write(f"---- rank {r} ----\n{text(outs[r], 1500)}\n{text(logs[r], 3000)}\n")
+        sys.stderr.write(f"bench.py: {failed}\n")
+        sys.exit(1)
+    line = [ln for ln in text(outs[0], 1 << 30).splitlines() if ln.startswith("{")]
+    if not line:
+        sys.stderr.write(f"bench.py: rank 0 printed no JSON line\n{text(outs[0], 2000)}\n{text(logs[0], 3000)}\n")
+        sys.exit(1)
+    print(line[-1], flush=True)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -351,7 +421,7 @@ def main():
     if world > 1:
         net = apply_gradient_allreduce(net)
     ac = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": None}[args.dtype]
-    step = TrainStep(net, autocast_dtype=ac, use_graph=(world == 1 and not args.no_graph))
+    step = TrainStep(net, autocast_dtype=ac, use_graph=not args.no_graph)
 
     B = args.batch_per_gpu
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -380,16 +450,21 @@ def main():
         loss, _ = step(clean, noisy)
     skipped_before = float(step.optimizer.state_vec[9]) if step.flat else 0.0
     barrier()
+    host0 = step.host_seconds
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step(clean, noisy)
+    host_ms = 1e3 * (step.host_seconds - host0) / max(args.steps, 1)      # enqueue time only: nothing inside synchronises
     barrier()
     elapsed = time.perf_counter() - t0
+    host_ms_ranks = [host_ms]
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        t = torch.tensor([elapsed, host_ms], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        elapsed = max(float(x[0]) for x in gathered)                      # MAX over ranks
+        host_ms_ranks = [float(x[1]) for x in gathered]
     final_loss = float(loss)
     graph_status = step.graph_status
     optim_info = {"optimizer": "flat clip + Adam (csrc/optim.hip)" if step.flat else "torch.optim.Adam"}
@@ -409,7 +484,11 @@ def main():
                                       " + grad all-reduce + clip + Adam; 10 s @ 16 kHz clips",
                           "global_batch": gb, "batch_per_gpu": B, "clip_samples": CLIP,
                           "parallelism": f"dp{world}", "weights": "random init (reference init, seed 0)"},
-               "final_loss": round(final_loss, 5), "step_graph": graph_status, "optimizer": optim_info}
+               "final_loss": round(final_loss, 5), "step_graph": graph_status, "optimizer": optim_info,
+               "host_ms_per_step_by_rank": [round(h, 3) for h in host_ms_ranks],
+               "exchange": ("none" if world == 1 else
+                            "one all-reduce (AVG) of the flat 165.5 MB gradient buffer between the two captured graphs"
+                            if graph_status == "captured" else "per-bucket all-reduce overlapped with the eager backward")}
         if not args.no_roofline:
             del step, loss
             torch.cuda.empty_cache()

@@ -80,5 +80,7 @@ __device__ __forceinline__ void load_bc(const float *base, int sn, int nvalid, f
 }
 
 int scan_check_shape(const cum_scan_shape *s);
+// d_state <= 16: wave-specialised backward (scan_bwd_small.hip); the caller runs scan_bwd_finalize_kernel afterwards
+int launch_bwd_small(const ScanParams &p, hipStream_t st);
 
 }  // namespace cum

@@ -97,6 +97,13 @@ SIGNATURES = {
     "cum_cfft": (c_i32, [c_i32, c_i64, _P, _P, c_i32, _P]),
     "cum_stft_loss_fwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P]),
     "cum_stft_loss_bwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P, _P, _P]),
+    "cum_lp_loss_parts": (c_i32, [c_i64]),
+    "cum_lp_loss_fwd": (c_i32, [c_i32, _P, _P, c_i64, _P, _P, _P]),
+    "cum_lp_loss_bwd": (c_i32, [c_i32, _P, _P, c_i64, _P, _P, _P]),
+    "cum_clip_std_parts": (c_i32, [c_i64]),
+    "cum_clip_std": (c_i32, [_P, c_i32, c_i64, c_i64, ctypes.c_float, _P, _P, _P]),
+    "cum_frame_rows": (c_i32, [c_i32, _P, c_i32, c_i64, c_i64, c_i64, c_i64, _P, c_i32, _P, _P]),
+    "cum_unframe_rows": (c_i32, [c_i32, _P, c_i32, c_i64, c_i64, _P, _P, _P]),
     "cum_optim_state_elems": (c_i32, []),
     "cum_optim_sumsq_parts": (c_i32, [c_i64]),
     "cum_optim_sumsq": (c_i32, [_P, c_i64, _P, _P]),
@@ -121,7 +128,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 6:
+        if L.cum_abi_version() != 7:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -213,20 +213,42 @@ class CleanUMamba(nn.Module):
             noisy_audio = noisy_audio.unsqueeze(1)
         B, C, L = noisy_audio.shape
         assert C == 1
+        fused = getattr(self, "use_fused_convs", True) and noisy_audio.is_cuda
+        if fused and not cs.supported(self):
+            raise NotImplementedError("fused conv stack covers kernel 4 / stride 2 / ungrouped / sigmoid-GLU "
+                                      "layers; set model.use_fused_convs = False for other variants")
+        if fused and noisy_audio.dtype == torch.float32 and not noisy_audio.requires_grad and self.channels_output == 1:
+            # waveform ends on the library's own kernels (csrc/loss.hip): per-clip std, `noisy / std` + padding written
+            # straight into the first conv's row buffer, `x[:, :, :L] * std` read straight from the last one's
+            std = cs.clip_std(noisy_audio, 1e-3) if self.normalize_input else None
+            T0 = self.valid_length(L)
+            dt = self._fused_dtype()
+            buf = cs.frame_input(noisy_audio, std, T0, dt)
+            if torch.is_grad_enabled():
+                buf, geo, skip_connections, tsfm_out = self._forward_fused(buf, B, T0, dt)
+            else:
+                with cs.small_m_gemms():     # inference on short inputs: few-tile GEMMs may split K over the waves
+                    buf, geo, skip_connections, tsfm_out = self._forward_fused(buf, B, T0, dt)
+            x = cs.Unframe.apply(buf, std, geo, L)
+            if return_skip_connections:
+                skip_connections.append(tsfm_out)
+                return x, skip_connections
+            return x
         if self.normalize_input:
             std = noisy_audio.std(dim=2, keepdim=True) + 1e-3
             noisy_audio = noisy_audio / std
         x = self.pad_signal(noisy_audio)
 
-        if getattr(self, "use_fused_convs", True) and x.is_cuda:
-            if not cs.supported(self):
-                raise NotImplementedError("fused conv stack covers kernel 4 / stride 2 / ungrouped / sigmoid-GLU "
-                                          "layers; set model.use_fused_convs = False for other variants")
+        if fused:
+            dt = self._fused_dtype()
+            geo = cs.Geo(B, x.shape[-1], 1)
+            buf = cs.to_rows(x, geo, dt)
             if torch.is_grad_enabled():
-                x, skip_connections, tsfm_out = self._forward_fused(x)
+                buf, geo, skip_connections, tsfm_out = self._forward_fused(buf, B, x.shape[-1], dt)
             else:
-                with cs.small_m_gemms():     # inference on short inputs: few-tile GEMMs may split K over the waves
-                    x, skip_connections, tsfm_out = self._forward_fused(x)
+                with cs.small_m_gemms():
+                    buf, geo, skip_connections, tsfm_out = self._forward_fused(buf, B, x.shape[-1], dt)
+            x = cs.from_rows(buf, geo).float()
         else:
             skip_connections = []
             for downsampling_block in self.encoder:
@@ -246,22 +268,25 @@ class CleanUMamba(nn.Module):
             return x, skip_connections
         return x
 
-    def _forward_fused(self, x):
-        """Encoder, bottleneck and decoder on channels-last row buffers (network/convstack.py).
-        x: (B, 1, valid_length) float32.  Returns (out (B, 1, T) float32, skips deepest first, tsfm_out)."""
-        B, _, T0 = x.shape
-        E = self.encoder_n_layers
-        dt = torch.float32
+    def _fused_dtype(self):
+        """Element type of every activation and GEMM operand of the fused path: the autocast dtype -- float16 (torch's
+        default, what the reference trains with: src/training/train.py:278-280) or bfloat16 -- else float32;
+        accumulation is f32 in every mode."""
         if torch.is_autocast_enabled("cuda"):
-            # the autocast dtype is the element type of every activation and GEMM operand: float16 (torch's default,
-            # what the reference trains with: src/training/train.py:278-280) or bfloat16; accumulation is f32
             dt = torch.get_autocast_dtype("cuda")
             if dt not in hip.HALF_TYPES:
                 raise RuntimeError(f"autocast dtype {dt} is not supported by the fused conv stack")
+            return dt
+        return torch.float32
+
+    def _forward_fused(self, buf, B, T0, dt):
+        """Encoder, bottleneck and decoder on channels-last row buffers (network/convstack.py).
+        buf: row buffer of the (B, 1, T0 = valid_length) input in element type dt.  Returns (row buffer of the output,
+        its Geo, skips deepest first as (B, C, T) views, tsfm_out)."""
+        E = self.encoder_n_layers
         save = torch.is_grad_enabled()
         self._activate_pack_plan(dt)
         geo = cs.Geo(B, T0, 1)
-        buf = cs.to_rows(x, geo, dt)
         enc_geos, enc_params = [], []
         for enc in self.encoder:
             T1 = (geo.T - self.kernel_size) // self.stride + 1
@@ -317,8 +342,7 @@ class CleanUMamba(nn.Module):
                 gbuf = cs.PointwiseGLU.apply(buf, dec[0].weight, dec[0].bias, gi, gg, save)
                 buf = cs.ConvT4S2.apply(gbuf, dec[2].weight, dec[2].bias, dec_skips[j] if j < E - 1 else None, gg, go,
                                         j < E - 1)
-        out = cs.from_rows(buf, geo).float()
-        return out, [cs.from_rows(b, g) for b, g in skips], tsfm_out
+        return buf, geo, [cs.from_rows(b, g) for b, g in skips], tsfm_out
 
     def _activate_pack_plan(self, dt):
         """One batched re-pack of all conv weights for this forward (and its backward); see cs.PackPlan.  Skipped

@@ -679,6 +679,98 @@ def from_rows(buf, geo):
     return geo.rows(buf)[:, :geo.T, :geo.C].transpose(1, 2)
 
 
+def clip_std(x, eps):
+    """(B, 1, L) f32 -> (B, 1, 1): unbiased std of every clip + eps (csrc/loss.hip cum_clip_std; the reference's
+    `noisy_audio.std(dim=2, keepdim=True) + 1e-3`, src/network/CleanUMamba.py:260-262)."""
+    hip.require_gpu(x)
+    B, _, L = x.shape
+    x2 = x.reshape(B, L)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    lib = hip.lib()
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    part = torch.empty(3 * B * lib.cum_clip_std_parts(L), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        hip.check(lib.cum_clip_std(hip.ptr(x2), B, L, x2.stride(0), float(eps), hip.ptr(part), hip.ptr(out),
+                                   hip.stream_ptr()))
+    return out.view(B, 1, 1)
+
+
+def frame_input(x, std, T, dtype):
+    """(B, 1, L) f32 signal -> row buffer of Geo(B, T, 1): x / std, zero padding to T, zero rows and columns, in one
+    launch (cum_frame_rows).  Not differentiable: the caller checks that the signal needs no gradient."""
+    hip.require_gpu(x)
+    B, _, L = x.shape
+    geo = Geo(B, T, 1)
+    x2 = x.reshape(B, L)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    buf = geo.new(dtype, x.device)
+    with torch.cuda.device(x.device):
+        hip.check(hip.lib().cum_frame_rows(hip.dtype_code(dtype), hip.ptr(x2), B, L, x2.stride(0), T, geo.R,
+                                           hip.ptr(std), 1, hip.ptr(buf), hip.stream_ptr()))
+    return buf
+
+
+class Unframe(torch.autograd.Function):
+    """Row buffer of the 1-channel output -> (B, 1, L) f32, times the clip's std (`x[:, :, :L] * std`,
+    src/network/CleanUMamba.py:319).  Backward: the gradient framed back into a row buffer (times std)."""
+
+    @staticmethod
+    def forward(ctx, buf, std, geo, L):
+        y = torch.empty(geo.B, 1, L, dtype=torch.float32, device=buf.device)
+        with torch.cuda.device(buf.device):
+            hip.check(hip.lib().cum_unframe_rows(hip.dtype_code(buf.dtype), hip.ptr(buf), geo.B, L, geo.T, hip.ptr(std),
+                                                 hip.ptr(y), hip.stream_ptr()))
+        ctx.geo, ctx.dtype, ctx.std = geo, buf.dtype, std
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        geo = ctx.geo
+        dy = dy.contiguous().float()
+        B, _, L = dy.shape
+        d = geo.new(ctx.dtype, dy.device)
+        with torch.cuda.device(dy.device):
+            hip.check(hip.lib().cum_frame_rows(hip.dtype_code(ctx.dtype), hip.ptr(dy), B, L, L, geo.T, geo.R,
+                                               hip.ptr(ctx.std), 0, hip.ptr(d), hip.stream_ptr()))
+        return d, None, None, None
+
+
+class LpLoss(torch.autograd.Function):
+    """mean |y - c|^p over all elements, p in {1, 2}: F.l1_loss / F.mse_loss of loss_fn (src/util/util.py:262-268) as
+    two launches with a fixed summation order (csrc/loss.hip).  Gradient wrt y only (c is the target)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, y, c, p):
+        hip.require_gpu(y, c)
+        if y.shape != c.shape:
+            raise RuntimeError("lp loss: denoised and clean audio must have the same shape")
+        y, c = y.contiguous(), c.contiguous()
+        lib, n = hip.lib(), y.numel()
+        out = torch.empty((), dtype=torch.float32, device=y.device)
+        part = torch.empty(lib.cum_lp_loss_parts(n), dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            hip.check(lib.cum_lp_loss_fwd(p, hip.ptr(y), hip.ptr(c), n, hip.ptr(part), hip.ptr(out), hip.stream_ptr()))
+        ctx.save_for_backward(y, c)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("lp loss: no gradient wrt the target signal")
+        y, c = ctx.saved_tensors
+        dy = torch.empty_like(y)
+        g = g.float().contiguous()
+        with torch.cuda.device(y.device):
+            hip.check(hip.lib().cum_lp_loss_bwd(ctx.p, hip.ptr(y), hip.ptr(c), y.numel(), hip.ptr(g), hip.ptr(dy),
+                                                hip.stream_ptr()))
+        return dy, None, None
+
+
 def supported(model):
     """The fused path covers the shipped configuration: kernel 4, stride 2, ungrouped convs, sigmoid GLU,
     no bypass channels."""

@@ -26,6 +26,13 @@ ST_NORM, ST_MULT, ST_FOUND_INF, ST_SCALE, ST_TRACKER, ST_STEP, ST_BC1, ST_BC2_SQ
 _SINKS = {}          # parameter data_ptr -> weakref(FlatParams) that owns it
 
 
+def _forget(ptrs, ref):
+    """A FlatParams was collected: drop its entries (unless a newer FlatParams has taken the address over)."""
+    for ptr in ptrs:
+        if _SINKS.get(ptr) is ref:
+            del _SINKS[ptr]
+
+
 def sink_of(param):
     """The FlatParams whose flat buffers hold ``param`` (None if the parameter is not flat-managed)."""
     ref = _SINKS.get(param.data_ptr())
@@ -76,13 +83,31 @@ class FlatParams:
         # fresh[i]: nothing has been accumulated into gradient i since zero_grad() -- a producer may then WRITE its
         # result into the view (GradSink below) instead of handing it to autograd's AccumulateGrad (read-read-write)
         self.fresh = [False] * len(self.params)
-        for p in self.params:
-            _SINKS[p.data_ptr()] = weakref.ref(self)
+        ref = weakref.ref(self)
+        ptrs = [p.data_ptr() for p in self.params]
+        for ptr in ptrs:
+            _SINKS[ptr] = ref
+        weakref.finalize(self, _forget, ptrs, ref)
 
     def intact(self):
         """False once somebody re-pointed a parameter (``.to()``, pruning, load_pruned_state_dict ...)."""
         base = self.data.data_ptr()
         return all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def require_intact(self):
+        """The optimizer, the gradient sinks and the exchange all work on the flat buffers: once a parameter points
+        somewhere else (``net.to()`` / ``.half()``, ``load_pruned_state_dict``, pruning, ``p.data = ...``) they would
+        silently keep training an orphaned copy.  Raise instead."""
+        if not self.intact():
+            raise RuntimeError("a parameter was re-allocated after FlatParams took it over (net.to() / .half() / pruning / "
+                               "load_pruned_state_dict after the TrainStep was built): its flat view is orphaned and the "
+                               "live parameter would silently stop training; build a new TrainStep / GradBuckets")
+
+    def bump_versions(self):
+        """The kernels update the flat buffer through raw pointers, which no autograd version counter sees.  Caches
+        keyed on ``p._version`` (packed conv weights, the captured streaming hop's weight copies, -exp(A_log)) would
+        go stale: count the update on every parameter (6 us for 103 tensors)."""
+        torch._C._increment_version(self.params)
 
     def attach_grads(self):
         """Make every ``p.grad`` the bucket view again (after ``zero_grad(set_to_none=True)`` or a foreign ``.grad``)."""
@@ -154,6 +179,7 @@ class FlatAdam:
         self.nparts = lib.cum_optim_sumsq_parts(flat.numel)
         self.partials = torch.zeros(self.nparts, dtype=torch.float32, device=dev)
         self._lr_written = lr
+        self._listeners = []
 
     # ---- loss scaling (device scalars: no host sync)
     def scale_loss(self, loss):
@@ -183,6 +209,7 @@ class FlatAdam:
         if write_lr:
             self.write_lr()
         lib, f = hip.lib(), self.flat
+        f.require_intact()
         st = hip.stream_ptr()
         with torch.cuda.device(f.data.device):
             hip.check(lib.cum_optim_sumsq(hip.ptr(f.grad), f.numel, hip.ptr(self.partials), st))
@@ -192,6 +219,7 @@ class FlatAdam:
             hip.check(lib.cum_optim_adam(hip.ptr(f.data), hip.ptr(f.grad), hip.ptr(self.exp_avg),
                                          hip.ptr(self.exp_avg_sq), f.numel, hip.ptr(self.state_vec), g["betas"][0],
                                          g["betas"][1], g["eps"], g["weight_decay"], st))
+        f.bump_versions()
 
     # ---- checkpoint format of torch.optim.Adam (src/training/train.py:183-186, 367: optimizer_state_dict)
     def state_dict(self):
@@ -208,8 +236,12 @@ class FlatAdam:
         return {"state": state, "param_groups": [g], "flat_state": self.state_vec.detach().clone()}
 
     def load_state_dict(self, sd):
+        """Moments and the step count come from the checkpoint; the loss scale and its growth tracker only when both the
+        checkpoint and this optimizer use loss scaling (a bf16 / f32 run saved scale 1.0: loaded into an fp16 run it
+        would underflow the gradients for thousands of steps); the learning rate is the scheduler's to write."""
         f = self.flat
         order = {id(p): i for i, p in enumerate(reversed(f.params))}
+        step = None
         with torch.no_grad():
             for p, o in zip(f.params, f.offsets):
                 ent = sd["state"].get(order[id(p)])
@@ -218,14 +250,32 @@ class FlatAdam:
                 n = p.numel()
                 self.exp_avg[o:o + n].copy_(ent["exp_avg"].reshape(-1))
                 self.exp_avg_sq[o:o + n].copy_(ent["exp_avg_sq"].reshape(-1))
-                self.state_vec[ST_STEP] = float(ent["step"])
-            if "flat_state" in sd:
-                self.state_vec.copy_(sd["flat_state"])
+                if step is None:
+                    step = float(ent["step"])                     # one host read, not one per parameter
+            saved = sd.get("flat_state")
+            if saved is not None:
+                saved = saved.detach().float().cpu()
+                if step is None:
+                    step = float(saved[ST_STEP])
+                if self.loss_scaling and float(saved[ST_SCALE]) > 1.0:      # the checkpoint scaled its loss too
+                    self.state_vec[ST_SCALE] = float(saved[ST_SCALE])
+                    self.state_vec[ST_TRACKER] = float(saved[ST_TRACKER])
+            if step is not None:
+                self.state_vec[ST_STEP] = step
         for k in ("lr", "betas", "eps", "weight_decay"):
             if k in sd["param_groups"][0]:
                 self.param_groups[0][k] = sd["param_groups"][0][k]
-        t = float(self.state_vec[ST_STEP])
+        t = float(step or 0.0)
         b1, b2 = self.param_groups[0]["betas"]
         if t > 0:
             self.state_vec[ST_BC1] = 1.0 - b1 ** t
             self.state_vec[ST_BC2_SQRT] = (1.0 - b2 ** t) ** 0.5
+        self.hyper_changed()
+
+    # ---- a captured train step bakes host-side values in (betas, eps, weight decay, clip norm): tell whoever captured
+    def hyper_changed(self):
+        for fn in list(self._listeners):
+            fn()
+
+    def on_hyper_change(self, fn):
+        self._listeners.append(fn)

@@ -9,9 +9,14 @@ Host-side differences:
     with device-side loss scaling (training/flat_optim.py, csrc/optim.hip) instead of ~10 multi-tensor launches over
     103 tensors and GradScaler's device->host sync;
   * with static shapes the whole step (forward, loss, backward, optimizer section) is captured ONCE in a hipGraph and
-    replayed: ~430 launches per step leave the host's critical path (``use_graph``; single-process runs only -- a
-    captured collective is not something this pool can validate, so ranks > 1 run eagerly).
+    replayed: ~430 launches per step leave the host's critical path (``use_graph``).  With several ranks the step is
+    TWO graphs around the exchange -- [zero_grad, forward, loss, backward] -> one all-reduce of the whole flat gradient
+    buffer, issued eagerly between the replays -> [clip + Adam] -- so that no collective is ever captured and every
+    rank's host issues three calls per step instead of ~430 launches.  The price is that the exchange (165.5 MB at E8)
+    is not overlapped with backward; ``use_graph=False`` is the eager step with per-bucket overlap
+    (training/train_distributed.py).
 """
+import time
 import warnings
 
 import torch
@@ -36,7 +41,8 @@ class TrainStep:
       src/training/train.py:282-300).  ``__call__`` splits the batch it is given into ``repeats`` equal micro-batches;
       ``micro_step`` / ``optimizer_step`` expose the two halves for loaders that deliver micro-batches one by one.
     flat_optimizer: None = on for fp32 CUDA models.  Off: torch.optim.Adam + clip_grad_norm_ + GradScaler.
-    use_graph: None = on for single-process CUDA runs with the flat optimizer."""
+    use_graph: None = on for CUDA runs with the flat optimizer (one graph for one process; two graphs around an eager
+      whole-buffer all-reduce for several ranks, see the module docstring)."""
 
     def __init__(self, net, optimization=None, loss_config=None, autocast_dtype=None, iteration=0, repeats=1,
                  flat_optimizer=None, use_graph=None):
@@ -76,11 +82,21 @@ class TrainStep:
             self.mrstft = MultiResolutionSTFTLoss(**self.loss_cfg["stft_config"]).to(dev)
         world = self.buckets.world if self.buckets is not None else 1
         if use_graph is None:
-            use_graph = self.flat and dev.type == "cuda" and world == 1
-        if use_graph and (not self.flat or world != 1):
-            raise ValueError("use_graph needs the flat optimizer and a single process")
+            use_graph = self.flat and dev.type == "cuda"
+        if use_graph and not self.flat:
+            raise ValueError("use_graph needs the flat optimizer")
         self.use_graph = bool(use_graph)
-        self._graph = None              # {"graph", "clean", "noisy", "loss"} | {"failed": error}
+        self.world = world
+        self._graph = None              # {"graph", "optim_graph", "clean", "noisy", "loss"} | {"failed": error}
+        self._eager_steps = 0
+        self.host_seconds = 0.0         # wall time the host spent inside __call__ (enqueueing; nothing here synchronises)
+        self.calls = 0
+        if self.flat:
+            self.optimizer.on_hyper_change(self.drop_graph)
+
+    def drop_graph(self):
+        """Forget the captured step: it bakes in betas / eps / weight decay / clip norm / repeats / the loss config."""
+        self._graph = None
         self._eager_steps = 0
 
     # ------------------------------------------------------------------ pieces
@@ -128,15 +144,7 @@ class TrainStep:
         return grad_norm
 
     def _body(self, clean_audio, noisy_audio, write_lr=True):
-        self.zero_grad()
-        if self.repeats == 1:
-            loss = self.micro_step(clean_audio, noisy_audio)
-        else:
-            if clean_audio.shape[0] % self.repeats:
-                raise ValueError(f"batch of {clean_audio.shape[0]} clips does not split into {self.repeats} micro-batches")
-            parts = zip(clean_audio.chunk(self.repeats), noisy_audio.chunk(self.repeats))
-            losses = [self.micro_step(c, n, last=(i == self.repeats - 1)) for i, (c, n) in enumerate(parts)]
-            loss = torch.stack(losses).mean()
+        loss = self._micro_steps(clean_audio, noisy_audio, exchange=True)
         return loss, self.optimizer_step(write_lr=write_lr)
 
     # ------------------------------------------------------------------ hipGraph
@@ -148,14 +156,37 @@ class TrainStep:
             return "pending"
         return "failed: " + self._graph["failed"] if "failed" in self._graph else "captured"
 
+    def _micro_steps(self, clean_audio, noisy_audio, exchange):
+        """zero_grad + the ``repeats`` micro-steps, with or without the in-backward gradient exchange."""
+        self.zero_grad()
+        if self.repeats == 1:
+            if exchange:
+                return self.micro_step(clean_audio, noisy_audio)
+            return self.micro_step(clean_audio, noisy_audio, last=False)
+        if clean_audio.shape[0] % self.repeats:
+            raise ValueError(f"batch of {clean_audio.shape[0]} clips does not split into {self.repeats} micro-batches")
+        parts = zip(clean_audio.chunk(self.repeats), noisy_audio.chunk(self.repeats))
+        losses = [self.micro_step(c, n, last=(exchange and i == self.repeats - 1)) for i, (c, n) in enumerate(parts)]
+        return torch.stack(losses).mean()
+
     def _capture(self, clean_audio, noisy_audio):
         g = {"clean": clean_audio.clone(), "noisy": noisy_audio.clone()}
         try:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss, norm = self._body(g["clean"], g["noisy"], write_lr=False)
-            g.update(graph=graph, loss=loss, norm=norm)
+            if self.world == 1:
+                with torch.cuda.graph(graph):
+                    loss, norm = self._body(g["clean"], g["noisy"], write_lr=False)
+                g.update(graph=graph, loss=loss, norm=norm)
+            else:
+                # several ranks: no collective inside a capture.  Graph 1 leaves this rank's gradient in the flat buffer,
+                # the exchange runs eagerly between the replays, graph 2 is the optimizer section.
+                with torch.cuda.graph(graph):
+                    loss = self._micro_steps(g["clean"], g["noisy"], exchange=False)
+                optim_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(optim_graph, pool=graph.pool()):
+                    norm = self.optimizer_step(write_lr=False)
+                g.update(graph=graph, optim_graph=optim_graph, loss=loss, norm=norm)
         except Exception as exc:          # noqa: BLE001 - capture is an optimisation; stay eager
             g = {"failed": repr(exc)}
             warnings.warn(f"TrainStep: hipGraph capture of the train step failed ({exc!r}); steps run eagerly")
@@ -163,21 +194,28 @@ class TrainStep:
 
     def __call__(self, clean_audio, noisy_audio):
         """Returns (loss tensor on device, grad_norm tensor)."""
+        t0 = time.perf_counter()
         g = self._graph
         if self.use_graph and g is None and self._eager_steps >= GRAPH_WARMUP_STEPS:
             self._capture(clean_audio, noisy_audio)       # capture does not execute: the replay below is this step
             g = self._graph
-        if self.use_graph and g is not None and "graph" in g and g["clean"].shape == clean_audio.shape \
-                and g["clean"].dtype == clean_audio.dtype:
-            if self.buckets is not None and not self.buckets.flat.intact():
-                raise RuntimeError("parameters were re-allocated after the train step was captured; build a new TrainStep")
+        if self.use_graph and g is not None and "graph" in g \
+                and (g["clean"].shape, g["clean"].dtype) == (clean_audio.shape, clean_audio.dtype) \
+                and (g["noisy"].shape, g["noisy"].dtype) == (noisy_audio.shape, noisy_audio.dtype):
+            self.buckets.flat.require_intact()
             g["clean"].copy_(clean_audio)
             g["noisy"].copy_(noisy_audio)
             self.optimizer.write_lr()
             g["graph"].replay()
+            if "optim_graph" in g:
+                self.buckets.exchange_all()
+                g["optim_graph"].replay()
+            self.buckets.flat.bump_versions()             # the replay moved the parameters behind autograd's back
             loss, grad_norm = g["loss"].clone(), g["norm"].clone()
         else:
             loss, grad_norm = self._body(clean_audio, noisy_audio)
             self._eager_steps += 1
         self.scheduler.step()
+        self.host_seconds += time.perf_counter() - t0
+        self.calls += 1
         return loss, grad_norm

@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 6
+#define CUM_ABI_VERSION 7
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -345,6 +345,35 @@ int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows, int32_t C
 int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t Cp, int32_t C, const void *y,
                            int64_t y_pitch, void *tail, const float *bias, const void *skip, int64_t skip_pitch,
                            void *out, int64_t out_pitch, int32_t relu, void *stream);
+
+/* ---- waveform ends of the train step (csrc/loss.hip).  All sums are per-workgroup partials in fixed order + one
+ * finishing workgroup: deterministic, graph-capturable, nothing returns to the host.
+ *
+ * cum_lp_loss_fwd / _bwd: the time-domain term of loss_fn, F.l1_loss (p = 1) / F.mse_loss (p = 2) of (denoised, clean)
+ * with reduction "mean" (src/util/util.py:262-268).  y, c, dy: n contiguous f32; partials: cum_lp_loss_parts(n) f32;
+ * out: 1 f32; gout: 1 f32 in device memory (the incoming gradient of the scalar).  dy = gout * sign(y - c) / n (p = 1;
+ * 0 where y == c, as torch) or gout * 2 (y - c) / n (p = 2). */
+int32_t cum_lp_loss_parts(int64_t n);
+int cum_lp_loss_fwd(int32_t p, const float *y, const float *c, int64_t n, float *partials, float *out, void *stream);
+int cum_lp_loss_bwd(int32_t p, const float *y, const float *c, int64_t n, const float *gout, float *dy, void *stream);
+
+/* cum_clip_std: out[r] = unbiased std of row r of x (rows x len f32, row stride `stride` elements) + eps -- the per-clip
+ * input normalisation `noisy_audio.std(dim=2, keepdim=True) + 1e-3` (src/network/CleanUMamba.py:260-262).  One pass
+ * (Welford per thread, Chan merges in fixed order).  partials: 3 * rows * cum_clip_std_parts(len) f32. */
+int32_t cum_clip_std_parts(int64_t len);
+int cum_clip_std(const float *x, int32_t rows, int64_t len, int64_t stride, float eps, float *partials, float *out,
+                 void *stream);
+
+/* cum_frame_rows: (batch, len) f32 signal -> the channels-last row buffer of a ONE-channel activation (8 columns per
+ * row: column 0 the sample, 1-7 zero; row 0 zero; per clip T rows + 2 zero rows; total_rows rows written in all):
+ * out = x / scale[b] (invert = 1: `noisy / std` + pad_signal, src/network/CleanUMamba.py:262-264) or x * scale[b]
+ * (invert = 0: the backward of cum_unframe_rows); steps len .. T-1 are zero; scale may be NULL (= 1).
+ * cum_unframe_rows: y[b][t] = rows[1 + b (T + 2) + t][0] * scale[b], t < len: `x[:, :, :L] * std`
+ * (src/network/CleanUMamba.py:319) read straight from the last transposed conv's row buffer. */
+int cum_frame_rows(int32_t dtype, const float *x, int32_t batch, int64_t len, int64_t stride, int64_t T,
+                   int64_t total_rows, const float *scale, int32_t invert, void *out, void *stream);
+int cum_unframe_rows(int32_t dtype, const void *rows, int32_t batch, int64_t len, int64_t T, const float *scale,
+                     float *y, void *stream);
 
 /* ---- optimizer section of the train step on flat buffers (src/training/train.py:303-310: scaler.unscale_,
  * clip_grad_norm_(clip_grad_norm_max), scaler.step(Adam), scaler.update; Adam built at :145-148 with betas / eps /

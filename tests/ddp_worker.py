@@ -6,7 +6,10 @@ Runs the reference's sequence -- init_distributed, apply_gradient_allreduce, Tra
 123-124, 255-312) -- on a real CleanUMamba and writes what the parent compares:
   grads after the first backward (before the optimizer touches anything), parameters after `steps` steps.
 
-usage: ddp_worker.py RANK WORLD PORT OUTDIR MODEL(442k|narrow_e8) DTYPE(f32|f16|bf16) STFT(0|1) STEPS
+usage: ddp_worker.py RANK WORLD PORT OUTDIR MODEL(442k|narrow_e8|e8) DTYPE(f32|f16|bf16) STFT(0|1) STEPS [graph]
+
+  e8     the real 41.4 M-parameter E8 of bench.py, one 1 s clip per rank, the DEFAULT 32 MiB buckets
+  graph  TrainStep(use_graph=True): with two ranks that is [captured fwd+loss+bwd] -> all-reduce -> [captured optimizer]
 """
 import json
 import os
@@ -20,6 +23,8 @@ sys.path.insert(0, ROOT)
 
 NARROW_E8 = dict(channels_input=1, channels_output=1, channels_H=16, max_H=48, encoder_n_layers=8, kernel_size=4,
                  stride=2, tsfm_n_layers=3, tsfm_n_head=8, tsfm_d_model=64, tsfm_d_inner=256)   # E8 shape, d_state 8
+E8 = dict(channels_input=1, channels_output=1, channels_H=64, max_H=768, encoder_n_layers=8, kernel_size=4,
+          stride=2, tsfm_n_layers=3, tsfm_n_head=8, tsfm_d_model=512, tsfm_d_inner=2048)        # bench.py's model
 
 
 def build(model, dev):
@@ -31,7 +36,7 @@ def build(model, dev):
         net = CleanUMamba(**cfg)
         net.load_state_dict(sd, strict=True)
     else:
-        net = CleanUMamba(**NARROW_E8)
+        net = CleanUMamba(**(E8 if model == "e8" else NARROW_E8))
     return net.to(dev).train()
 
 
@@ -44,6 +49,8 @@ def batch(rank, n, length, dev):
 def main():
     rank, world, port, out, model, dtype, stft, steps = sys.argv[1:9]
     rank, world, steps = int(rank), int(world), int(steps)
+    use_graph = len(sys.argv) > 9 and sys.argv[9] == "graph"
+    length, per_rank = (16000, 1) if model == "e8" else (8000, 2)
     from cleanumamba_amd.training.train_distributed import apply_gradient_allreduce, init_distributed
     from cleanumamba_amd.training.train_step import TrainStep
     dev = torch.device("cuda:0")
@@ -52,17 +59,21 @@ def main():
         init_distributed(rank, world, None, "gloo", f"tcp://127.0.0.1:{port}")
     torch.manual_seed(1000 + rank)                  # ranks initialise differently: the broadcast must fix it
     net = build(model, dev)
+    n_buckets = 0
     if world > 1:
-        net = apply_gradient_allreduce(net, bucket_bytes=256 << 10)       # several buckets even on small models
-        assert len(net.grad_buckets.buckets) >= 2
+        if model == "e8":
+            net = apply_gradient_allreduce(net)                           # the bench's configuration: 32 MiB buckets
+        else:
+            net = apply_gradient_allreduce(net, bucket_bytes=256 << 10)   # several buckets even on small models
+        n_buckets = len(net.grad_buckets.buckets)
+        assert n_buckets >= 2
     ac = {"f32": None, "f16": torch.float16, "bf16": torch.bfloat16}[dtype]
     step = TrainStep(net, optimization={"n_iters": 1000}, loss_config={"stft_lambda": int(stft)},
-                     autocast_dtype=ac, use_graph=False)
-    per_rank = 2
+                     autocast_dtype=ac, use_graph=use_graph)
     if world > 1:
-        clean, noisy = batch(rank, per_rank, 8000, dev)
+        clean, noisy = batch(rank, per_rank, length, dev)
     else:                                            # the single-process run sees the concatenated batch
-        parts = [batch(r, per_rank, 8000, dev) for r in range(int(os.environ.get("CUM_TEST_RANKS", "2")))]
+        parts = [batch(r, per_rank, length, dev) for r in range(int(os.environ.get("CUM_TEST_RANKS", "2")))]
         clean, noisy = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     # first backward by hand (so the gradients can be dumped before the optimizer runs) ...
     step.zero_grad()
@@ -85,7 +96,8 @@ def main():
     torch.cuda.synchronize()
     params = {k: p.detach().float().cpu() for k, p in net.named_parameters()}
     torch.save({"grads": grads, "params": params, "losses": losses,
-                "skipped": float(step.optimizer.state_vec[9]), "announced": announced},
+                "skipped": float(step.optimizer.state_vec[9]), "announced": announced, "buckets": n_buckets,
+                "graph_status": step.graph_status, "numel": sum(p.numel() for p in net.parameters())},
                os.path.join(out, f"rank{rank}_of{world}.pt"))
     if world > 1:
         import torch.distributed as dist

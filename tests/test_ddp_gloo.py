@@ -49,6 +49,19 @@ def _worker(rank, world, port, out):
             idx, view = net.grad_buckets.where[id(p)]
             assert p.grad.data_ptr() == view.data_ptr(), "grad is not a view of its bucket"
         assert torch.all(unused.weight.grad == 0)
+    # the captured-step form of the exchange: backward WITHOUT the in-backward collectives (require_sync = False, what
+    # graph 1 of TrainStep records), then one all-reduce of the whole flat gradient buffer -> the same averaged gradients
+    want = net.grad_buckets.flat.grad.clone()
+    net.grad_buckets.zero_grad()
+    net.grad_buckets.require_sync = False
+    y = net[4](net[3](net[2](net[1](net[0](x)))))
+    y.square().mean().backward()
+    assert not net.grad_buckets.handles and not net.grad_buckets._armed
+    local_only = net.grad_buckets.flat.grad.clone()
+    net.grad_buckets.exchange_all()
+    net.grad_buckets.require_sync = True
+    assert torch.allclose(net.grad_buckets.flat.grad, want, rtol=1e-6, atol=1e-7)
+    assert not torch.allclose(local_only, want, rtol=1e-3, atol=1e-5), "ranks saw different data: local != averaged"
     loss = torch.tensor([float(rank + 1)])
     assert reduce_tensor(loss, world).item() == 1.5
     out.put((rank, "ok"))

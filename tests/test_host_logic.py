@@ -143,3 +143,67 @@ def test_graft_entry_build_is_consistent_with_the_header():
     g.build()
     from cleanumamba_amd import hip
     assert set(hip.SIGNATURES) and hip.lib().cum_abi_version() >= 3
+
+
+def test_bench_launcher_starts_ranks_and_fails_fast_without_a_gpu():
+    """`python bench.py --gpus 2` with no rank environment must start its own two rank processes and relay a failure:
+    here (no GPU) every rank stops at "bench.py needs a GPU", and the launcher must exit non-zero promptly, naming a
+    rank, instead of asserting on WORLD_SIZE as it did before or hanging in a rendezvous."""
+    import os
+    import subprocess
+    import sys
+    import time
+    if torch.cuda.is_available():
+        pytest.skip("the failing-rank path needs a box without a GPU (tests/test_train_gpu.py covers the working one)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--rank-timeout", "120"], env=env, capture_output=True, text=True, timeout=150)
+    assert res.returncode == 1
+    assert "exited with code" in res.stderr and "bench.py needs a GPU" in res.stderr, res.stderr[-1500:]
+    assert "---- rank 1 ----" in res.stderr
+    assert time.time() - t0 < 100
+
+
+def test_flat_adam_checkpoint_rules_and_sink_registry():
+    """FlatAdam.load_state_dict: a checkpoint written by a run WITHOUT loss scaling must not overwrite the live loss
+    scale of an fp16 run (scale 1.0 would underflow the gradients for thousands of steps), one written with scaling
+    restores it; the step count is restored; listeners (a captured train step) hear about the change.  FlatParams leaves
+    no entry in the gradient-sink registry once it is collected."""
+    import gc
+    from cleanumamba_amd.training import flat_optim as fo
+    torch.manual_seed(0)
+    mk = lambda: nn.Sequential(nn.Linear(5, 7), nn.Linear(7, 3))
+    a = mk()
+    opt_plain = fo.FlatAdam(fo.FlatParams(a), lr=1e-3, loss_scaling=False)
+    opt_plain.state_vec[fo.ST_STEP] = 41.0
+    opt_plain.exp_avg.fill_(0.25)
+    sd_plain = opt_plain.state_dict()
+    b = mk()
+    flat_b = fo.FlatParams(b)
+    opt16 = fo.FlatAdam(flat_b, lr=1e-3, loss_scaling=True)
+    heard = []
+    opt16.on_hyper_change(lambda: heard.append(1))
+    sd_plain["param_groups"][0]["betas"] = (0.8, 0.99)
+    opt16.load_state_dict(sd_plain)
+    assert float(opt16.state_vec[fo.ST_SCALE]) == 65536.0          # kept: the checkpoint did not scale its loss
+    assert float(opt16.state_vec[fo.ST_STEP]) == 41.0 and float(opt16.exp_avg[0]) == 0.25
+    assert opt16.param_groups[0]["betas"] == (0.8, 0.99) and heard == [1]
+    opt16.state_vec[fo.ST_SCALE] = 8192.0
+    opt16.state_vec[fo.ST_TRACKER] = 17.0
+    c = mk()
+    opt16c = fo.FlatAdam(fo.FlatParams(c), lr=1e-3, loss_scaling=True)
+    opt16c.load_state_dict(opt16.state_dict())
+    assert float(opt16c.state_vec[fo.ST_SCALE]) == 8192.0 and float(opt16c.state_vec[fo.ST_TRACKER]) == 17.0
+    # re-pointed parameters are refused by name
+    flat_b.require_intact()
+    b[0].weight.data = b[0].weight.data.clone()
+    with pytest.raises(RuntimeError, match="re-allocated"):
+        flat_b.require_intact()
+    # the registry forgets collected FlatParams
+    ptrs = [p.data_ptr() for p in c.parameters()]
+    assert all(ptr in fo._SINKS for ptr in ptrs)
+    del opt16c, c
+    gc.collect()
+    assert not any(ptr in fo._SINKS for ptr in ptrs)

@@ -1,4 +1,5 @@
-"""Small C-ABI entry points against their torch equivalents (GPU): operand gather, hipFFT wrappers."""
+"""Small C-ABI entry points against their torch equivalents (GPU): operand gather, hipFFT wrappers, the waveform-end
+kernels of csrc/loss.hip (time-domain loss term, per-clip std, input / output framing)."""
 import pytest
 import torch
 
@@ -107,3 +108,67 @@ def test_small_linear_matches_torch(cuda, rows, cols):
                                              hip.stream_ptr()))
     ref = x.double() @ W.double().t() + b.double()
     assert rel_l2(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize("p", [1, 2])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 1, 4099), (16, 1, 160000)])
+def test_lp_loss_matches_torch_and_replays_in_a_graph(cuda, p, shape):
+    """cum_lp_loss_fwd / _bwd (F.l1_loss / F.mse_loss of src/util/util.py:262-268) against torch in f64, and the value
+    a captured graph returns on NEW data against the eager value -- the ATen reduction it replaces returned a stale sum
+    from the second replay of the train-step graph on (tools/debug_graph_e8.py)."""
+    import torch.nn.functional as F
+    from cleanumamba_amd.network.convstack import LpLoss
+    g = torch.Generator().manual_seed(sum(shape) + p)
+    y = torch.randn(*shape, generator=g).to(cuda).requires_grad_(True)
+    c = torch.randn(*shape, generator=g).to(cuda)
+    if y.numel() > 10:
+        with torch.no_grad():
+            y[0, 0, 3] = c[0, 0, 3]                               # an exact tie: gradient 0, as torch.sgn
+    loss = LpLoss.apply(y, c, p)
+    (loss * 3.0).backward()
+    yd = y.detach().double().requires_grad_(True)
+    want = (F.l1_loss if p == 1 else F.mse_loss)(yd, c.double())
+    (want * 3.0).backward()
+    assert abs(float(loss) - float(want)) < 2e-6 * abs(float(want)) + 1e-12
+    assert rel_l2(y.grad, yd.grad) < 1e-6
+    two = LpLoss.apply(y.detach(), c, p)
+    assert torch.equal(two, loss.detach())                         # fixed summation order: bit-reproducible
+    ys, cs_ = y.detach().clone(), c.clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = LpLoss.apply(ys, cs_, p)
+    for it in range(3):
+        ys.copy_(torch.randn(*shape, generator=g).to(cuda))
+        cs_.copy_(torch.randn(*shape, generator=g).to(cuda))
+        graph.replay()
+        assert torch.equal(out, LpLoss.apply(ys, cs_, p)), it
+
+
+@pytest.mark.parametrize("shape", [(1, 2), (3, 777), (16, 160000), (2, 480000)])
+def test_clip_std_and_framing(cuda, shape):
+    """cum_clip_std against torch.std (f64) -- `noisy_audio.std(dim=2, keepdim=True) + 1e-3`, src/network/CleanUMamba.py:
+    260-262 -- on signals with a large offset (one-pass Welford must not cancel); cum_frame_rows / cum_unframe_rows
+    against the torch construction of the row buffer."""
+    from cleanumamba_amd.network import convstack as cs
+    B, L = shape
+    g = torch.Generator().manual_seed(L)
+    x = (0.05 * torch.randn(B, 1, L, generator=g) + torch.linspace(-3, 3, B).view(B, 1, 1)).to(cuda)
+    std = cs.clip_std(x, 1e-3)
+    want = x.double().std(dim=2, keepdim=True) + 1e-3
+    assert std.shape == (B, 1, 1) and rel_l2(std, want) < 2e-6
+    assert torch.equal(std, cs.clip_std(x, 1e-3))
+    T = L + 5
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        geo = cs.Geo(B, T, 1)
+        buf = cs.frame_input(x, std, T, dt)
+        ref = cs.to_rows(torch.nn.functional.pad(x / std, (0, T - L)), geo, dt)
+        assert buf.shape == ref.shape and torch.equal(buf, ref)
+        y = cs.Unframe.apply(buf.clone().requires_grad_(True), std, geo, L)
+        assert torch.equal(y, cs.from_rows(ref, geo).float()[:, :, :L] * std)
+        leaf = buf.clone().float().requires_grad_(True)
+        dy = torch.randn(B, 1, L, generator=g).to(cuda)
+        (cs.Unframe.apply(leaf.to(dt), std, geo, L) * dy).sum().backward()
+        wleaf = ref.clone().float().requires_grad_(True)
+        ((cs.from_rows(wleaf.to(dt), geo).float()[:, :, :L] * std) * dy).sum().backward()
+        assert rel_l2(leaf.grad, wleaf.grad) < (1e-6 if dt == torch.float32 else 4e-3)

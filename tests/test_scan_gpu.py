@@ -41,7 +41,11 @@ def test_scan_fwd_bwd_vs_golden(cuda, idx, layout):
             assert rel_l2(ins[k].grad, g[f"d{k}64"]) < BWD_TOL, k
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (3, 70, 20, 47), (2, 130, 64, 16), (1, 64, 37, 17), (2, 9, 5, 100)])
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (3, 70, 20, 47), (2, 130, 64, 16), (1, 64, 37, 17), (2, 9, 5, 100),
+                                   # d_state <= 16: the wave-specialised backward (csrc/scan_bwd_small.hip) -- the d_state
+                                   # values of the shipped checkpoints (8, 12, 13, 14, 16), lengths around the 8-step half
+                                   (2, 130, 16, 41), (2, 70, 12, 23), (1, 200, 14, 8), (3, 64, 9, 7), (2, 136, 13, 64),
+                                   (1, 8, 8, 129), (2, 48, 8, 9)])
 def test_scan_odd_shapes_vs_oracle(cuda, shape):
     """ragged sizes: channels not a multiple of 64, d_state not a multiple of 8, L not a multiple of 16."""
     from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
@@ -62,6 +66,35 @@ def test_scan_odd_shapes_vs_oracle(cuda, shape):
     assert rel_l2(y, yr) < FWD_TOL
     (y * dout.to(cuda)).sum().backward()
     for k in cpu:
+        assert rel_l2(dev[k].grad, ref[k].grad) < BWD_TOL, k
+
+
+@pytest.mark.parametrize("N", [8, 16])
+@pytest.mark.parametrize("opts", ["plain", "no_z", "no_softplus_no_bias", "no_D"])
+def test_scan_small_state_optional_arguments(cuda, N, opts):
+    """d_state <= 16 backward (producer / consumer waves): the optional operands of selective_scan_fn -- no gate, no
+    softplus, no bias, no skip term -- against the f64 oracle."""
+    from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    bsz, dim, L = 2, 96, 37
+    gen = torch.Generator().manual_seed(N + len(opts))
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    cpu = dict(u=rn(bsz, L, dim).transpose(1, 2), delta=(0.5 * rn(bsz, L, dim)).abs().transpose(1, 2),
+               A=-torch.exp(0.5 * rn(dim, N)), B=rn(bsz, L, N).transpose(1, 2), C=rn(bsz, L, N).transpose(1, 2),
+               D=rn(dim), z=rn(bsz, L, dim).transpose(1, 2), delta_bias=0.5 * rn(dim))
+    drop = {"plain": (), "no_z": ("z",), "no_softplus_no_bias": ("delta_bias",), "no_D": ("D",)}[opts]
+    softplus = opts != "no_softplus_no_bias"
+    dout = rn(bsz, L, dim).transpose(1, 2)
+
+    def run(t, fn):
+        kw = dict(z=t.get("z"), delta_bias=t.get("delta_bias"), delta_softplus=softplus)
+        y = fn(t["u"], t["delta"], t["A"], t["B"], t["C"], t.get("D"), **kw)
+        (y * dout.to(y.device).to(y.dtype)).sum().backward()
+        return y
+    ref = {k: v.double().detach().requires_grad_(True) for k, v in cpu.items() if k not in drop}
+    dev = {k: v.to(cuda).requires_grad_(True) for k, v in cpu.items() if k not in drop}
+    yr, y = run(ref, M.selective_scan_ref), run(dev, selective_scan_fn)
+    assert rel_l2(y, yr) < FWD_TOL
+    for k in ref:
         assert rel_l2(dev[k].grad, ref[k].grad) < BWD_TOL, k
 
 

@@ -100,7 +100,10 @@ def test_autocast_gradients_vs_reference(cuda, name, dtype):
     record(f"autocast_grad_all[{name}-{dtype}].rel", rel_l2(grads["lo"], grads["f32"]))
     cos = torch.nn.functional.cosine_similarity(grads["lo"].double(), grads["f32"].double(), dim=0).item()
     record(f"autocast_grad_all[{name}-{dtype}].cos", cos)     # measured 0.75 / 0.95 (E8), 0.26 / 0.74 (E6) for bf16 / f16
-    assert cos > 0.1
+    # NOT a parity check: on random weights the ReLU gates that flip under 16-bit rounding decorrelate an end-to-end
+    # gradient whichever implementation computes it.  What is asserted for the full gradient is only that it is finite
+    # (above) and not degenerate; the parity statements of this test are the two `*_last` bounds.
+    assert float(grads["lo"].abs().max()) > 0
 
 
 def test_train_step_fp16_autocast_e8(cuda):
@@ -125,6 +128,92 @@ def test_train_step_fp16_autocast_e8(cuda):
     assert float(st[3]) == 65536.0 * 0.5 ** float(st[9])        # the scale halves once per skipped step
     assert not torch.equal(before, net.encoder[3][0].weight.detach())
     assert losses[-1] < losses[0]
+
+
+def test_benched_configuration_graph_replay_equals_eager(cuda):
+    """The configuration bench.py times -- E8, fp16 autocast with device-side loss scaling, the whole step replayed from a
+    hipGraph, 10 s clips -- at B = 2: eight steps against the same steps run eagerly, including the loss-scale back-off of
+    the first steps and one step whose batch holds a NaN (both must skip it, halve the scale and carry on)."""
+    from cleanumamba_amd.network import Net
+    from cleanumamba_amd.training.train_step import TrainStep
+    nets, steps = [], []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        nets.append(Net("CleanUMamba", E8).to(cuda).train())
+        steps.append(TrainStep(nets[-1], autocast_dtype=torch.float16, use_graph=graph))
+    losses, skipped = [[], []], [[], []]
+    for it in range(8):
+        clean, noisy = synth.waveform(2, 160000, seed=40 + it)
+        if it == 5:
+            noisy[1, 0, 777] = float("nan")                     # a replayed step (captured at it == 3)
+        for k in range(2):
+            loss, gn = steps[k](clean.to(cuda), noisy.to(cuda))
+            losses[k].append(float(loss))
+            skipped[k].append(float(steps[k].optimizer.state_vec[9]))
+    assert steps[0].graph_status == "captured", steps[0].graph_status
+    assert skipped[0] == skipped[1], skipped
+    assert skipped[0][5] == skipped[0][4] + 1 and skipped[0][7] == skipped[0][5], "the NaN step, and only it, is skipped late"
+    assert float(steps[0].optimizer.state_vec[5]) >= 3          # real optimizer steps were taken
+    assert float(steps[0].optimizer.state_vec[3]) == float(steps[1].optimizer.state_vec[3])     # same loss scale
+    worst = max(rel_l2(pa, pb) for pa, pb in zip(nets[0].parameters(), nets[1].parameters()))
+    assert record("graph_vs_eager_e8_f16", worst) < 1e-5
+    fin = [i for i in range(8) if i != 5]
+    assert all(losses[0][i] == losses[0][i] for i in fin)
+    assert max(abs(losses[0][i] - losses[1][i]) for i in fin) < 1e-4 * max(abs(l) for l in (losses[1][i] for i in fin))
+
+
+@pytest.mark.parametrize("dtype", [None, torch.float16])
+def test_trained_weights_reach_every_inference_cache(cuda, dtype):
+    """FlatAdam (eager and replayed) moves the parameters through raw pointers; every no-grad cache keyed on a
+    parameter's version counter -- packed conv weights, -exp(A_log), the captured streaming hop's weight copies -- must
+    notice.  Validation inside the training loop is a reference flow (src/training/train.py:339): after training steps
+    `net.eval()` must equal a fresh model loaded from `state_dict()`, full forward and streaming, f32 and autocast."""
+    from cleanumamba_amd.network import CleanUMamba
+    from cleanumamba_amd.training.train_step import TrainStep
+    sd, cfg = load_ckpt("442k")
+    net = CleanUMamba(**cfg)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(cuda).train()
+    step = TrainStep(net, optimization={"n_iters": 100, "learning_rate": 1e-3}, autocast_dtype=dtype, use_graph=True)
+    _, x = synth.waveform(1, 4000, seed=77)
+    x = x.to(cuda)
+
+    def evaluate(model):
+        model.eval()
+        with torch.no_grad():
+            y32 = model(x)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y16 = model(x)
+            ys = torch.cat([model.feed(x[0]), model.flush()], dim=-1)
+        model.train()
+        return y32, y16, ys
+    evaluate(net)                                         # fill every cache with the UNTRAINED weights
+    seen = [p.detach().clone() for p in net.parameters()]
+    for it in range(7):                                   # 3 eager steps, then replays
+        clean, noisy = synth.waveform(2, 8000, seed=60 + it)
+        step(clean.to(cuda), noisy.to(cuda))
+        if it in (1, 6):                                  # after an eager step and after a replayed one
+            assert any(not torch.equal(a, p.detach()) for a, p in zip(seen, net.parameters()))
+            fresh = CleanUMamba(**cfg)
+            fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, strict=True)
+            fresh = fresh.to(cuda)
+            for tag, a, b in zip(("f32", "bf16", "stream"), evaluate(net), evaluate(fresh)):
+                assert rel_l2(a, b) < 1e-6, (it, tag, rel_l2(a, b))
+    assert step.graph_status == "captured"
+
+
+def test_flat_optimizer_refuses_orphaned_parameters(cuda):
+    """Re-pointing a parameter after the TrainStep exists (net.half(), pruning, load_pruned_state_dict ...) orphans its
+    flat view: the eager optimizer step must raise instead of training a dead copy (the replay path always did)."""
+    from cleanumamba_amd.training.train_step import TrainStep
+    net = _net442(cuda)
+    step = TrainStep(net, optimization={"n_iters": 100}, use_graph=False)
+    clean, noisy = synth.waveform(2, 8000, seed=5)
+    step(clean.to(cuda), noisy.to(cuda))
+    p = net.encoder[0][0].weight
+    p.data = p.data.clone()
+    with pytest.raises(RuntimeError, match="re-allocated"):
+        step(clean.to(cuda), noisy.to(cuda))
 
 
 def test_flat_adam_matches_torch_adam_clip_and_scaler(cuda):
@@ -264,13 +353,13 @@ def _free_port():
     return port
 
 
-def _run_ranks(tmp, world, model, dtype, stft, steps):
+def _run_ranks(tmp, world, model, dtype, stft, steps, graph=False):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUM_TEST_RANKS="2")
     logs = [open(os.path.join(tmp, f"log_{world}_{dtype}_{r}.txt"), "w+") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), str(world), str(port),
-                               str(tmp), model, dtype, str(stft), str(steps)], env=env, stdout=logs[r],
-                              stderr=subprocess.STDOUT) for r in range(world)]
+                               str(tmp), model, dtype, str(stft), str(steps)] + (["graph"] if graph else []), env=env,
+                              stdout=logs[r], stderr=subprocess.STDOUT) for r in range(world)]
 
     def tails():
         out = []
@@ -321,3 +410,78 @@ def test_two_ranks_real_model(cuda, tmp_path, model):
     # the encoder stack hands its three deepest layers (12 parameters) to the exchange before the outer layers are done
     if model == "narrow_e8":
         assert 12 in two[0]["announced"] and 20 in two[0]["announced"], two[0]["announced"]
+
+
+def _e8_bucket_plan():
+    """Bucket count and sizes FlatParams cuts the real E8 into at the default 32 MiB, computed on the CPU."""
+    from cleanumamba_amd.network import CleanUMamba
+    from cleanumamba_amd.training.flat_optim import FlatParams
+    flat = FlatParams(CleanUMamba(**E8))
+    return flat.numel, flat.slices(32 << 20)
+
+
+def test_two_ranks_real_e8_default_buckets(cuda, tmp_path):
+    """The configuration `bench.py --gpus N` runs, on two ranks: the real 41.4 M-parameter E8 with the DEFAULT 32 MiB
+    buckets (one 1 s clip per rank; fresh child processes sharing the GPU, gradients over gloo).  f32: every parameter's
+    averaged gradient equals the single-process gradient on the concatenated batch, ranks bit-identical after optimizer
+    steps, bucket count and the encoder's early-announce groups as designed.  f16 + the full loss: ranks stay in step."""
+    torch.cuda.empty_cache()
+    numel, plan = _e8_bucket_plan()
+    assert numel >= 41_376_385 and len(plan) >= 5
+    assert all((e - s) * 4 <= (32 << 20) or len(m) == 1 for s, e, m in plan)
+    two = _run_ranks(tmp_path, 2, "e8", "f32", 0, 2)
+    one = _run_ranks(tmp_path, 1, "e8", "f32", 0, 2)[0]
+    assert two[0]["numel"] == 41_376_385 and two[0]["buckets"] == two[1]["buckets"] == len(plan)
+    worst = 0.0
+    for k, g1 in one["grads"].items():
+        for r in range(2):
+            denom = g1.double().norm().item()
+            err = (two[r]["grads"][k].double() - g1.double()).norm().item() / max(denom, 1e-20)
+            worst = max(worst, err)
+            assert err < 1e-4 or denom < 1e-12, (k, r, err)
+    record("ddp_grad_vs_single[e8]", worst)
+    for k in one["params"]:
+        assert torch.equal(two[0]["params"][k], two[1]["params"][k]), f"ranks diverged on {k}"
+    # the three deepest encoder layers (12 parameters) go to the exchange before the five outer ones (20) are done
+    assert 12 in two[0]["announced"] and 20 in two[0]["announced"], two[0]["announced"]
+    lo = _run_ranks(tmp_path, 2, "e8", "f16", 1, 4)
+    for k in lo[0]["params"]:
+        assert torch.equal(lo[0]["params"][k], lo[1]["params"][k]), f"fp16 ranks diverged on {k}"
+    assert lo[0]["skipped"] == lo[1]["skipped"]
+    assert all(l == l for l in lo[0]["losses"][-1:] + lo[1]["losses"][-1:])
+
+
+def test_two_ranks_captured_step_equals_eager(cuda, tmp_path):
+    """Several ranks with use_graph: [captured zero_grad + forward + loss + backward] -> ONE all-reduce of the flat
+    gradient buffer -> [captured clip + Adam].  Seven steps (three eager, four replayed) on two ranks against the same
+    steps with the eager per-bucket exchange: same parameters, ranks bit-identical, the graphs were really captured."""
+    torch.cuda.empty_cache()
+    (tmp_path / "g").mkdir()
+    (tmp_path / "e").mkdir()
+    graph = _run_ranks(tmp_path / "g", 2, "442k", "f32", 1, 7, graph=True)
+    eager = _run_ranks(tmp_path / "e", 2, "442k", "f32", 1, 7)
+    assert graph[0]["graph_status"] == graph[1]["graph_status"] == "captured"
+    assert eager[0]["graph_status"] == "off"
+    for k in graph[0]["params"]:
+        assert torch.equal(graph[0]["params"][k], graph[1]["params"][k]), f"ranks diverged on {k}"
+        assert rel_l2(graph[0]["params"][k], eager[0]["params"][k]) < 1e-5, k
+    assert max(abs(a - b) for a, b in zip(graph[0]["losses"], eager[0]["losses"])) < 1e-5 * max(eager[0]["losses"])
+
+
+def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path):
+    """`python bench.py --gpus 2 ...` with no rank environment must start its own two ranks (fresh processes, here both on
+    the one GPU with gradients over gloo), and print ONE JSON line for n_gpus = 2 -- the shape of the driver's command."""
+    import json
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(CUM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline",
+           "--batch-per-gpu", "2", "--rank-timeout", "600"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=700)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 4
+    assert out["value"] > 0 and out["scaling"] == "weak" and len(out["host_ms_per_step_by_rank"]) == 2
+    assert out["step_graph"] == "captured", out["step_graph"]

@@ -303,6 +303,73 @@ def _layer_row(name, ms, byt, fl):
             "mfma_frac": round(mf, 4), "bound": "hbm" if byt / (HBM_PEAK_GBS * 1e9) > fl / (MFMA_PEAK_TFS * 1e12) else "mfma"}
 
 
+E6 = dict(channels_input=1, channels_output=1, channels_H=64, max_H=768, encoder_n_layers=6, kernel_size=4,
+          stride=2, tsfm_n_layers=3, tsfm_n_head=8, tsfm_d_model=512, tsfm_d_inner=2048)
+
+
+def c2_e6_forward(dev, dt):
+    """BASELINE.json configs[1]: CleanUMamba-E6 (27.2 M) forward on one GPU, batch 32, 10 s @ 16 kHz (no_grad, random init,
+    reference init seed 0), under autocast `dt` and in f32; plus its selective scan in isolation (the `scan` row of the
+    same shape: B = 32, D = 2048, N = 64, L = 2499).  The output-vs-reference tolerance check of this config is
+    tests/test_model_gpu.py / test_train_gpu.py on the golden E6 fixture."""
+    from cleanumamba_amd.network import Net
+    torch.manual_seed(0)
+    net = Net("CleanUMamba", E6).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(4321)
+    noisy = 0.05 * torch.randn(32, 1, CLIP, generator=g, device=dev)
+    out = {"workload": "CleanUMamba-E6 (27.2M) forward, batch 32, 10 s @ 16 kHz, no_grad", "batch": 32, "clip_samples": CLIP}
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=dt):
+            ms = _time(lambda: net(noisy), iters=10, warm=3)
+        out[f"forward_{_name(dt)}_ms"] = round(ms, 3)
+        out[f"samples_per_s_{_name(dt)}"] = round(32 * CLIP / ms * 1e3, 1)
+        ms32 = _time(lambda: net(noisy), iters=3, warm=1)
+        out["forward_f32_ms"] = round(ms32, 3)
+        out["samples_per_s_f32"] = round(32 * CLIP / ms32 * 1e3, 1)
+    del net, noisy
+    torch.cuda.empty_cache()
+    return out
+
+
+def c5_streaming(dev, streams=256, seconds=30.0):
+    """BASELINE.json configs[4]: the pruned CleanUMamba-E8 (492 K parameters, shipped checkpoint: tests/golden/
+    ckpt_pruned500k.npz is its state dict as data) streaming 256 concurrent 30 s @ 16 kHz streams through feed_batch /
+    flush_batch (16 hops per call).  Real-time factor = audio seconds produced / wall seconds, aggregate over the streams
+    (the reference prints ms/frame and x real time for ONE stream, src/examples/streaming_demo.py:183-186)."""
+    import numpy as np
+    from cleanumamba_amd.network import CleanUMamba
+    with np.load(os.path.join(ROOT, "tests", "golden", "ckpt_pruned500k.npz")) as f:
+        cfg = json.loads(bytes(f["__network_config__"]).decode())
+        sd = {k: torch.from_numpy(f[k].astype(np.float32)) for k in f.files if k != "__network_config__"}
+    out = {"workload": f"pruned CleanUMamba-E8 (492K) streaming, {streams} concurrent streams x {seconds:.0f} s @ 16 kHz",
+           "streams": streams, "seconds_per_stream": seconds}
+    n = int(seconds * 16000)
+    g = torch.Generator(device=dev).manual_seed(99)
+    x = 0.05 * torch.randn(streams, n, generator=g, device=dev)
+    for tag, bf16 in (("f32", False), ("bf16_conv_activations", True)):
+        net = CleanUMamba(**cfg)
+        net.load_pruned_state_dict(sd)
+        net = net.to(dev).eval()
+        net.stream_bf16 = bf16
+        hop = net.total_stride
+        with torch.no_grad():
+            net.feed_batch(x[:, :4 * hop + net.frame_length])       # warm-up: state buffers, hop graph
+            net.reset_stream()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(0, n, 16 * hop):                         # 256 ms of audio per call
+                net.feed_batch(x[:, i:i + 16 * hop])
+            status = net.hop_graph_status                           # (flush ends the streams; their graph goes with them)
+            net.flush_batch()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        out[tag] = {"wall_s": round(wall, 3), "ms_per_hop": round(1e3 * wall / (n // hop), 4),
+                    "hop_ms_audio": 1e3 * hop / 16000, "rtf_aggregate": round(streams * seconds / wall, 1),
+                    "rtf_per_stream": round(seconds / wall, 2), "hop_graph": status}
+        del net
+    return out
+
+
 def cpu_baseline(clip):
     """Oracle forward + loss + backward on the host cores, one clip (bounded sample)."""
     from oracle import cleanumamba_ref as R
@@ -500,6 +567,11 @@ def main():
                 # the kernel north_star names, against the HBM roof it nominates and the issue roof that binds at N = 64
                 out["north_star_kernel"] = out["scan"][0]
                 out["layers"] = layer_table(net, dev, kdt)
+                del net
+                torch.cuda.empty_cache()
+                # the other single-GPU configurations of BASELINE.json, so that the driver's record carries them
+                out["c2_e6_forward"] = c2_e6_forward(dev, kdt)
+                out["c5_streaming"] = c5_streaming(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_clip)
         print(json.dumps(out), flush=True)

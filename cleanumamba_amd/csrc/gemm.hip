@@ -1319,7 +1319,10 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
   // few tiles and a K axis worth splitting: the small-M kernel (64x64 tiles, K split over the four waves)
   const int64_t tiles_128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
   const int bk = sizeof(T) == 2 ? 64 : 32;
-  if ((tile == 64 || (!tile && p.allow_split_k && tiles_128 <= 64)) && p.K >= 4 * bk) return launch_gemm_splitk<T>(p, epi, st);
+  // (allow_split_k == 2: the caller asks for it whatever the tile count -- the narrow Mamba projections, N <= 256 with
+  //  K = 2048, where 128-wide tiles waste half of their columns and 78 row tiles do not fill the chip)
+  if ((tile == 64 || (!tile && (p.allow_split_k == 2 || (p.allow_split_k && tiles_128 <= 64)))) && p.K >= 4 * bk)
+    return launch_gemm_splitk<T>(p, epi, st);
   if (tile == 64) tile = 128;
   if (!tile) {
     // 256x256 (one workgroup per CU) once it fills the chip and N wastes little of the 256-wide tile; 256-row

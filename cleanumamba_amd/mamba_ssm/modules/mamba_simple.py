@@ -31,34 +31,39 @@ from ...causal_conv1d import causal_conv1d_fn, causal_conv1d_update
 
 
 class _ProjFn(torch.autograd.Function):
-    """y = x @ w.T for the four bias-free projections.  Forward and the data gradient stay on hipBLASLt; the weight
-    gradient dW[n][k] = sum_m dY[m][n] X[m][k] runs on cum_gemm_tn: its reduction axis is only B*L = 9984 long while
-    the outputs are small (160 x 2048, 2048 x 32, ...), so a library GEMM without a split over m leaves most CUs
-    idle (46-98 us per call measured), whereas the weight-gradient kernel of the conv stack splits m across
-    workgroups and reduces the f32 slabs deterministically."""
+    """y = x @ w.T for the four bias-free projections of the Mamba block, all three GEMMs on the library's own MFMA
+    kernels: the forward and the data gradient on cum_gemm_nt (csrc/gemm.hip; 256 x 256 / 128 x 128 tiles, the narrow
+    ones -- x_proj forward, dt_proj data gradient -- on the 64 x 64 kernel that splits K over its four waves), the
+    weight gradient dW[n][k] = sum_m dY[m][n] X[m][k] on cum_gemm_tn, whose split over the only 9984-long row axis is
+    what keeps the chip busy there.  Packed (cast, zero-padded, for the data gradient transposed) weight operands come
+    out of the model's per-step pack plan (network/convstack.py PackPlan) with the conv weights: no cast kernels."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, w, cd):
-        xc, wc = x.to(cd), w.to(cd)
-        ctx.save_for_backward(xc, wc)
-        ctx.x_dtype, ctx.w_dtype = x.dtype, w.dtype
+        from ...network import convstack as cs
+        N, K = w.shape
+        xc = x if x.dtype == cd else x.to(cd)
+        x2 = xc.reshape(-1, K)
+        y = cs.proj_fwd(x2, w, cd)
+        ctx.save_for_backward(x2, w)
+        ctx.x_dtype, ctx.w_dtype, ctx.cd, ctx.x_shape = x.dtype, w.dtype, cd, x.shape
         # the parameter itself (identity only: gradient-sink lookup), when the weight is an f32 leaf
         ctx.weight = w if (w.is_leaf and w.dtype == torch.float32) else None
-        return F.linear(xc, wc)
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         from ...network import convstack as cs
-        xc, wc = ctx.saved_tensors
-        N, K = wc.shape
-        dyc = dy.to(wc.dtype)
+        x2, w = ctx.saved_tensors
+        N, K = w.shape
+        cd = ctx.cd
+        d2 = (dy if dy.dtype == cd else dy.to(cd)).reshape(-1, N)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.matmul(dyc, wc).to(ctx.x_dtype)
+            dx = cs.proj_dgrad(d2, w, cd).view(ctx.x_shape).to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
-            x2, d2 = xc.reshape(-1, K), dyc.reshape(-1, N)
             if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
                 x2 = x2.contiguous()
             if d2.stride(1) != 1 or d2.stride(0) % 8 or d2.data_ptr() % 16:
@@ -88,16 +93,19 @@ class _SplitXZ(torch.autograd.Function):
         return torch.cat([dx.transpose(1, 2), dz.transpose(1, 2)], dim=-1), None
 
 
-_PROJ_TN = os.environ.get("CUM_PROJ_TN", "1") != "0"      # "0": plain F.linear everywhere (A/B timing)
 _FUSED_STEP = os.environ.get("CUM_FUSED_STEP", "1") != "0"  # "0": Block + Mamba.step as separate small kernels
 
 
 def _proj(x, w, bias=None):
-    """F.linear, with the weight gradient on the HIP kernel when training on the GPU (see _ProjFn)."""
-    if _PROJ_TN and bias is None and x.is_cuda and torch.is_grad_enabled() and w.requires_grad and w.shape[0] % 8 == 0 \
-            and w.shape[1] % 8 == 0:
+    """F.linear(x, w) of a bias-free projection on the library's GEMM kernels (see _ProjFn): training and inference,
+    f32 and autocast.  Shapes the kernels do not take (a bias, channel counts that are not multiples of 8: pruned
+    checkpoints) stay on F.linear; the per-token streaming step has its own kernels (cum_mamba_step / cum_small_linear).
+    The choice must not depend on the number of rows: two f32 implementations of one GEMM differ in the last bit, which
+    flips enough ReLU gates downstream to move end-to-end gradients by 1e-3 -- a 2-rank run and its single-process
+    twin would no longer agree (tools/debug_batch_invariance.py)."""
+    if bias is None and x.is_cuda and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
         cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-        if cd in hip.IO_TYPES and (cd in hip.HALF_TYPES or w.dtype == torch.float32):
+        if cd in hip.IO_TYPES and (cd in hip.HALF_TYPES or w.dtype == torch.float32) and x.dtype in hip.IO_TYPES:
             return _ProjFn.apply(x, w, cd)
     return F.linear(x, w, bias)
 

@@ -229,7 +229,8 @@ class CleanUMamba(nn.Module):
             else:
                 with cs.small_m_gemms():     # inference on short inputs: few-tile GEMMs may split K over the waves
                     buf, geo, skip_connections, tsfm_out = self._forward_fused(buf, B, T0, dt)
-            x = cs.Unframe.apply(buf, std, geo, L)
+            # (without input normalisation the reference returns the padded length: src/network/CleanUMamba.py:318-319)
+            x = cs.Unframe.apply(buf, std, geo, L if self.normalize_input else T0)
             if return_skip_connections:
                 skip_connections.append(tsfm_out)
                 return x, skip_connections
@@ -350,6 +351,12 @@ class CleanUMamba(nn.Module):
         plans = self.__dict__.setdefault("_pack_plans", {})
         plan = plans.get(dt)
         conv_params = [p for m in (self.encoder, self.decoder, self.tsfm_conv1, self.tsfm_conv2) for p in m.parameters()]
+        for layer in self.tsfm_Mamba_layers:              # the Mamba projections' GEMM operands ride in the same gather
+            mixer = getattr(layer, "mixer", None)
+            for name in ("in_proj", "x_proj", "dt_proj", "out_proj"):
+                lin = getattr(mixer, name, None)
+                if lin is not None:
+                    conv_params.append(lin.weight)
         if plan is None or [p.data_ptr() for p in plan.params] != [p.data_ptr() for p in conv_params]:
             plan = plans[dt] = cs.PackPlan(conv_params)
         # tensor version counters see optimizer steps, load_state_dict and every other in-place update, but not

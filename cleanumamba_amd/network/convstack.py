@@ -64,7 +64,7 @@ def bk_of(dtype):
 
 # ------------------------------------------------------------------ GEMM launcher
 def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_store, res=None, r_off=0, ldr=0,
-         aux=None, x_off=0, ldz=0, geo=None, aux2=None, y_off=0, ldy=0, gate_only=False, mask_bits=False):
+         aux=None, x_off=0, ldz=0, geo=None, aux2=None, y_off=0, ldy=0, gate_only=False, mask_bits=False, split_k=False):
     """A, out, res, aux, aux2: flat tensors; *_off element offsets of row 0; Wp [N, K] packed weights."""
     hip.require_gpu(A, Wp, out, res, aux, aux2, any_dtype=True)
     dt = A.dtype
@@ -78,7 +78,8 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
     d.pitch, d.valid, d.n_store = pitch, valid, n_store
     d.gate_only, d.ldy = int(gate_only), ldy if aux2 is not None else 4
     d.mask_bits = int(mask_bits)
-    d.allow_split_k = int(_SPLIT_K_OK)     # small-M split-K kernel: streaming hops only (see small_m_gemms)
+    # small-M split-K kernel: streaming hops (see small_m_gemms); split_k: asked for by the caller (narrow projections)
+    d.allow_split_k = 2 if split_k else int(_SPLIT_K_OK)
     if geo is not None:      # out (and an activation-type aux) is a row buffer of this geometry: frame it with zeros
         d.zero_head, d.zero_tail = geo.head, geo.tail
     # offsets are in elements of the GEMM dtype; bit arrays (mask_bits) are passed as views that start at the right word
@@ -178,9 +179,16 @@ class PackPlan:
 
     def __init__(self, params):
         self.params = [p for p in params]
+        # Parameters that live in ONE flat f32 buffer (training/flat_optim.py: p.data are views of it) are gathered
+        # straight from that buffer, cast in the same pass: no concatenation, no cast pass.  Otherwise they are
+        # concatenated first.
+        self.source = self._shared_buffer(self.params)
         self.offset, off = {}, 0
         for p in self.params:
-            self.offset[p.data_ptr()] = off
+            if self.source is not None:
+                self.offset[p.data_ptr()] = (p.data_ptr() - self.source.data_ptr()) // p.element_size()
+            else:
+                self.offset[p.data_ptr()] = off
             off += p.numel()
         self.total = off
         self.reqs = {}                        # (key, ptr, dtype) -> (global index (cpu), shape)
@@ -188,6 +196,19 @@ class PackPlan:
         self.gidx = {}                        # dtype -> (device index tensor, [(reqkey, start, numel, shape)])
         self.current = {}
         self.big = {}                         # dtype -> the flat buffer all packed operands of that dtype are views of
+
+    @staticmethod
+    def _shared_buffer(params):
+        """A flat view over the storage all ``params`` are contiguous f32 slices of, or None."""
+        if not params or any(p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda for p in params):
+            return None
+        st = params[0].untyped_storage()
+        if any(p.untyped_storage().data_ptr() != st.data_ptr() for p in params):
+            return None
+        n = st.nbytes() // 4
+        if n >= 2 ** 31:
+            return None
+        return torch.empty(0, dtype=torch.float32, device=params[0].device).set_(st, 0, (n,), (1,))
 
     def record(self, key, src, idx, shape, dtype):
         rk = (key, src.data_ptr(), dtype)
@@ -223,10 +244,14 @@ class PackPlan:
                 self.gidx[dt] = (torch.cat(parts).to(dev), metas)
             self.dirty = False
         with torch.no_grad():
-            flat = torch.cat([p.detach().reshape(-1) for p in self.params])
+            flat = self.source if self.source is not None else torch.cat([p.detach().reshape(-1) for p in self.params])
             for dt, (gi, metas) in self.gidx.items():
-                # cast first: the gather then reads 2-byte elements of a source that stays cache-resident
-                big = gather(flat if flat.dtype == dt else flat.to(dt), gi, dt, out=self.big.get(dt))
+                if self.source is None and flat.dtype != dt:
+                    # cast first: the gather then reads 2-byte elements of a source that stays cache-resident
+                    flat_dt = flat.to(dt)
+                else:
+                    flat_dt = flat                    # flat parameter buffer: converted inside the gather
+                big = gather(flat_dt, gi, dt, out=self.big.get(dt))
                 if self.big.get(dt) is not big:
                     self.big[dt] = big
                     for rk, start, n, shape in metas:
@@ -677,6 +702,72 @@ def to_rows(x, geo, dtype):
 def from_rows(buf, geo):
     """row buffer -> (B, C, T) view (channel stride 1)."""
     return geo.rows(buf)[:, :geo.T, :geo.C].transpose(1, 2)
+
+
+# ------------------------------------------------------------------ plain projections (Mamba in / x / dt / out_proj)
+def lay_proj(shape, Np, Kp):
+    """nn.Linear weight [N, K] -> [Np, Kp] (zero padded): the NT GEMM's weight operand of y = x W^T."""
+    N, K = shape
+    ids = _zeros(Np, Kp)
+    ids[:N, :K] = _ids((N, K))
+    return ids
+
+
+def lay_proj_t(shape, Np, Kp):
+    """nn.Linear weight [N, K] -> its transpose [K -> Np rows, N -> Kp columns] (zero padded): the weight operand of the
+    data gradient dx = dy W, which is the NT GEMM dy (W^T)^T."""
+    N, K = shape
+    ids = _zeros(Np, Kp)
+    ids[:K, :N] = _ids((N, K)).t()
+    return ids
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n, dev):
+    z = _ZERO_BIAS.get((n, dev))
+    if z is None:
+        z = _ZERO_BIAS[(n, dev)] = torch.zeros(n, dtype=torch.float32, device=dev)
+    return z
+
+
+def _gemm_rows(x2, Kp):
+    """x2 as an A operand whose rows can be read Kp elements wide: 16-byte aligned rows, unit column stride, and either a
+    row stride that covers Kp (the over-read stays inside the next columns of the same row, which zero weight columns
+    ignore) or a zero-padded copy."""
+    K = x2.shape[1]
+    ok = x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
+    if ok and (K == Kp or x2.stride(0) >= Kp):
+        return x2
+    if K == Kp:
+        return x2.contiguous()
+    return torch.nn.functional.pad(x2, (0, Kp - K))
+
+
+def proj_fwd(x2, w, dt):
+    """y [M, N] = x2 [M, K] @ w[N, K]^T on cum_gemm_nt (csrc/gemm.hip): the forward GEMM of a bias-free nn.Linear
+    (upstream Mamba.forward's in_proj / x_proj / dt_proj / out_proj, reached from src/network/CleanUMamba.py:172-189)."""
+    N, K = w.shape
+    Np, Kp = rup(N, 32), rup(K, bk_of(dt))
+    wp = take(w, ("proj", (N, K), Np, Kp), lambda: lay_proj((N, K), Np, Kp), dt)
+    a = _gemm_rows(x2, Kp)
+    M = a.shape[0]
+    out = torch.empty(M, N, dtype=dt, device=a.device)
+    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, N, M, 1 << 30, 1 << 30, hip.EPI_BIAS, N, split_k=N <= 256)
+    return out
+
+
+def proj_dgrad(dy2, w, dt):
+    """dx [M, K] = dy2 [M, N] @ w[N, K]: the data gradient of the same layer, as the NT GEMM against w^T."""
+    N, K = w.shape
+    Np, Kp = rup(K, 32), rup(N, bk_of(dt))
+    wp = take(w, ("proj_t", (N, K), Np, Kp), lambda: lay_proj_t((N, K), Np, Kp), dt)
+    a = _gemm_rows(dy2, Kp)
+    M = a.shape[0]
+    out = torch.empty(M, K, dtype=dt, device=a.device)
+    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, K, M, 1 << 30, 1 << 30, hip.EPI_BIAS, K, split_k=K <= 256)
+    return out
 
 
 def clip_std(x, eps):

@@ -193,7 +193,9 @@ def test_trained_weights_reach_every_inference_cache(cuda, dtype):
         clean, noisy = synth.waveform(2, 8000, seed=60 + it)
         step(clean.to(cuda), noisy.to(cuda))
         if it in (1, 6):                                  # after an eager step and after a replayed one
-            assert any(not torch.equal(a, p.detach()) for a, p in zip(seen, net.parameters()))
+            if it == 6:                                   # (fp16: the first steps overflow at scale 65536 and are skipped)
+                assert float(step.optimizer.state_vec[5]) >= 1
+                assert any(not torch.equal(a, p.detach()) for a, p in zip(seen, net.parameters()))
             fresh = CleanUMamba(**cfg)
             fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, strict=True)
             fresh = fresh.to(cuda)

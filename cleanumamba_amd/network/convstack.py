@@ -975,6 +975,49 @@ def _glu_dgrad_weights(w, gi, G32, dt):
                 lambda: torch.nn.functional.pad(lay_glu_fwd(sh, G32, Nd).t(), (0, Kd - G32)), dt)
 
 
+_ENC0_FUSED = os.environ.get("CUM_ENC0_FUSED", "1") != "0"     # "0": first encoder layer on the generic GEMM path (A/B)
+
+
+def _enc0_ok(w1, w2, gi, gm, go, dt):
+    """The fused first-layer kernels (csrc/enc0.hip): one input channel, 64 conv channels, 16-bit activations."""
+    return (_ENC0_FUSED and dt in hip.HALF_TYPES and tuple(w1.shape) == (64, 1, 4) and tuple(w2.shape) == (128, 64, 1)
+            and gi.C == 1 and gi.Cp == 8 and gm.C == 64 and go.C == 64 and w1.dtype == torch.float32)
+
+
+def _enc0_w2p(w2, gm, dt):
+    sh = tuple(w2.shape)
+    G = (sh[0] // 2 + 15) // 16
+    Kp = rup(gm.Cp, bk_of(dt))
+    wp = take(w2, ("glu_fwd", sh, G * 32, Kp), lambda: lay_glu_fwd(sh, G * 32, Kp), dt)
+    return wp
+
+
+def _enc0_fwd(xbuf, w1, b1, w2, b2, gm, go, save_z):
+    dt, dev = xbuf.dtype, xbuf.device
+    wp = _enc0_w2p(w2, gm, dt)
+    bp = take(b2, ("glu_vec", w2.shape[0]), lambda: lay_glu_vec(w2.shape[0]), torch.float32)
+    ybuf = go.new(dt, dev)
+    z = torch.empty(go.M, 64, dtype=dt, device=dev) if save_z else None
+    with torch.cuda.device(dev):
+        hip.check(hip.lib().cum_enc0_fwd(hip.dtype_code(dt), go.M, go.P, go.T, hip.ptr(xbuf), hip.ptr(w1.detach()),
+                                         hip.ptr(b1.detach()), hip.ptr(wp), hip.ptr(bp), hip.ptr(ybuf), go.tail, hip.ptr(z),
+                                         hip.stream_ptr()))
+    return ybuf, z
+
+
+def _enc0_bwd(dz, xbuf, w1, b1, w2, gm, go, slot_w1, slot_w2):
+    """slot_* = (arena buffer, offset): weight / bias gradients of the conv and of the 1x1 in their arena layouts."""
+    dt, dev = dz.dtype, dz.device
+    wp = _enc0_w2p(w2, gm, dt)
+    lib = hip.lib()
+    ws = torch.empty(lib.cum_enc0_bwd_workspace_elems(go.M), dtype=torch.float32, device=dev)
+    (a1, o1), (a2, o2) = slot_w1, slot_w2
+    with torch.cuda.device(dev):
+        hip.check(lib.cum_enc0_bwd(hip.dtype_code(dt), go.M, go.P, go.T, hip.ptr(dz), hip.ptr(xbuf), hip.ptr(w1.detach()),
+                                   hip.ptr(b1.detach()), hip.ptr(wp), ctypes.c_void_p(a2.data_ptr() + 4 * o2),
+                                   ctypes.c_void_p(a1.data_ptr() + 4 * o1), hip.ptr(ws), hip.stream_ptr()))
+
+
 class EncoderStack(torch.autograd.Function):
     """x -> (x_1, ..., x_E): every encoder layer [Conv1d k4 s2, ReLU, Conv1d 1x1, GLU]
     (src/network/CleanUMamba.py:108-113) on row buffers.  geos[i] = (g_in, g_mid, g_out); params = w1, b1, w2, b2
@@ -986,8 +1029,12 @@ class EncoderStack(torch.autograd.Function):
         for i, (gi, gm, go) in enumerate(geos):
             w1, b1, w2, b2 = params[4 * i:4 * i + 4]
             assert gi.P == 2 * gm.P and gm.T == go.T and gi.C == w1.shape[1] and gm.C == w1.shape[0] == w2.shape[1]
-            y1 = _conv_relu_fwd(bufs[-1], w1, b1, gi, gm)
-            y, z = _glu_fwd(y1, w2, b2, gm, go, save_z)
+            if i == 0 and _enc0_ok(w1, w2, gi, gm, go, xbuf.dtype):
+                y1 = None                      # rebuilt from the input where the backward needs it (csrc/enc0.hip)
+                y, z = _enc0_fwd(xbuf, w1, b1, w2, b2, gm, go, save_z)
+            else:
+                y1 = _conv_relu_fwd(bufs[-1], w1, b1, gi, gm)
+                y, z = _glu_fwd(y1, w2, b2, gm, go, save_z)
             bufs.append(y)
             y1s.append(y1)
             zs.append(z)
@@ -1046,13 +1093,19 @@ class EncoderStack(torch.autograd.Function):
                     raise RuntimeError("EncoderStack: the deepest output must be used")
                 dz = _glu_bwd(zs[i], bufs[i + 1], dys[i].contiguous(), go)
             G32 = dz.shape[1]
-            grads[4 * i + 2], grads[4 * i + 3] = _glu_wgrad(dz, y1s[i], w2, gm, go.M,
+            y1 = y1s[i]
+            if y1 is None:                     # fused first layer: y1 was never stored
+                if arena is not None and not ctx.needs_input_grad[0]:
+                    _enc0_bwd(dz, bufs[0], w1, b1, w2, gm, go, arena.out(0), arena.out(1))
+                    break
+                y1 = _conv_relu_fwd(bufs[0], w1, b1, gi, gm)      # generic route (input gradient wanted): rebuild it
+            grads[4 * i + 2], grads[4 * i + 3] = _glu_wgrad(dz, y1, w2, gm, go.M,
                                                             out=arena.out(2 * i + 1) if arena else None)
             # 1x1 data gradient, gated by the ReLU below it in the epilogue
             wt = _glu_dgrad_weights(w2, gm, G32, dt)
             dzc = gm.new(dt, dev)
             gemm(dz, 0, G32, wt, None, dzc, gm.Cp, gm.Cp, gm.M, gm.P, gm.T, hip.EPI_MASK, gm.Cp,
-                 res=y1s[i], r_off=gm.Cp, ldr=gm.Cp, geo=gm)
+                 res=y1, r_off=gm.Cp, ldr=gm.Cp, geo=gm)
             # conv weight gradient: X row m = the 4*Cp contiguous inputs of output row m
             sh = tuple(w1.shape)
             dwp, dbp = wgrad(dzc, gm.Cp, gm.Cp, gm.Cp, bufs[i], gi.Cp, 2 * gi.Cp, 4 * gi.Cp, gm.M,

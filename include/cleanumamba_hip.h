@@ -346,6 +346,30 @@ int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t C
                            int64_t y_pitch, void *tail, const float *bias, const void *skip, int64_t skip_pitch,
                            void *out, int64_t out_pitch, int32_t relu, void *stream);
 
+/* ---- first encoder layer, fused (csrc/enc0.hip): Conv1d(1 -> 64, k 4, s 2) + ReLU + Conv1d(64 -> 128, 1x1) + GLU of
+ * src/network/CleanUMamba.py:108-113 at channels_input = 1, channels_H = 64 (E6 / E8), 16-bit element types.  The ReLU
+ * output of the one-input-channel conv is rebuilt from the four input samples wherever it is needed instead of being
+ * stored: forward and backward each move the layer's output-sized tensors once.
+ *   xin      the layer's input row buffer [1 + 2 M + >= 2][8] (column 0 = sample, as cum_frame_rows writes it)
+ *   w1, b1   the conv's parameters as stored: (64, 1, 4) and (64) f32
+ *   w2p, b2p the 1x1 conv in the forward GEMM's packed operand order: [128][64] element type / [128] f32, per 32 rows
+ *            16 a-rows then the 16 b-rows of the same channels
+ *   M rows = clips x pitch; rows with (m mod pitch) >= valid are the zero rows between clips
+ * cum_enc0_fwd: out = row buffer [1 + M + slack][64] (row 0 and zero_tail elements behind row M are cleared), gate
+ *   [M][64] = the GLU's gate pre-activations for the backward (NULL: not kept).
+ * cum_enc0_bwd: dZ [M][128] (gradient wrt the 1x1 conv's output, packed column order) -> slot_w2 = dW2 [128][64] then
+ *   db2 [128], slot_w1 = dW1 [64][32] (element (h, 8 k) = tap k, other columns 0) then db1 [64]: the layouts
+ *   cum_gemm_tn writes for these two layers.  workspace: cum_enc0_bwd_workspace_elems(M) f32.  Deterministic (slabs
+ *   per workgroup, fixed-order sum).  The layer has no input gradient. */
+int cum_enc0_fwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const void *xin, const float *w1,
+                 const float *b1, const void *w2p, const float *b2p, void *out, int64_t zero_tail, void *gate,
+                 void *stream);
+int32_t cum_enc0_bwd_workgroups(int64_t M);
+int64_t cum_enc0_bwd_workspace_elems(int64_t M);
+int cum_enc0_bwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const void *dZ, const void *xin,
+                 const float *w1, const float *b1, const void *w2p, float *slot_w2, float *slot_w1, float *workspace,
+                 void *stream);
+
 /* ---- waveform ends of the train step (csrc/loss.hip).  All sums are per-workgroup partials in fixed order + one
  * finishing workgroup: deterministic, graph-capturable, nothing returns to the host.
  *

@@ -218,3 +218,52 @@ def test_weight_gradient_gemm_against_torch(cuda, M, N, K, ldx, dtype, tol):
     assert dw.shape == (N, K) and db.shape == (N,)
     assert record(f"wgrad[{M}x{N}x{K}-{dtype}].dW", rel_l2(dw, want_w)) < tol
     assert record(f"wgrad[{M}x{N}x{K}-{dtype}].db", rel_l2(db, want_b)) < tol
+
+
+@pytest.mark.parametrize("tin", [62, 510, 4100])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_first_encoder_layer(cuda, tin, dtype, monkeypatch):
+    """csrc/enc0.hip -- the first encoder layer (1 -> 64 channels) with its ReLU intermediate rebuilt from the input
+    instead of stored (src/network/CleanUMamba.py:108-113 at channels_input 1, channels_H 64) -- through EncoderStack:
+    forward and all four parameter gradients against the f64 oracle (the per-layer bounds), against the generic GEMM
+    route on the same inputs, bit-reproducible, and really taken."""
+    from cleanumamba_amd.network import convstack as cs
+    tol, btol = LAYER_TOL[dtype]
+    B, cin, h = 3, 1, 64
+    sd = _layer_params(cin, h, h, seed=7)
+    x = torch.randn(B, cin, tin, generator=torch.Generator().manual_seed(11))
+    tout = (tin - 4) // 2 + 1
+    dout = torch.randn(B, h, tout, generator=torch.Generator().manual_seed(12))
+    ref = {k: (_rounded(v, dtype) if k.endswith("weight") else v.double()).requires_grad_(True)
+           for k, v in sd.items() if k.startswith("encoder")}
+    yr = R.encoder_layer(ref, 0, _rounded(x, dtype), store=_store(dtype))
+    (yr * dout.double()).sum().backward()
+    gi, gm, go = cs.Geo(B, tin, cin), cs.Geo(B, tout, h), cs.Geo(B, tout, h)
+    keys = ["encoder.0.0.weight", "encoder.0.0.bias", "encoder.0.2.weight", "encoder.0.2.bias"]
+    calls = []
+    real_fwd, real_bwd = cs._enc0_fwd, cs._enc0_bwd
+    monkeypatch.setattr(cs, "_enc0_fwd", lambda *a, **k: (calls.append("fwd"), real_fwd(*a, **k))[1])
+    monkeypatch.setattr(cs, "_enc0_bwd", lambda *a, **k: (calls.append("bwd"), real_bwd(*a, **k))[1])
+
+    def run(fused):
+        monkeypatch.setattr(cs, "_ENC0_FUSED", fused)
+        dev = {k: sd[k].to(cuda).requires_grad_(True) for k in keys}
+        buf = cs.to_rows(x.to(cuda), gi, dtype)
+        (ybuf,) = cs.EncoderStack.apply(buf, [(gi, gm, go)], True, *[dev[k] for k in keys])
+        y = cs.from_rows(ybuf, go).float()
+        rows = go.rows(ybuf)
+        assert float(rows[:, go.T:].abs().max()) == 0 and float(ybuf[0].abs().max()) == 0     # framing rows stay zero
+        (y * dout.to(cuda)).sum().backward()
+        return y.detach(), {k: dev[k].grad.detach() for k in keys}
+    y_f, g_f = run(True)
+    assert calls == ["fwd", "bwd"]
+    y_f2, g_f2 = run(True)
+    assert torch.equal(y_f, y_f2) and all(torch.equal(g_f[k], g_f2[k]) for k in keys)              # deterministic
+    y_g, g_g = run(False)
+    assert calls == ["fwd", "bwd"] * 2                                                           # generic route: not called
+    tag = f"enc0_fused[{tin}-{dtype}]"
+    assert record(tag + ".fwd", rel_l2(y_f, yr)) < tol
+    assert record(tag + ".fwd_vs_generic", rel_l2(y_f, y_g)) < tol
+    for k in keys:
+        assert record(tag + ".d" + k, rel_l2(g_f[k], ref[k].grad)) < btol, k
+        assert rel_l2(g_f[k], g_g[k]) < btol, k

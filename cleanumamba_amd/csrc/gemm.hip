@@ -51,6 +51,7 @@ struct GemmParams {
   int64_t lda, ldw, ldc, ldr, ldz, ldy;
   int gate_only;           // GLU / GLU_BWD: aux holds only the gate pre-activation b ([M][ldz], output-column order)
   int allow_split_k;       // few-tile launches may use gemm_nt_splitk_kernel
+  int var;                 // experiment switch of gemm_nt9_kernel (CUM_NT9=1|2|3)
   int mask_bits;           // RELU: aux receives the SIGN (value > 0) of each element instead of the activation, four
                            // consecutive channels per byte (low nibble; byte index (m * ld + n) / 4) -- what a lane
                            // holds after the MFMA, so no cross-lane packing; MASK: res is such an array.
@@ -1057,6 +1058,233 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GemmParams p) {
                                 reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
 }
 
+// ---------------------------------------------------------------- 256 x 256 tile, 8 waves, two wave groups in ping-pong
+// Same tile, units, DMA scheme and epilogues as gemm_nt8_kernel; what changes is WHEN the two halves of the workgroup do
+// what.  In gemm_nt8_kernel all eight waves run the same phase at the same time: both waves of a SIMD issue their 20
+// fragment reads together, wait for them together, want the matrix pipe together and meet at the same three barriers --
+// the pipe measured 48 % busy.  Here a K-tile is eight SLOTS (one barrier each), alternately a LOAD slot (issue the
+// fragment reads of the next 16 MFMAs and this slot's share of the LDS-DMAs, then wait at the barrier) and a COMPUTE slot
+// (16 MFMAs = one 64 x 32 quadrant over the K-tile), and waves 4-7 run ONE SLOT BEHIND waves 0-3: on every SIMD one wave
+// computes while its partner loads (MI355X_MICROARCH.md "Two waves per SIMD", cdna_hip_programming.md 5 "8-phase").
+//   group 0 (rows 0-127):   L1 C1 L2 C2 L3 C3 L4 C4 | L1 ...        group 1 (rows 128-255): .. L1 C1 L2 C2 L3 C3 L4 C4 | ...
+//   L1: A rows 0-63 + W channels 0-31 (12 reads)   C1: (rows 0-63,  ch 0-31)
+//   L2: A rows 64-127 (8 reads)                    C2: (rows 64-127, ch 0-31)
+//   L3: W channels 32-63 (4 reads)                 C3: (rows 64-127, ch 32-63)
+//   L4: -                                          C4: (rows 0-63,  ch 32-63)
+// Unit lifetimes (K-tile t, slots counted in barriers 8 t + i of group 0): A0 is read by group 0 only, in L1 / L2 -> free
+// after barrier 8t+4; A1 by group 1 only -> free after 8t+5; W0 / W1 by both, last in group 1's L3 -> free after 8t+7.
+// LDS-DMA of K-tile t + 2 into the freed units: group 0 issues A0 in L3, A1 in L4, W0 + W1 in the next K-tile's L1;
+// group 1 issues A0 + A1 in L3, W0 + W1 in L4.  One counted wait per K-tile and wave (end of C4 / in L4): vmcnt(4) = K-tile
+// t + 1 has landed, the four A instructions of K-tile t + 2 stay in flight; the barrier behind it publishes K-tile t + 1.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
+  static_assert(sizeof(T) == 2, "16-bit element types only");
+  constexpr int EPC = 8, BK = 64;
+  constexpr int UNIT = 128 * 8;
+  __shared__ uint4 lds_all[2 * 4 * UNIT];             // [K-tile parity][A0, A1, W0, W1]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4, r = lane & 15;
+  const int NB = (p.N + 255) / 256;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int m_tile = (local / NB) * 8 + xcd;
+  const int n0 = (local % NB) * 256;
+  const int m0 = m_tile * 256;
+  if (m0 >= p.M) return;
+  if (blockIdx.x == 0) {                              // framing rows of the output buffer (see gemm_nt_kernel)
+    T *o = static_cast<T *>(p.out);
+    T *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD && !(EPI == EPI_RELU && p.mask_bits)) ? static_cast<T *>(p.aux) : nullptr;
+    for (int64_t i = threadIdx.x; i < p.zero_head; i += 512) {
+      o[-1 - i] = Elem<T>::from_f(0.f);
+      if (x) x[-1 - i] = Elem<T>::from_f(0.f);
+    }
+    const int64_t tail0 = (int64_t)p.M * p.ldc, tailx = (int64_t)p.M * p.ldz;
+    for (int64_t i = threadIdx.x; i < p.zero_tail; i += 512) {
+      o[tail0 + i] = Elem<T>::from_f(0.f);
+      if (x) x[tailx + i] = Elem<T>::from_f(0.f);
+    }
+  }
+  const T *A = static_cast<const T *>(p.A);
+  const T *W = static_cast<const T *>(p.W);
+  const T *src[4][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pos = it * 512 + tid;
+      const int row = pos >> 3, cphys = pos & 7;
+      const int clog = cphys ^ (row & 7);
+      if (u < 2) {
+        int am = m0 + 128 * u + row;
+        am = am < p.M ? am : p.M - 1;
+        src[u][it] = A + (int64_t)am * p.lda + clog * EPC;
+      } else {
+        int wn_ = n0 + 128 * (u - 2) + row;
+        wn_ = wn_ < p.N ? wn_ : p.N - 1;
+        src[u][it] = W + (int64_t)wn_ * p.ldw + clog * EPC;
+      }
+    }
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+#define CUM_STAGE(u, kt, par)                                                                                   \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it)                                                           \
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src[u][it] + (kt) * BK),                                      \
+                                       (lds_ptr)(&lds_all[((par) * 4 + (u)) * UNIT + it * 512 + wave * 64]), 16, 0, 0); \
+  } while (0)
+
+  f32x4 acc[2][4][4];                                 // [m half][ni][mi]: rows 128 wr + 64 h + 16 mi, channels 64 wc + 16 ni
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bv[4][4];
+  nt_load_bias(p, n0, wc, g, bv);
+
+  const int nk = p.K / BK;
+  const int var = p.var;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) CUM_STAGE(u, 0, 0);
+  if (nk > 1) {
+    CUM_STAGE(0, 1, 1);
+    CUM_STAGE(1, 1, 1);
+    if (var != 3) {
+      CUM_STAGE(2, 1, 1);
+      CUM_STAGE(3, 1, 1);
+    }
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)lds_all;
+  unsigned aA[2], aW[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int cl = ks * 4 + g;
+    aA[ks] = lds0 + (unsigned)((wr * UNIT + r * 8 + (cl ^ (r & 7))) * 16);
+    aW[ks] = lds0 + (unsigned)(((2 + (wc >> 1)) * UNIT + ((wc & 1) * 64 + r) * 8 + (cl ^ (r & 7))) * 16);
+  }
+#define CUM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+#define CUM_BAR()                               \
+  do {                                          \
+    __builtin_amdgcn_sched_barrier(0);          \
+    asm volatile("s_barrier" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);          \
+  } while (0)
+#define CUM_HALFQ(h, nlo, ks)                                                                                  \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                           \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                       \
+        if constexpr (__is_same(T, f16))                                                                       \
+          acc[h][(nlo) + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                     \
+              __builtin_bit_cast(f16x8, wf[ks][ni]), __builtin_bit_cast(f16x8, af[ks][4 * (h) + mi]),          \
+              acc[h][(nlo) + ni][mi], 0, 0, 0);                                                                \
+        else                                                                                                   \
+          acc[h][(nlo) + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                    \
+              __builtin_bit_cast(bf16x8, wf[ks][ni]), __builtin_bit_cast(bf16x8, af[ks][4 * (h) + mi]),        \
+              acc[h][(nlo) + ni][mi], 0, 0, 0);                                                                \
+      }                                                                                                        \
+  } while (0)
+#define CUM_QUAD(h, nlo)                 \
+  do {                                   \
+    __builtin_amdgcn_s_setprio(1);       \
+    CUM_HALFQ(h, nlo, 0);                \
+    CUM_HALFQ(h, nlo, 1);                \
+    __builtin_amdgcn_s_setprio(0);       \
+  } while (0)
+
+  if (nk > 1) {
+    if (var == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile 0 landed; what was issued of K-tile 1 stays in flight
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CUM_BAR();                                                           // K-tile 0 is visible to every wave
+  if (wr != 0) CUM_BAR();                                              // group 1 runs one slot behind group 0
+  u32x4 af[2][8], wf[2][2];
+  for (int kt = 0; kt < nk; ++kt) {
+    const int par = kt & 1;
+    const unsigned pb = (unsigned)par * (4 * UNIT * 16);
+    const unsigned a0 = aA[0] + pb, a1 = aA[1] + pb, w0 = aW[0] + pb, w1 = aW[1] + pb;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    // ---- L1: W channels 0-31 and A rows 0-63; group 0 stages the W units of K-tile kt + 1 (freed one slot ago)
+    CUM_DSR(wf[0][0], w0, 0);     CUM_DSR(wf[0][1], w0, 2048);
+    CUM_DSR(af[0][0], a0, 0);     CUM_DSR(af[0][1], a0, 2048);  CUM_DSR(af[0][2], a0, 4096);  CUM_DSR(af[0][3], a0, 6144);
+    CUM_DSR(wf[1][0], w1, 0);     CUM_DSR(wf[1][1], w1, 2048);
+    CUM_DSR(af[1][0], a1, 0);     CUM_DSR(af[1][1], a1, 2048);  CUM_DSR(af[1][2], a1, 4096);  CUM_DSR(af[1][3], a1, 6144);
+    if (var == 3) {
+      if (more1) CUM_STAGE(2, kt + 1, par ^ 1);
+    } else if (wr == 0 && kt >= 1 && more1) {
+      CUM_STAGE(2, kt + 1, par ^ 1);
+      if (var != 2) CUM_STAGE(3, kt + 1, par ^ 1);
+    }
+    CUM_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(af[0][0]), "+v"(af[0][1]),
+                   "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]) : : "memory");
+    CUM_QUAD(0, 0);                                                       // C1
+    CUM_BAR();
+    // ---- L2: A rows 64-127
+    CUM_DSR(af[0][4], a0, 8192);  CUM_DSR(af[0][5], a0, 10240); CUM_DSR(af[0][6], a0, 12288); CUM_DSR(af[0][7], a0, 14336);
+    CUM_DSR(af[1][4], a1, 8192);  CUM_DSR(af[1][5], a1, 10240); CUM_DSR(af[1][6], a1, 12288); CUM_DSR(af[1][7], a1, 14336);
+    if (var == 3) {
+      if (more1) CUM_STAGE(3, kt + 1, par ^ 1);
+    } else if (var == 2 && wr == 0 && kt >= 1 && more1) {
+      CUM_STAGE(3, kt + 1, par ^ 1);
+    }
+    CUM_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(af[0][4]), "+v"(af[0][5]), "+v"(af[0][6]), "+v"(af[0][7]), "+v"(af[1][4]), "+v"(af[1][5]),
+                   "+v"(af[1][6]), "+v"(af[1][7]) : : "memory");
+    CUM_QUAD(1, 0);                                                       // C2
+    CUM_BAR();
+    // ---- L3: W channels 32-63; the A units of this parity are free: K-tile kt + 2
+    CUM_DSR(wf[0][0], w0, 4096);  CUM_DSR(wf[0][1], w0, 6144);  CUM_DSR(wf[1][0], w1, 4096);  CUM_DSR(wf[1][1], w1, 6144);
+    if (more2) {
+      CUM_STAGE(0, kt + 2, par);
+      if (wr != 0 && var != 3) CUM_STAGE(1, kt + 2, par);
+    }
+    CUM_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]) : : "memory");
+    CUM_QUAD(1, 2);                                                       // C3
+    CUM_BAR();
+    // ---- L4: no reads.  group 0: A1 of K-tile kt + 2; group 1: K-tile kt + 1 must have landed, then W of K-tile kt + 2
+    if (var == 3) {
+      if (wr != 0 && more1) {                      // group 1's wait sits in front of its last DMA of the K-tile
+        if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (more2) CUM_STAGE(1, kt + 2, par);
+    } else if (wr == 0) {
+      if (more2) CUM_STAGE(1, kt + 2, par);
+    } else {
+      if (more1) {
+        if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (more2) {
+        CUM_STAGE(2, kt + 2, par);
+        CUM_STAGE(3, kt + 2, par);
+      }
+    }
+    CUM_BAR();
+    CUM_QUAD(0, 2);                                                       // C4
+    if (wr == 0 && more1) {
+      if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CUM_BAR();
+  }
+  if (wr == 0) CUM_BAR();                                                // group 1's last slot
+#undef CUM_HALFQ
+#undef CUM_DSR
+#undef CUM_QUAD
+#undef CUM_STAGE
+#undef CUM_BAR
+  asm volatile("s_barrier" ::: "memory");          // every wave is done reading the K loop's LDS units
+  nt_epilogue_any<T, EPI, 2, 1>(p, acc, bv, m0, n0, 2 * wr, wc, lane,
+                                reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
+}
+
 // ---------------------------------------------------------------- small-M variant (streaming hops)
 // Launches with only a few dozen 128x128 tiles (M = streams x a handful of rows) leave most of the chip idle while
 // every workgroup walks the whole K axis at one exposed DMA latency per step.  Here a workgroup owns a 64x64 tile and
@@ -1287,6 +1515,31 @@ static int nt8_enabled() {
   return v;
 }
 
+static int nt9_enabled() {
+  static const int v = [] {
+    const char *e = getenv("CUM_NT9");     // "0": gemm_nt8_kernel (A/B); "2", "3": other DMA placements (measured equal)
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
+template <typename T>
+static int launch_gemm_nt9(const GemmParams &p, int epi, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    const int NB = (p.N + 255) / 256, MB = (p.M + 255) / 256;
+    dim3 grid(8 * NB * ((MB + 7) / 8)), block(512);
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm_nt9_kernel<T, EPI_BIAS>), grid, block, 0, st, p); break;
+      case EPI_RELU: hipLaunchKernelGGL((gemm_nt9_kernel<T, EPI_RELU>), grid, block, 0, st, p); break;
+      case EPI_MASK: hipLaunchKernelGGL((gemm_nt9_kernel<T, EPI_MASK>), grid, block, 0, st, p); break;
+      case EPI_GLU_BWD: hipLaunchKernelGGL((gemm_nt9_kernel<T, EPI_GLU_BWD>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm_nt9_kernel<T, EPI_GLU>), grid, block, 0, st, p); break;
+    }
+    CUM_CHECK_LAUNCH();
+  }
+  return CUM_OK;
+}
+
 template <typename T, int BM, int BN>
 static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   const int NB = (p.N + BN - 1) / BN, MB = (p.M + BM - 1) / BM;
@@ -1338,6 +1591,7 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
     else if (sizeof(T) == 4 && p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
     else tile = 128;
   }
+  if (tile == 512 && sizeof(T) == 2 && nt9_enabled()) return launch_gemm_nt9<T>(p, epi, st);
   if (tile == 512 && sizeof(T) == 2 && nt8_enabled()) return launch_gemm_nt8<T>(p, epi, st);
   if (tile == 512) return launch_gemm_tile<T, 256, 256>(p, epi, st);
   if (tile == 256) return launch_gemm_tile<T, 256, 128>(p, epi, st);
@@ -1374,6 +1628,7 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
   p.gate_only = d->gate_only;
   p.mask_bits = d->mask_bits;
   p.allow_split_k = d->allow_split_k;
+  p.var = nt9_enabled();
   CUM_REQUIRE(!d->mask_bits || (d->epilogue == EPI_RELU && aux) || d->epilogue == EPI_MASK,
               "gemm: mask_bits applies to RELU (aux = sign array) and MASK (res = sign array)");
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;

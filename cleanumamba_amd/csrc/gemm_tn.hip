@@ -499,6 +499,274 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnParams p) {
   if (bias_wave) p.bslab[(int64_t)sp * p.Np + n0 + wn * 64 + 16 * g + r] = bacc[0];
 }
 
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_tn9_kernel(const TnParams p) {
+  static_assert(sizeof(T) == 2, "16-bit element types only");
+  constexpr int UNIT = 64 * 16;                      // 16-byte chunks of one unit
+  __shared__ uint4 lds_all[2 * 4 * UNIT];            // [step parity][X0, X1, Z0, Z1]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wk = wave >> 2, wn = wave & 3;
+  const int g = lane >> 4, r = lane & 15;
+  // One resident round: work item w = xcd * (slots per XCD) + slot, split = w / tiles, tile = w % tiles (n fastest):
+  // the workgroups of one XCD hold consecutive tiles of one or two splits, so their rows meet in that XCD's L2.
+  const int ntn = p.Np / 256, ntk = p.Kp / 256, tiles = ntn * ntk;
+  const int w = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  if (w >= tiles * p.nsplit) return;
+  const int sp = w / tiles, tile = w % tiles;
+  const int n0 = (tile % ntn) * 256, k0 = (tile / ntn) * 256;
+  const int64_t m_begin = (int64_t)sp * p.rows_per_split;
+  int64_t m_end = m_begin + p.rows_per_split;
+  m_end = m_end < p.M ? m_end : p.M;
+  const int len = (int)(m_end - m_begin);
+  const int nk = (len + 63) / 64;
+  const int rem = len - 64 * (nk - 1);               // rows of step 0 (1 .. 64)
+  const T *dZ = static_cast<const T *>(p.dZ);
+  const T *X = static_cast<const T *>(p.X);
+  const bool bias_wave = p.bslab != nullptr && k0 == 0 && wk == 0;
+
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+  // DMA sources: unit u, instruction it fills linear chunk it * 512 + tid of the unit = (row, physical chunk).  The
+  // address is a wave-uniform base (SGPRs: tile corner + step) plus a small per-thread byte offset (row * ld + chunk),
+  // so a step's eight DMAs need four offset registers and no vector address arithmetic.
+  const int64_t stepx = 128 * p.ldx, stepz = 128 * p.ldz;                 // bytes per 64-row step
+  const char *xb = reinterpret_cast<const char *>(X + k0) + m_begin * p.ldx * 2;
+  const char *zb = reinterpret_cast<const char *>(dZ + n0) + m_begin * p.ldz * 2;
+  unsigned xo[2], zo[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int pos = it * 512 + tid;
+    const int row = pos >> 4;
+    const int clog = (pos & 15) ^ TnCfg<T>::swz(row);
+    const int rowc = row < rem ? row : rem - 1;                            // step 0: clamped rows (zeroed below)
+    xo[it] = (unsigned)(row * (int)p.ldx * 2 + clog * 16);
+    zo[it] = (unsigned)(row * (int)p.ldz * 2 + clog * 16);
+    const unsigned x0 = (unsigned)(rowc * (int)p.ldx * 2 + clog * 16), z0 = (unsigned)(rowc * (int)p.ldz * 2 + clog * 16);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      __builtin_amdgcn_global_load_lds((glb_ptr)((u < 2 ? xb + x0 : zb + z0) + 256 * (u & 1)),
+                                       (lds_ptr)(&lds_all[u * UNIT + it * 512 + wave * 64]), 16, 0, 0);
+  }
+  // step s >= 1 covers rows m_begin + rem + 64 (s - 1) ..: base of step s = b1 + s * step
+  const char *xb1 = xb + (int64_t)(rem - 64) * p.ldx * 2, *zb1 = zb + (int64_t)(rem - 64) * p.ldz * 2;
+#define CUM_STAGE(u, s, par)                                                                                    \
+  do {                                                                                                          \
+    const char *ub = ((u) < 2 ? xb1 + (s) * stepx : zb1 + (s) * stepz) + 256 * ((u) & 1);                        \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it)                                                           \
+      __builtin_amdgcn_global_load_lds((glb_ptr)(ub + ((u) < 2 ? xo[it] : zo[it])),                            \
+                                       (lds_ptr)(&lds_all[((par) * 4 + (u)) * UNIT + it * 512 + wave * 64]), 16, 0, 0); \
+  } while (0)
+  if (nk > 1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) CUM_STAGE(u, 1, 1);
+  }
+  if (rem < 64) {                                    // rows past the end of the split must contribute nothing
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pos = it * 512 + tid;
+      if ((pos >> 4) >= rem) {                       // this thread's own DMA filled the chunk: no barrier needed
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lds_all[u * UNIT + pos] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  f32x4 acc[2][4][4];                                // [k half][ni][ki]: k = 128 wk + 64 h + 16 ki + 4 g + j, n = 64 wn + 16 ni + r
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Transposing reads (see gemm_tn_kernel): lane (g, q = r >> 2, pp = r & 3) addresses row 32 ks + 8 g + q (+ 4 for the
+  // upper half of the fragment), columns 16 blk + 4 pp ..; the row swizzle term t = q | (g & 1) << 2 is the same for both
+  // halves and both ks, so a block's four reads share one address register and differ by immediate offsets.
+  const int q = r >> 2, pp = r & 3, t = q | ((g & 1) << 2);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)lds_all;
+  const unsigned lane_base = lds0 + (unsigned)((8 * g + q) * 256 + 8 * pp);
+  unsigned ax[8], az[4];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) ax[b] = lane_base + (unsigned)(wk * UNIT * 16 + 32 * (b ^ t));
+#pragma unroll
+  for (int b = 0; b < 4; ++b) az[b] = lane_base + (unsigned)((2 + (wn >> 1)) * UNIT * 16 + 32 * ((4 * (wn & 1) + b) ^ t));
+  // bias selector for fragment ni: lanes whose MFMA row r lies in [4 ni, 4 ni + 4) hold ones
+  const unsigned one2 = __is_same(T, f16) ? 0x3C003C00u : 0x3F803F80u;
+
+#define CUM_TR(dst, reg, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "={" reg "}"(dst) : "v"(addr) : "memory")
+#define CUM_MFMA(a, b, c)                                                                                      \
+  do {                                                                                                         \
+    if constexpr (__is_same(T, f16))                                                                           \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0); \
+    else                                                                                                       \
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0); \
+  } while (0)
+#define CUM_HALFQ(h, nlo, ks)                                                                                  \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                           \
+      _Pragma("unroll") for (int ki = 0; ki < 4; ++ki)                                                         \
+        CUM_MFMA(xf[ks][4 * (h) + ki], zf[ks][ni], acc[h][(nlo) + ni][ki]);                                    \
+  } while (0)
+#define CUM_BIAS(nlo)                                                                                          \
+  do {                                                                                                         \
+    if (bias_wave) {                                                                                           \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                       \
+        const unsigned sv = q == (nlo) + ni ? one2 : 0u;                                                       \
+        const u32x4 sel = u32x4{sv, sv, sv, sv};                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) CUM_MFMA(sel, zf[ks][ni], bacc);                      \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+
+  // Fragments are pinned to physical registers as in gemm_tn8_kernel (x (ks, blk): v[176 + 32 ks + 4 blk ..+3], dZ (ks, ni):
+  // v[240 + 8 ks + 4 ni ..+3]).  Schedule: gemm_nt9_kernel's ping-pong (gemm.hip) -- eight slots per reduction step, load
+  // and compute alternating, waves 4-7 (wk = 1, the X1 unit) one slot behind waves 0-3 (wk = 0, X0):
+  //   L1: X columns 0-63 of the wave's half + dZ columns 0-31 (24 reads)   C1: (k 0-63,  n 0-31) + bias MFMAs
+  //   L2: X columns 64-127 (16 reads)                                      C2: (k 64-127, n 0-31)
+  //   L3: dZ columns 32-63 (8 reads)                                       C3: (k 64-127, n 32-63)
+  //   L4: -                                                                C4: (k 0-63,  n 32-63) + bias MFMAs
+  // LDS-DMA of step s + 2: group 0: X0 in L3, X1 in L4, Z0 + Z1 in the next step's L1; group 1: X0 + X1 in L3, Z0 + Z1 in L4.
+#define CUM_BAR()                               \
+  do {                                          \
+    __builtin_amdgcn_sched_barrier(0);          \
+    asm volatile("s_barrier" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);          \
+  } while (0)
+#define CUM_QUADT(h, nlo)                \
+  do {                                   \
+    __builtin_amdgcn_s_setprio(1);       \
+    CUM_HALFQ(h, nlo, 0);                \
+    CUM_HALFQ(h, nlo, 1);                \
+    __builtin_amdgcn_s_setprio(0);       \
+  } while (0)
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // step 0 landed (and zeroed where ragged); step 1 in flight
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CUM_BAR();
+  if (wk != 0) CUM_BAR();                                                // group 1 runs one slot behind
+  for (int s = 0; s < nk; ++s) {
+    const int par = s & 1;
+    const bool more1 = s + 1 < nk, more2 = s + 2 < nk;
+    u32x2 xl[2][8], xh[2][8], zl[2][2], zh[2][2];
+    u32x4 xf[2][8], zf[2][2];
+    // ---- L1
+    CUM_TR(zl[0][0], "v[240:241]", az[0], 0); CUM_TR(zh[0][0], "v[242:243]", az[0], 1024);  CUM_TR(zl[0][1], "v[244:245]", az[1], 0); CUM_TR(zh[0][1], "v[246:247]", az[1], 1024);
+    CUM_TR(xl[0][0], "v[176:177]", ax[0], 0); CUM_TR(xh[0][0], "v[178:179]", ax[0], 1024);  CUM_TR(xl[0][1], "v[180:181]", ax[1], 0); CUM_TR(xh[0][1], "v[182:183]", ax[1], 1024);
+    CUM_TR(xl[0][2], "v[184:185]", ax[2], 0); CUM_TR(xh[0][2], "v[186:187]", ax[2], 1024);  CUM_TR(xl[0][3], "v[188:189]", ax[3], 0); CUM_TR(xh[0][3], "v[190:191]", ax[3], 1024);
+    CUM_TR(zl[1][0], "v[248:249]", az[0], 8192); CUM_TR(zh[1][0], "v[250:251]", az[0], 9216);  CUM_TR(zl[1][1], "v[252:253]", az[1], 8192); CUM_TR(zh[1][1], "v[254:255]", az[1], 9216);
+    CUM_TR(xl[1][0], "v[208:209]", ax[0], 8192); CUM_TR(xh[1][0], "v[210:211]", ax[0], 9216);  CUM_TR(xl[1][1], "v[212:213]", ax[1], 8192); CUM_TR(xh[1][1], "v[214:215]", ax[1], 9216);
+    CUM_TR(xl[1][2], "v[216:217]", ax[2], 8192); CUM_TR(xh[1][2], "v[218:219]", ax[2], 9216);  CUM_TR(xl[1][3], "v[220:221]", ax[3], 8192); CUM_TR(xh[1][3], "v[222:223]", ax[3], 9216);
+    if (wk == 0 && s >= 1 && more1) {
+      CUM_STAGE(2, s + 1, par ^ 1);
+      CUM_STAGE(3, s + 1, par ^ 1);
+    }
+    CUM_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "={v[240:243]}"(zf[0][0]), "={v[244:247]}"(zf[0][1]), "={v[248:251]}"(zf[1][0]), "={v[252:255]}"(zf[1][1]),
+                   "={v[176:179]}"(xf[0][0]), "={v[180:183]}"(xf[0][1]), "={v[184:187]}"(xf[0][2]), "={v[188:191]}"(xf[0][3]),
+                   "={v[208:211]}"(xf[1][0]), "={v[212:215]}"(xf[1][1]), "={v[216:219]}"(xf[1][2]), "={v[220:223]}"(xf[1][3])
+                 : "{v[240:241]}"(zl[0][0]), "{v[242:243]}"(zh[0][0]), "{v[244:245]}"(zl[0][1]), "{v[246:247]}"(zh[0][1]),
+                   "{v[248:249]}"(zl[1][0]), "{v[250:251]}"(zh[1][0]), "{v[252:253]}"(zl[1][1]), "{v[254:255]}"(zh[1][1]),
+                   "{v[176:177]}"(xl[0][0]), "{v[178:179]}"(xh[0][0]), "{v[180:181]}"(xl[0][1]), "{v[182:183]}"(xh[0][1]),
+                   "{v[184:185]}"(xl[0][2]), "{v[186:187]}"(xh[0][2]), "{v[188:189]}"(xl[0][3]), "{v[190:191]}"(xh[0][3]),
+                   "{v[208:209]}"(xl[1][0]), "{v[210:211]}"(xh[1][0]), "{v[212:213]}"(xl[1][1]), "{v[214:215]}"(xh[1][1]),
+                   "{v[216:217]}"(xl[1][2]), "{v[218:219]}"(xh[1][2]), "{v[220:221]}"(xl[1][3]), "{v[222:223]}"(xh[1][3]) : "memory");
+    CUM_QUADT(0, 0);                                                       // C1
+    CUM_BIAS(0);
+    CUM_BAR();
+    // ---- L2
+    CUM_TR(xl[0][4], "v[192:193]", ax[4], 0); CUM_TR(xh[0][4], "v[194:195]", ax[4], 1024);  CUM_TR(xl[0][5], "v[196:197]", ax[5], 0); CUM_TR(xh[0][5], "v[198:199]", ax[5], 1024);
+    CUM_TR(xl[0][6], "v[200:201]", ax[6], 0); CUM_TR(xh[0][6], "v[202:203]", ax[6], 1024);  CUM_TR(xl[0][7], "v[204:205]", ax[7], 0); CUM_TR(xh[0][7], "v[206:207]", ax[7], 1024);
+    CUM_TR(xl[1][4], "v[224:225]", ax[4], 8192); CUM_TR(xh[1][4], "v[226:227]", ax[4], 9216);  CUM_TR(xl[1][5], "v[228:229]", ax[5], 8192); CUM_TR(xh[1][5], "v[230:231]", ax[5], 9216);
+    CUM_TR(xl[1][6], "v[232:233]", ax[6], 8192); CUM_TR(xh[1][6], "v[234:235]", ax[6], 9216);  CUM_TR(xl[1][7], "v[236:237]", ax[7], 8192); CUM_TR(xh[1][7], "v[238:239]", ax[7], 9216);
+    CUM_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "={v[192:195]}"(xf[0][4]), "={v[196:199]}"(xf[0][5]), "={v[200:203]}"(xf[0][6]), "={v[204:207]}"(xf[0][7]), "={v[224:227]}"(xf[1][4]), "={v[228:231]}"(xf[1][5]), "={v[232:235]}"(xf[1][6]), "={v[236:239]}"(xf[1][7])
+                 : "{v[192:193]}"(xl[0][4]), "{v[194:195]}"(xh[0][4]),
+                   "{v[196:197]}"(xl[0][5]), "{v[198:199]}"(xh[0][5]),
+                   "{v[200:201]}"(xl[0][6]), "{v[202:203]}"(xh[0][6]),
+                   "{v[204:205]}"(xl[0][7]), "{v[206:207]}"(xh[0][7]),
+                   "{v[224:225]}"(xl[1][4]), "{v[226:227]}"(xh[1][4]),
+                   "{v[228:229]}"(xl[1][5]), "{v[230:231]}"(xh[1][5]),
+                   "{v[232:233]}"(xl[1][6]), "{v[234:235]}"(xh[1][6]),
+                   "{v[236:237]}"(xl[1][7]), "{v[238:239]}"(xh[1][7]) : "memory");
+    CUM_QUADT(1, 0);                                                       // C2
+    CUM_BAR();
+    // ---- L3: dZ fragments of n columns 32-63 (same registers as columns 0-31); the X units are free: step s + 2
+    CUM_TR(zl[0][0], "v[240:241]", az[2], 0); CUM_TR(zh[0][0], "v[242:243]", az[2], 1024);  CUM_TR(zl[0][1], "v[244:245]", az[3], 0); CUM_TR(zh[0][1], "v[246:247]", az[3], 1024);
+    CUM_TR(zl[1][0], "v[248:249]", az[2], 8192); CUM_TR(zh[1][0], "v[250:251]", az[2], 9216);  CUM_TR(zl[1][1], "v[252:253]", az[3], 8192); CUM_TR(zh[1][1], "v[254:255]", az[3], 9216);
+    if (more2) {
+      CUM_STAGE(0, s + 2, par);
+      if (wk != 0) CUM_STAGE(1, s + 2, par);
+    }
+    CUM_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "={v[240:243]}"(zf[0][0]), "={v[244:247]}"(zf[0][1]), "={v[248:251]}"(zf[1][0]), "={v[252:255]}"(zf[1][1])
+                 : "{v[240:241]}"(zl[0][0]), "{v[242:243]}"(zh[0][0]),
+                   "{v[244:245]}"(zl[0][1]), "{v[246:247]}"(zh[0][1]),
+                   "{v[248:249]}"(zl[1][0]), "{v[250:251]}"(zh[1][0]),
+                   "{v[252:253]}"(zl[1][1]), "{v[254:255]}"(zh[1][1]) : "memory");
+    CUM_QUADT(1, 2);                                                       // C3
+    CUM_BAR();
+    // ---- L4
+    if (wk == 0) {
+      if (more2) CUM_STAGE(1, s + 2, par);
+    } else {
+      if (more1) {
+        if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (more2) {
+        CUM_STAGE(2, s + 2, par);
+        CUM_STAGE(3, s + 2, par);
+      }
+    }
+    CUM_BAR();
+    CUM_QUADT(0, 2);                                                       // C4
+    CUM_BIAS(2);
+    if (wk == 0 && more1) {
+      if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CUM_BAR();
+    const unsigned flip = par ? 0u - 65536u : 65536u;                   // the other parity's units
+#pragma unroll
+    for (int b = 0; b < 8; ++b) ax[b] += flip;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) az[b] += flip;
+  }
+  if (wk == 0) CUM_BAR();                                                // group 1's last slot
+#undef CUM_BAR
+#undef CUM_QUADT
+#undef CUM_TR
+#undef CUM_MFMA
+#undef CUM_HALFQ
+#undef CUM_BIAS
+#undef CUM_STAGE
+
+  // ---- slab store: lane holds D[k = kb + 4g + j][n = nb + r]
+  float *slab = p.slab + (int64_t)sp * p.Np * p.Kp;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = n0 + wn * 64 + ni * 16 + r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ki = 0; ki < 4; ++ki) {
+        const int k = k0 + wk * 128 + h * 64 + ki * 16 + 4 * g;
+        *reinterpret_cast<float4 *>(slab + (int64_t)n * p.Kp + k) =
+            make_float4(acc[h][ni][ki][0], acc[h][ni][ki][1], acc[h][ni][ki][2], acc[h][ni][ki][3]);
+      }
+  }
+  // selector rows 4 ni .. 4 ni + 3 (held by lane group g = ni) carry the column sums of fragment ni
+  if (bias_wave) p.bslab[(int64_t)sp * p.Np + n0 + wn * 64 + 16 * g + r] = bacc[0];
+}
+
 // Slab reduction, parallel over outputs AND over slabs, fixed summation order (deterministic).
 //   in : [S][rows][ld_in] f32        out: [gridDim.y][rows][ld_out] partial sums of S / gridDim.y slabs each
 // A workgroup = 64 float4 outputs x 4 slab lanes; lanes are combined through LDS.  One launch carries two jobs (the
@@ -644,7 +912,12 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   if (tn_use8(M, N, K, dtype)) {
     const int items = (N / 256) * (K / 256) * S;
     const dim3 grid8(8 * ((items + 7) / 8)), block8(512);
-    if (dtype == CUM_BF16)
+    static const int tn9 = [] { const char *e = getenv("CUM_TN9"); return e ? atoi(e) : 1; }();   // "0": gemm_tn8_kernel (A/B)
+    if (tn9 && dtype == CUM_BF16)
+      hipLaunchKernelGGL(gemm_tn9_kernel<__bf16>, grid8, block8, 0, st, p);
+    else if (tn9)
+      hipLaunchKernelGGL(gemm_tn9_kernel<f16>, grid8, block8, 0, st, p);
+    else if (dtype == CUM_BF16)
       hipLaunchKernelGGL(gemm_tn8_kernel<__bf16>, grid8, block8, 0, st, p);
     else
       hipLaunchKernelGGL(gemm_tn8_kernel<f16>, grid8, block8, 0, st, p);

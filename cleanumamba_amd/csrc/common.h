@@ -27,6 +27,20 @@ extern "C" void cum_set_error(const char *msg);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Experiment switches.  The shipped library (plain `make`) reads NO environment variable and carries only the kernels the
+// dispatch rules below choose: every alternative kernel kept for same-box A/B runs, and every CUM_* knob that selects
+// one, exists only in a `make AB=1` build (-DCUM_AB).  cum_knob(name, dflt) is the knob's value there and the constant
+// `dflt` here.
+#ifdef CUM_AB
+#include <stdlib.h>
+static inline int64_t cum_knob(const char *name, int64_t dflt) {
+  const char *e = getenv(name);
+  return e ? atoll(e) : dflt;
+}
+#else
+#define cum_knob(name, dflt) ((int64_t)(dflt))
+#endif
+
 namespace cum {
 
 typedef _Float16 f16;

@@ -51,7 +51,6 @@ struct GemmParams {
   int64_t lda, ldw, ldc, ldr, ldz, ldy;
   int gate_only;           // GLU / GLU_BWD: aux holds only the gate pre-activation b ([M][ldz], output-column order)
   int allow_split_k;       // few-tile launches may use gemm_nt_splitk_kernel
-  int var;                 // experiment switch of gemm_nt9_kernel (CUM_NT9=1|2|3)
   int mask_bits;           // RELU: aux receives the SIGN (value > 0) of each element instead of the activation, four
                            // consecutive channels per byte (low nibble; byte index (m * ld + n) / 4) -- what a lane
                            // holds after the MFMA, so no cross-lane packing; MASK: res is such an array.
@@ -849,6 +848,7 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(si
     nt_epilogue<T, EPI>(p, &acc, bv, m0, n0, wm, wn, g, r);
 }
 
+#ifdef CUM_AB   // gemm_nt8_kernel: the predecessor of gemm_nt9_kernel, kept for same-box A/B runs (CUM_NT9=0)
 // ---------------------------------------------------------------- 256 x 256 tile, 8 waves, DMA in flight across barriers
 // The 16-wave 256x256 kernel above waits `vmcnt(0)` + `__syncthreads()` at the top of every K-step: one LDS-DMA stage in
 // flight, every wave stalled while it lands, 16 waves x 64x64 sub-tiles (0.5 fragment reads per MFMA).  This variant
@@ -1058,6 +1058,8 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GemmParams p) {
                                 reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
 }
 
+#endif  // CUM_AB
+
 // ---------------------------------------------------------------- 256 x 256 tile, 8 waves, two wave groups in ping-pong
 // Same tile, units, DMA scheme and epilogues as gemm_nt8_kernel; what changes is WHEN the two halves of the workgroup do
 // what.  In gemm_nt8_kernel all eight waves run the same phase at the same time: both waves of a SIMD issue their 20
@@ -1076,6 +1078,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const GemmParams p) {
 // LDS-DMA of K-tile t + 2 into the freed units: group 0 issues A0 in L3, A1 in L4, W0 + W1 in the next K-tile's L1;
 // group 1 issues A0 + A1 in L3, W0 + W1 in L4.  One counted wait per K-tile and wave (end of C4 / in L4): vmcnt(4) = K-tile
 // t + 1 has landed, the four A instructions of K-tile t + 2 stay in flight; the barrier behind it publishes K-tile t + 1.
+// (Spreading the DMA issue evenly over the load slots -- two instructions in each -- measured the same to +-2 %.)
+// Measured on MI355X (tools/bench_gemm.py, bf16): enc3-enc6 conv 0.84 / 1.01 / 1.09 / 1.08 -> 0.90 / 1.09 / 1.20 / 1.17
+// PFLOP/s, plain 8192^3 1.14 -> 1.22-1.25; SQ counters on the plain GEMM (tools/pmc_gemm_plain.sh): matrix pipe busy
+// 59 -> 68 % of the kernel's cycles while the chip's clock under this load fell 1.58 -> 1.51 GHz (power: part of every
+// gain in MFMA density is given back as clock, MI355X_MICROARCH.md "DVFS give-back").
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit element types only");
@@ -1146,16 +1153,11 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
   nt_load_bias(p, n0, wc, g, bv);
 
   const int nk = p.K / BK;
-  const int var = p.var;
 #pragma unroll
   for (int u = 0; u < 4; ++u) CUM_STAGE(u, 0, 0);
   if (nk > 1) {
-    CUM_STAGE(0, 1, 1);
-    CUM_STAGE(1, 1, 1);
-    if (var != 3) {
-      CUM_STAGE(2, 1, 1);
-      CUM_STAGE(3, 1, 1);
-    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) CUM_STAGE(u, 1, 1);
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)lds_all;
   unsigned aA[2], aW[2];
@@ -1194,10 +1196,8 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
     __builtin_amdgcn_s_setprio(0);       \
   } while (0)
 
-  if (nk > 1) {
-    if (var == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile 0 landed; what was issued of K-tile 1 stays in flight
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // K-tile 0 landed; K-tile 1 stays in flight
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   CUM_BAR();                                                           // K-tile 0 is visible to every wave
   if (wr != 0) CUM_BAR();                                              // group 1 runs one slot behind group 0
   u32x4 af[2][8], wf[2][2];
@@ -1211,11 +1211,9 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
     CUM_DSR(af[0][0], a0, 0);     CUM_DSR(af[0][1], a0, 2048);  CUM_DSR(af[0][2], a0, 4096);  CUM_DSR(af[0][3], a0, 6144);
     CUM_DSR(wf[1][0], w1, 0);     CUM_DSR(wf[1][1], w1, 2048);
     CUM_DSR(af[1][0], a1, 0);     CUM_DSR(af[1][1], a1, 2048);  CUM_DSR(af[1][2], a1, 4096);  CUM_DSR(af[1][3], a1, 6144);
-    if (var == 3) {
-      if (more1) CUM_STAGE(2, kt + 1, par ^ 1);
-    } else if (wr == 0 && kt >= 1 && more1) {
+    if (wr == 0 && kt >= 1 && more1) {
       CUM_STAGE(2, kt + 1, par ^ 1);
-      if (var != 2) CUM_STAGE(3, kt + 1, par ^ 1);
+      CUM_STAGE(3, kt + 1, par ^ 1);
     }
     CUM_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -1226,11 +1224,6 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
     // ---- L2: A rows 64-127
     CUM_DSR(af[0][4], a0, 8192);  CUM_DSR(af[0][5], a0, 10240); CUM_DSR(af[0][6], a0, 12288); CUM_DSR(af[0][7], a0, 14336);
     CUM_DSR(af[1][4], a1, 8192);  CUM_DSR(af[1][5], a1, 10240); CUM_DSR(af[1][6], a1, 12288); CUM_DSR(af[1][7], a1, 14336);
-    if (var == 3) {
-      if (more1) CUM_STAGE(3, kt + 1, par ^ 1);
-    } else if (var == 2 && wr == 0 && kt >= 1 && more1) {
-      CUM_STAGE(3, kt + 1, par ^ 1);
-    }
     CUM_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(af[0][4]), "+v"(af[0][5]), "+v"(af[0][6]), "+v"(af[0][7]), "+v"(af[1][4]), "+v"(af[1][5]),
@@ -1241,20 +1234,14 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
     CUM_DSR(wf[0][0], w0, 4096);  CUM_DSR(wf[0][1], w0, 6144);  CUM_DSR(wf[1][0], w1, 4096);  CUM_DSR(wf[1][1], w1, 6144);
     if (more2) {
       CUM_STAGE(0, kt + 2, par);
-      if (wr != 0 && var != 3) CUM_STAGE(1, kt + 2, par);
+      if (wr != 0) CUM_STAGE(1, kt + 2, par);
     }
     CUM_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]) : : "memory");
     CUM_QUAD(1, 2);                                                       // C3
     CUM_BAR();
     // ---- L4: no reads.  group 0: A1 of K-tile kt + 2; group 1: K-tile kt + 1 must have landed, then W of K-tile kt + 2
-    if (var == 3) {
-      if (wr != 0 && more1) {                      // group 1's wait sits in front of its last DMA of the K-tile
-        if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      if (more2) CUM_STAGE(1, kt + 2, par);
-    } else if (wr == 0) {
+    if (wr == 0) {
       if (more2) CUM_STAGE(1, kt + 2, par);
     } else {
       if (more1) {
@@ -1490,6 +1477,7 @@ __global__ void colsum_stage2(const float *__restrict__ part, int nparts, int n,
   out[c] = s;
 }
 
+#ifdef CUM_AB
 template <typename T>
 static int launch_gemm_nt8(const GemmParams &p, int epi, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
@@ -1507,21 +1495,7 @@ static int launch_gemm_nt8(const GemmParams &p, int epi, hipStream_t st) {
   return CUM_OK;
 }
 
-static int nt8_enabled() {
-  static const int v = [] {
-    const char *e = getenv("CUM_NT8");     // "0": the 16-wave 256x256 kernel (A/B runs)
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
-  return v;
-}
-
-static int nt9_enabled() {
-  static const int v = [] {
-    const char *e = getenv("CUM_NT9");     // "0": gemm_nt8_kernel (A/B); "2", "3": other DMA placements (measured equal)
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
+#endif  // CUM_AB
 
 template <typename T>
 static int launch_gemm_nt9(const GemmParams &p, int epi, hipStream_t st) {
@@ -1555,20 +1529,12 @@ static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   return CUM_OK;
 }
 
-// CUM_NT_TILE=128|256|512 pins the tile (128x128 / 256x128 / 256x256) for experiments; default: heuristic below.
-static int nt_tile_override() {
-  static const int v = [] {
-    const char *e = getenv("CUM_NT_TILE");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
 template <typename T>
 static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
   const int64_t mb256 = (p.M + 255) / 256;
   const int64_t tiles_256x256 = mb256 * ((p.N + 255) / 256), tiles_256x128 = mb256 * ((p.N + 127) / 128);
-  int tile = nt_tile_override();
+  // AB build: CUM_NT_TILE=64|128|256|512 pins the tile (split-K 64x64 / 128x128 / 256x128 / 256x256)
+  int tile = (int)cum_knob("CUM_NT_TILE", 0);
   // few tiles and a K axis worth splitting: the small-M kernel (64x64 tiles, K split over the four waves)
   const int64_t tiles_128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
   const int bk = sizeof(T) == 2 ? 64 : 32;
@@ -1578,24 +1544,33 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
     return launch_gemm_splitk<T>(p, epi, st);
   if (tile == 64) tile = 128;
   if (!tile) {
-    // 256x256 (one workgroup per CU) once it fills the chip and N wastes little of the 256-wide tile; 256-row
-    // tiles while they still give every CU >= 2 workgroups per XCD-round; K >= 256 so the saved weight traffic
-    // matters (the outer layers are bound by their activation traffic, where the tile shape is irrelevant)
-    // (16-bit only: the f32 instantiation of the 1024-thread tile is capped at 128 VGPRs and spills)
-    // ... and enough work per byte for one workgroup per CU to pay off: at N K / (N + K) < 256 (the 256 / 512-channel
-    // layers with 320 512 rows) four 128 x 128 workgroups per CU are 5-18 % faster (same-box per-call table)
+    // 256x256 (one workgroup per CU) once it fills the chip and N wastes little of the 256-wide tile; K >= 256 so the
+    // saved weight traffic matters (the outer layers are bound by their activation traffic, where the tile shape is
+    // irrelevant) ... and enough work per byte for one workgroup per CU to pay off: at N K / (N + K) < 256 (the 256 /
+    // 512-channel layers with 320 512 rows) four 128 x 128 workgroups per CU are 5-18 % faster (same-box per-call table)
     if (sizeof(T) == 2 && p.K >= 256 && tiles_256x256 >= 224 && p.N % 256 == 0 &&
         (int64_t)p.N * p.K >= 256 * (int64_t)(p.N + p.K)) tile = 512;
-    // (16-bit types: the 128 x 128 kernel routes its epilogue through LDS, which the outer, HBM-bound layers that
-    //  used to take the 256 x 128 tile gain more from than from the taller tile)
+    // f32 (the parity path): 256-row tiles while they still give every CU >= 2 workgroups per XCD-round.  16-bit types
+    // never take this tile: the 128 x 128 kernel routes its epilogue through LDS, which the outer, HBM-bound layers gain
+    // more from than from the taller tile.
     else if (sizeof(T) == 4 && p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
     else tile = 128;
   }
-  if (tile == 512 && sizeof(T) == 2 && nt9_enabled()) return launch_gemm_nt9<T>(p, epi, st);
-  if (tile == 512 && sizeof(T) == 2 && nt8_enabled()) return launch_gemm_nt8<T>(p, epi, st);
-  if (tile == 512) return launch_gemm_tile<T, 256, 256>(p, epi, st);
-  if (tile == 256) return launch_gemm_tile<T, 256, 128>(p, epi, st);
-  return launch_gemm_tile<T, 128, 128>(p, epi, st);
+  if constexpr (sizeof(T) == 2) {
+    if (tile == 512) {
+#ifdef CUM_AB
+      if (cum_knob("CUM_NT9", 1) == 0) return launch_gemm_nt8<T>(p, epi, st);
+#endif
+      return launch_gemm_nt9<T>(p, epi, st);
+    }
+#ifdef CUM_AB
+    if (tile == 256) return launch_gemm_tile<T, 256, 128>(p, epi, st);
+#endif
+    return launch_gemm_tile<T, 128, 128>(p, epi, st);
+  } else {
+    if (tile == 256 || tile == 512) return launch_gemm_tile<T, 256, 128>(p, epi, st);
+    return launch_gemm_tile<T, 128, 128>(p, epi, st);
+  }
 }
 
 }  // namespace cum
@@ -1628,15 +1603,11 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
   p.gate_only = d->gate_only;
   p.mask_bits = d->mask_bits;
   p.allow_split_k = d->allow_split_k;
-  p.var = nt9_enabled();
   CUM_REQUIRE(!d->mask_bits || (d->epilogue == EPI_RELU && aux) || d->epilogue == EPI_MASK,
               "gemm: mask_bits applies to RELU (aux = sign array) and MASK (res = sign array)");
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;
   p.zero_head = d->zero_head; p.zero_tail = d->zero_tail;
-  {
-    static const int rows = [] { const char *e = getenv("CUM_NT8_ROWS"); return (e && e[0] == '0') ? 0 : 1; }();
-    p.rows_epilogue = rows;
-  }
+  p.rows_epilogue = (int)cum_knob("CUM_NT8_ROWS", 1);      // AB build: 0 = the generic GLU-backward epilogue
   if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);
   if (d->dtype == CUM_F16) return launch_gemm<f16>(p, d->epilogue, (hipStream_t)stream);
   return launch_gemm<float>(p, d->epilogue, (hipStream_t)stream);

@@ -17,7 +17,6 @@
 // lane ends with 4 consecutive k of one output row n: 16-byte slab stores.
 // Column sums of dZ (the bias gradient) are accumulated from the registers that stage
 // dZ, for free, by the workgroups of the first k tile.
-#include <stdlib.h>
 #include "common.h"
 
 namespace cum {
@@ -254,6 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+#ifdef CUM_AB   // gemm_tn8_kernel: the predecessor of gemm_tn9_kernel (same pipeline, all waves in one phase), CUM_TN9=0
 template <typename T>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnParams p) {
   static_assert(sizeof(T) == 2, "16-bit element types only");
@@ -498,6 +498,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnParams p) {
   // selector rows 4 ni .. 4 ni + 3 (held by lane group g = ni) carry the column sums of fragment ni
   if (bias_wave) p.bslab[(int64_t)sp * p.Np + n0 + wn * 64 + 16 * g + r] = bacc[0];
 }
+
+#endif  // CUM_AB
 
 template <typename T>
 __global__ __launch_bounds__(512) void gemm_tn9_kernel(const TnParams p) {
@@ -827,10 +829,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const ReduceJob j0, cons
 
 using namespace cum;
 
-static int tn8_enabled() {
-  static const int on = [] { const char *e = getenv("CUM_TN8"); return e ? atoi(e) : 1; }();
-  return on;
-}
+static int tn8_enabled() { return (int)cum_knob("CUM_TN8", 1); }      // AB build: 0 = the 128 x 128 kernel everywhere
 
 // 256 x 256 tiles (gemm_tn8_kernel): 16-bit types, N and K multiples of 256.  One workgroup per CU, so the split count is
 // the largest that keeps tiles x splits within ONE resident round of 256 workgroups.
@@ -839,7 +838,7 @@ static bool tn_use8(int64_t M, int32_t N, int32_t K, int32_t dtype) {
 }
 
 static void tn_plan(int64_t M, int32_t N, int32_t K, int32_t dtype, int *Np, int *Kp, int *S, int *rps) {
-  static const int force = [] { const char *e = getenv("CUM_TN_SPLITS"); return e ? atoi(e) : 0; }();
+  const int force = (int)cum_knob("CUM_TN_SPLITS", 0);             // AB build: pins the split count
   if (tn_use8(M, N, K, dtype)) {
     *Np = N;
     *Kp = K;
@@ -912,15 +911,16 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   if (tn_use8(M, N, K, dtype)) {
     const int items = (N / 256) * (K / 256) * S;
     const dim3 grid8(8 * ((items + 7) / 8)), block8(512);
-    static const int tn9 = [] { const char *e = getenv("CUM_TN9"); return e ? atoi(e) : 1; }();   // "0": gemm_tn8_kernel (A/B)
-    if (tn9 && dtype == CUM_BF16)
+#ifdef CUM_AB
+    if (cum_knob("CUM_TN9", 1) == 0) {
+      if (dtype == CUM_BF16) hipLaunchKernelGGL(gemm_tn8_kernel<__bf16>, grid8, block8, 0, st, p);
+      else hipLaunchKernelGGL(gemm_tn8_kernel<f16>, grid8, block8, 0, st, p);
+    } else
+#endif
+    if (dtype == CUM_BF16)
       hipLaunchKernelGGL(gemm_tn9_kernel<__bf16>, grid8, block8, 0, st, p);
-    else if (tn9)
-      hipLaunchKernelGGL(gemm_tn9_kernel<f16>, grid8, block8, 0, st, p);
-    else if (dtype == CUM_BF16)
-      hipLaunchKernelGGL(gemm_tn8_kernel<__bf16>, grid8, block8, 0, st, p);
     else
-      hipLaunchKernelGGL(gemm_tn8_kernel<f16>, grid8, block8, 0, st, p);
+      hipLaunchKernelGGL(gemm_tn9_kernel<f16>, grid8, block8, 0, st, p);
   } else if (dtype == CUM_BF16)
     hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, block, 0, st, p);
   else if (dtype == CUM_F16)

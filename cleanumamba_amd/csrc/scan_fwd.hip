@@ -664,58 +664,47 @@ __global__ void state_update_kernel(int batch, int dim, int N, float *__restrict
   out[i] = y;
 }
 
-static int scan_fwd_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("CUM_SCAN_FWD_LDS");   // "0" selects the scalar-load variant (kept for A/B runs)
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
-static int scan_small_variant() {
-  static const int v = [] {
-    const char *e = getenv("CUM_SCAN_SMALL");     // d_state <= 16: "0" the NW-wave kernels, "2" the one-wave kernel (A/B)
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-
 template <int NW, typename TIO>
 static int launch_fwd_io(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
   if constexpr (NW <= 2) {
-    const int v = scan_small_variant();
-    if (v == 2) {                        // one wave per workgroup, everything in one wave
+    // d_state <= 16.  Measured on MI355X (D = 2048, L = 2499, f32 I/O; tools/bench_scan.py): the wave-specialised form
+    // (producer wave + NW consumer waves per workgroup) wins while the grid cannot give every SIMD a wave of its own --
+    // up to 1024 workgroups at d_state <= 8, 512 at d_state <= 16; beyond that one wave per workgroup holding all states.
+    // AB build: CUM_SCAN_SMALL=0 the NW-wave kernel below, 2 always the one-wave kernel; CUM_SCAN_WS_MAX the threshold.
+    const int v = (int)cum_knob("CUM_SCAN_SMALL", 1);
+    const int64_t ws_max = cum_knob("CUM_SCAN_WS_MAX", NW == 1 ? 1024 : 512);
+    if (v == 2 || (v == 1 && (int64_t)grid.x * grid.y > ws_max)) {
       hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO>), grid, dim3(64), 0, st, p);
       CUM_CHECK_LAUNCH();
       return CUM_OK;
     }
-    // measured on MI355X (D = 2048, L = 2499, f32 I/O; tools/bench_scan.py): the specialised form wins while the grid
-    // cannot give every SIMD a wave of its own -- up to 1024 workgroups at d_state <= 8, 512 at d_state <= 16
-    static const int64_t ws_max = [] { const char *e = getenv("CUM_SCAN_WS_MAX"); return e ? atoll(e) : (NW == 1 ? 1024LL : 512LL); }();
-    if (v == 1 && (int64_t)grid.x * grid.y > ws_max) {   // enough workgroups to fill the chip with one-wave workgroups
-      hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO>), grid, dim3(64), 0, st, p);
-      CUM_CHECK_LAUNCH();
-      return CUM_OK;
-    }
-    if (v == 1) {                        // few workgroups: producer wave + NW consumer waves each
+#ifdef CUM_AB
+    if (v == 1)
+#endif
+    {
       hipLaunchKernelGGL((scan_fwd_ws_kernel<NW, TIO>), grid, dim3((NW + 1) * 64), 0, st, p);
       CUM_CHECK_LAUNCH();
       return CUM_OK;
     }
   }
-  if (scan_fwd_variant() == 1) {
-    hipLaunchKernelGGL((scan_fwd_lds_kernel<NW, TIO>), grid, block, 0, st, p);
+#ifndef CUM_AB
+  if constexpr (NW > 2)     // (the NW-wave kernels are not even instantiated for d_state <= 16 outside an AB build)
+#endif
+  {
+#ifdef CUM_AB   // CUM_SCAN_FWD_LDS=0: B_t / C_t through the constant address space (s_load) instead of the LDS tile
+  if (cum_knob("CUM_SCAN_FWD_LDS", 1) == 0) {
+    if (p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW)
+      hipLaunchKernelGGL((scan_fwd_kernel<NW, true, TIO>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((scan_fwd_kernel<NW, false, TIO>), grid, block, 0, st, p);
     CUM_CHECK_LAUNCH();
     return CUM_OK;
   }
-  const bool fast = p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW;
-  if (fast)
-    hipLaunchKernelGGL((scan_fwd_kernel<NW, true, TIO>), grid, block, 0, st, p);
-  else
-    hipLaunchKernelGGL((scan_fwd_kernel<NW, false, TIO>), grid, block, 0, st, p);
-  CUM_CHECK_LAUNCH();
+#endif
+    hipLaunchKernelGGL((scan_fwd_lds_kernel<NW, TIO>), grid, block, 0, st, p);
+    CUM_CHECK_LAUNCH();
+  }
   return CUM_OK;
 }
 

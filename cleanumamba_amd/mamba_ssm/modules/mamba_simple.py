@@ -80,6 +80,156 @@ class _ProjFn(torch.autograd.Function):
         return dx, dw, None
 
 
+class _MambaInnerFn(torch.autograd.Function):
+    """xz (B, L, 2 D) -> y (B, L, D): everything of upstream Mamba.forward between in_proj and out_proj -- split, causal
+    depthwise conv + SiLU, x_proj, dt_proj, selective scan with the z gate (reached from
+    src/network/CleanUMamba.py:289-290) -- as ONE autograd node on the library's kernels.  The arithmetic is that of the
+    separate Functions (causal_conv1d_fn, _ProjFn, selective_scan_fn); what the single node removes is autograd's glue
+    between them: the slice-backward / cat pairs of the (x | z) and (dt | B | C) splits, the float casts of B and C and
+    their backward, the -exp(A_log) chain, and one AccumulateGrad add per parameter -- the kernels write dx and dz
+    straight into the two halves of ONE d(xz) buffer, d(dt) / dB / dC into one d(x_dbl) buffer, and the parameter
+    gradients into the flat gradient buffer (training/flat_optim.py) when it is fresh."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, xz, conv_w, conv_b, xw, dtw, dt_bias, A_log, Dp, cd, save):
+        import ctypes
+        from ...causal_conv1d import _shape as conv_shape
+        from ...network import convstack as cs
+        from ..ops import selective_scan_interface as ssi
+        lib = hip.lib()
+        xz = xz if xz.dtype == cd else xz.to(cd)
+        if not xz.is_contiguous():
+            xz = xz.contiguous()
+        Bn, L, D2 = xz.shape
+        Dn = D2 // 2
+        M = Bn * L
+        R = dtw.shape[1]
+        N = (xw.shape[0] - R) // 2
+        dev = xz.device
+        xv, zv = xz[..., :Dn].transpose(1, 2), xz[..., Dn:].transpose(1, 2)        # (B, D, L) views, channel stride 1
+        w2 = conv_w.detach().reshape(Dn, -1).contiguous().float()
+        cb = conv_b.detach().float().contiguous()
+        xc = torch.empty(Bn, L, Dn, dtype=cd, device=dev)
+        xcT = xc.transpose(1, 2)
+        sc = conv_shape(xv, xcT, w2.shape[1], True)
+        with torch.cuda.device(dev):
+            hip.check(lib.cum_causal_conv1d_fwd(ctypes.byref(sc), hip.ptr(xv), hip.ptr(w2), hip.ptr(cb), hip.ptr(xcT),
+                                                hip.stream_ptr()))
+        x_dbl = cs.proj_fwd(xc.view(M, Dn), xw, cd)                                    # (M, R + 2 N)
+        dt = cs.proj_fwd(x_dbl[:, :R], dtw, cd)                                        # (M, D); the bias goes in the scan
+        bc = x_dbl[:, R:].float().view(Bn, L, 2 * N)                                   # B | C in f32, as the scan reads them
+        Bm, Cm = bc[..., :N].transpose(1, 2), bc[..., N:].transpose(1, 2)
+        A = -torch.exp(A_log.detach().float())
+        Df, bias = Dp.detach().float().contiguous(), dt_bias.detach().float().contiguous()
+        dtT = dt.view(Bn, L, Dn).transpose(1, 2)
+        y = torch.empty(Bn, L, Dn, dtype=cd, device=dev)
+        yT = y.transpose(1, 2)
+        ckpt = None
+        if save:
+            ckpt = torch.empty(max(lib.cum_scan_ckpt_elems(Bn, Dn, N, L), 1), dtype=torch.float32, device=dev)
+        ss = ssi._shape(xcT, dtT, zv, yT, Bm, Cm, True)
+        with torch.cuda.device(dev):
+            hip.check(lib.cum_selective_scan_fwd(ctypes.byref(ss), hip.ptr(xcT), hip.ptr(dtT), hip.ptr(A), hip.ptr(Bm),
+                                                 hip.ptr(Cm), hip.ptr(Df), hip.ptr(zv), hip.ptr(bias), hip.ptr(yT), None,
+                                                 hip.ptr(ckpt), hip.stream_ptr()))
+        ctx.save_for_backward(xz, w2, cb, xc, x_dbl, dt, bc, A, Df, bias, ckpt, xw, dtw)
+        ctx.params = (conv_w, conv_b, xw, dtw, dt_bias, A_log, Dp)
+        ctx.cd, ctx.dims = cd, (Bn, L, Dn, N, R)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        import ctypes
+        from ...causal_conv1d import _shape as conv_shape
+        from ...network import convstack as cs
+        from ..ops import selective_scan_interface as ssi
+        xz, w2, cb, xc, x_dbl, dt, bc, A, Df, bias, ckpt, xw, dtw = ctx.saved_tensors
+        if ckpt is None:
+            raise RuntimeError("Mamba inner backward called but the forward saved no scan checkpoints")
+        conv_w, conv_b, xw_p, dtw_p, dt_bias_p, A_log_p, D_p = ctx.params
+        cd = ctx.cd
+        Bn, L, Dn, N, R = ctx.dims
+        M, S = Bn * L, R + 2 * N
+        dev = xz.device
+        lib = hip.lib()
+        dy = dy if dy.dtype == cd else dy.to(cd)
+        dyT = (dy if dy.is_contiguous() else dy.contiguous()).transpose(1, 2)
+        xv, zv = xz[..., :Dn].transpose(1, 2), xz[..., Dn:].transpose(1, 2)
+        xcT, dtT = xc.transpose(1, 2), dt.view(Bn, L, Dn).transpose(1, 2)
+        Bm, Cm = bc[..., :N].transpose(1, 2), bc[..., N:].transpose(1, 2)
+        dxz = torch.empty_like(xz)
+        dzT = dxz[..., Dn:].transpose(1, 2)
+        du = torch.empty(Bn, L, Dn, dtype=cd, device=dev)
+        ddelta = torch.empty(Bn, L, Dn, dtype=cd, device=dev)
+        duT, ddT = du.transpose(1, 2), ddelta.transpose(1, 2)
+        dBC = torch.empty(2, Bn, L, N, dtype=torch.float32, device=dev)
+        # parameter gradients: straight into the flat gradient buffer where it is fresh (training/flat_optim.py)
+        small = [conv_w, conv_b, dt_bias_p, A_log_p, D_p]
+        sink = cs.grad_sink(small) if all(p.is_leaf and p.dtype == torch.float32 for p in small) else None
+
+        def slot(i, like):
+            if sink is not None:
+                flat, _, offs = sink
+                return flat.grad[offs[i]:offs[i] + like.numel()].view(like.shape)
+            return torch.empty(like.shape, dtype=torch.float32, device=dev)
+        dcw, dcb, dbias, dA_log, dD = slot(0, w2), slot(1, cb), slot(2, bias), slot(3, A), slot(4, Df)
+        dA = torch.empty_like(A)
+        ws = torch.empty(max(lib.cum_scan_bwd_workspace_elems(Bn, Dn, N, L), 1), dtype=torch.float32, device=dev)
+        su = ssi._shape(xcT, dtT, zv, dyT, Bm, Cm, True)                  # o_* strides := dout's
+        gs = hip.ScanGradStrides()
+        gs.du_sb, gs.du_sd, gs.du_sl = duT.stride()
+        gs.dd_sb, gs.dd_sd, gs.dd_sl = ddT.stride()
+        gs.dz_sb, gs.dz_sd, gs.dz_sl = dzT.stride()
+        with torch.cuda.device(dev):
+            hip.check(lib.cum_selective_scan_bwd(ctypes.byref(su), ctypes.byref(gs), hip.ptr(xcT), hip.ptr(dtT), hip.ptr(A),
+                                                 hip.ptr(Bm), hip.ptr(Cm), hip.ptr(Df), hip.ptr(zv), hip.ptr(bias),
+                                                 hip.ptr(dyT), hip.ptr(ckpt), hip.ptr(duT), hip.ptr(ddT), hip.ptr(dA),
+                                                 hip.ptr(dBC[0]), hip.ptr(dBC[1]), hip.ptr(dD), hip.ptr(dzT), hip.ptr(dbias),
+                                                 hip.ptr(ws), hip.stream_ptr()))
+        torch.mul(dA, A, out=dA_log)                                       # A = -exp(A_log): dA / dA_log = A
+        # d(x_dbl) = (d dt | dB | dC): one buffer, rows readable 64 columns past their end (zero weight columns there)
+        pad = cs.rup(S, cs.bk_of(cd)) - S
+        dxd_flat = torch.empty(M * S + pad, dtype=cd, device=dev)
+        if pad:
+            dxd_flat[M * S:].zero_()
+        dxd = dxd_flat[:M * S].view(M, S)
+        cs.proj_dgrad(ddelta.view(M, Dn), dtw, cd, out=dxd[:, :R])                       # d dt = d delta W_dt
+        dxd[:, R:].view(M, 2, N).copy_(dBC.view(2, M, N).transpose(0, 1))               # dB | dC, cast
+        # weight gradients of the two projections (row-split GEMM, csrc/gemm_tn.hip)
+        d_xw = d_dtw = None
+        for w_p, w_s, dz2, x2 in ((dtw_p, dtw, ddelta.view(M, Dn), x_dbl[:, :R]), (xw_p, xw, dxd, xc.view(M, Dn))):
+            Nw, Kw = w_s.shape
+            sk = cs.grad_sink([w_p]) if (w_p.is_leaf and w_p.dtype == torch.float32) else None
+            if sk is not None:
+                flat, idx, offs = sk
+                cs.wgrad(dz2, 0, dz2.stride(0), Nw, x2, 0, x2.stride(0), Kw, M, want_bias=False,
+                         out_w=flat.grad[offs[0]:offs[0] + Nw * Kw])
+                flat.wrote(idx)
+            else:
+                g, _ = cs.wgrad(dz2, 0, dz2.stride(0), Nw, x2, 0, x2.stride(0), Kw, M, want_bias=False)
+                if w_p is dtw_p:
+                    d_dtw = g.to(w_p.dtype)
+                else:
+                    d_xw = g.to(w_p.dtype)
+        # d(conv output) = d(x_dbl) W_x + du, then the depthwise conv's backward writes dx into the first half of d(xz)
+        dxc = cs.proj_dgrad(dxd, xw, cd, res=du.view(M, Dn), tail_ok=True)
+        dxcT = dxc.view(Bn, L, Dn).transpose(1, 2)
+        dxT = dxz[..., :Dn].transpose(1, 2)
+        wsc = torch.empty(max(lib.cum_conv_bwd_workspace_elems(Bn, Dn, L, w2.shape[1]), 1), dtype=torch.float32, device=dev)
+        sc = conv_shape(xv, dxcT, w2.shape[1], True)
+        with torch.cuda.device(dev):
+            hip.check(lib.cum_causal_conv1d_bwd(ctypes.byref(sc), hip.ptr(xv), hip.ptr(w2), hip.ptr(cb), hip.ptr(dxcT),
+                                                hip.ptr(dxT), dxT.stride(0), dxT.stride(1), dxT.stride(2), hip.ptr(dcw),
+                                                hip.ptr(dcb), hip.ptr(wsc), hip.stream_ptr()))
+        if sink is not None:
+            sink[0].wrote(sink[1])
+            return dxz, None, None, d_xw, d_dtw, None, None, None, None, None
+        return (dxz, dcw.view(conv_w.shape).to(conv_w.dtype), dcb.to(conv_b.dtype), d_xw, d_dtw, dbias.to(dt_bias_p.dtype),
+                dA_log.to(A_log_p.dtype), dD.to(D_p.dtype), None, None)
+
+
 class _SplitXZ(torch.autograd.Function):
     """xz (B, L, 2D) -> x, z as (B, D, L) views.  Plain slicing leaves autograd two zero-filled (B, L, 2D) buffers, two
     slice copies and an add per block; the two gradients are simply concatenated here."""
@@ -93,6 +243,7 @@ class _SplitXZ(torch.autograd.Function):
         return torch.cat([dx.transpose(1, 2), dz.transpose(1, 2)], dim=-1), None
 
 
+_FUSED_INNER = os.environ.get("CUM_FUSED_INNER", "1") != "0"  # "0": conv / projections / scan as separate autograd nodes
 _FUSED_STEP = os.environ.get("CUM_FUSED_STEP", "1") != "0"  # "0": Block + Mamba.step as separate small kernels
 
 
@@ -172,6 +323,16 @@ class Mamba(nn.Module):
         d_conv = self.conv1d.weight.shape[-1]
 
         xz = _proj(hidden_states, self.in_proj.weight, self.in_proj.bias)         # (B, L, 2 d_inner)
+        if (_FUSED_INNER and xz.is_cuda and conv_state is None and ssm_state is None and causal_conv1d_fn is not None
+                and d_conv <= 4 and self.conv1d.bias is not None and self.x_proj.weight.shape[0] % 8 == 0
+                and dt_rank % 8 == 0 and d_inner % 8 == 0 and self.dt_proj.weight.dtype == torch.float32):
+            cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else xz.dtype
+            if cd in hip.IO_TYPES:
+                params = (self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, self.dt_proj.bias,
+                          self.A_log, self.D)
+                save = torch.is_grad_enabled() and (xz.requires_grad or any(p.requires_grad for p in params))
+                y = _MambaInnerFn.apply(xz, *params, cd, save)                             # (B, L, d_inner)
+                return _proj(y, self.out_proj.weight, self.out_proj.bias)
         x, z = _SplitXZ.apply(xz, d_inner)                                         # (B, d_inner, L) views, channel stride 1
         A = -torch.exp(self.A_log.float())
         if conv_state is not None:

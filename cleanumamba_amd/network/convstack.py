@@ -732,41 +732,48 @@ def _zero_bias(n, dev):
     return z
 
 
-def _gemm_rows(x2, Kp):
+def _gemm_rows(x2, Kp, tail_ok=False):
     """x2 as an A operand whose rows can be read Kp elements wide: 16-byte aligned rows, unit column stride, and either a
     row stride that covers Kp (the over-read stays inside the next columns of the same row, which zero weight columns
-    ignore) or a zero-padded copy."""
+    ignore), or -- ``tail_ok``: the caller's buffer continues Kp - K readable elements past its last row, so an over-read
+    runs into the next row (finite values times zero weights) -- or a zero-padded copy."""
     K = x2.shape[1]
     ok = x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
-    if ok and (K == Kp or x2.stride(0) >= Kp):
+    if ok and (K == Kp or x2.stride(0) >= Kp or tail_ok):
         return x2
     if K == Kp:
         return x2.contiguous()
     return torch.nn.functional.pad(x2, (0, Kp - K))
 
 
-def proj_fwd(x2, w, dt):
+def proj_fwd(x2, w, dt, out=None):
     """y [M, N] = x2 [M, K] @ w[N, K]^T on cum_gemm_nt (csrc/gemm.hip): the forward GEMM of a bias-free nn.Linear
-    (upstream Mamba.forward's in_proj / x_proj / dt_proj / out_proj, reached from src/network/CleanUMamba.py:172-189)."""
+    (upstream Mamba.forward's in_proj / x_proj / dt_proj / out_proj, reached from src/network/CleanUMamba.py:172-189).
+    ``out``: a [M, >= N] view with unit column stride that receives the result (row stride = its own)."""
     N, K = w.shape
     Np, Kp = rup(N, 32), rup(K, bk_of(dt))
     wp = take(w, ("proj", (N, K), Np, Kp), lambda: lay_proj((N, K), Np, Kp), dt)
     a = _gemm_rows(x2, Kp)
     M = a.shape[0]
-    out = torch.empty(M, N, dtype=dt, device=a.device)
-    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, N, M, 1 << 30, 1 << 30, hip.EPI_BIAS, N, split_k=N <= 256)
+    if out is None:
+        out = torch.empty(M, N, dtype=dt, device=a.device)
+    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, out.stride(0), M, 1 << 30, 1 << 30, hip.EPI_BIAS, N,
+         split_k=N <= 256)
     return out
 
 
-def proj_dgrad(dy2, w, dt):
-    """dx [M, K] = dy2 [M, N] @ w[N, K]: the data gradient of the same layer, as the NT GEMM against w^T."""
+def proj_dgrad(dy2, w, dt, out=None, res=None, tail_ok=False):
+    """dx [M, K] = dy2 [M, N] @ w[N, K] (+ res): the data gradient of the same layer, as the NT GEMM against w^T.
+    ``out``: a [M, >= K] view that receives it; ``res`` [M, K] (row stride = its own) is added in the epilogue."""
     N, K = w.shape
     Np, Kp = rup(K, 32), rup(N, bk_of(dt))
     wp = take(w, ("proj_t", (N, K), Np, Kp), lambda: lay_proj_t((N, K), Np, Kp), dt)
-    a = _gemm_rows(dy2, Kp)
+    a = _gemm_rows(dy2, Kp, tail_ok)
     M = a.shape[0]
-    out = torch.empty(M, K, dtype=dt, device=a.device)
-    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, K, M, 1 << 30, 1 << 30, hip.EPI_BIAS, K, split_k=K <= 256)
+    if out is None:
+        out = torch.empty(M, K, dtype=dt, device=a.device)
+    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, out.stride(0), M, 1 << 30, 1 << 30, hip.EPI_BIAS, K,
+         res=res, r_off=0, ldr=res.stride(0) if res is not None else 0, split_k=K <= 256 and res is None)
     return out
 
 

@@ -323,3 +323,32 @@ def test_add_layernorm_vs_torch(cuda, dim, dt):
     assert float(base.grad[:, L:].abs().max()) == 0.0
     for a, bb in ((r.grad, rd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
         assert rel_l2(a, bb) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(None, 2e-5), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("d_model,d_state", [(64, 16), (512, 64), (56, 12)])
+def test_mamba_inner_single_node_equals_separate_ops(cuda, monkeypatch, dtype, tol, d_model, d_state):
+    """Mamba.forward with everything between in_proj and out_proj as ONE autograd node (_MambaInnerFn: no slice / cat /
+    cast glue, gradients written into shared buffers) against the same block built from the separate Functions
+    (causal_conv1d_fn, _ProjFn, selective_scan_fn): same output, same input and parameter gradients."""
+    from cleanumamba_amd.mamba_ssm.modules import mamba_simple as ms
+    torch.manual_seed(d_model + d_state)
+    blk = ms.Mamba(d_model, d_state=d_state, d_conv=4, expand=2).to(cuda)
+    x = torch.randn(3, 37, d_model, generator=torch.Generator().manual_seed(1)).to(cuda)
+    dout = torch.randn(3, 37, d_model, generator=torch.Generator().manual_seed(2)).to(cuda)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ms, "_FUSED_INNER", fused)
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        if dtype is None:
+            y = blk(xi)
+        else:
+            with torch.autocast("cuda", dtype=dtype):
+                y = blk(xi)
+        (y.float() * dout).sum().backward()
+        res[fused] = (y.detach().float(), xi.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
+    assert rel_l2(res[True][0], res[False][0]) < tol
+    assert rel_l2(res[True][1], res[False][1]) < 3 * tol
+    for k in res[True][2]:
+        assert rel_l2(res[True][2][k], res[False][2][k]) < 3 * tol, k

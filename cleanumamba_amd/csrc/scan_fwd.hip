@@ -633,6 +633,190 @@ __global__ __launch_bounds__((NW + 1) * 64) void scan_fwd_ws_kernel(const ScanPa
   }
 }
 
+#ifdef CUM_AB
+// EXPERIMENT, AB builds only (measured and rejected, round 3): the role split of scan_fwd_ws_kernel / scan_bwd_ws_kernel at
+// d_state > 16.  Result on MI355X, E8 shape (B = 16, D = 2048, N = 64, L = 624): 0.405 ms against 0.272 ms for
+// scan_fwd_lds_kernel.  At N = 64 the grid already puts 16 recurrence waves on every CU (4 per SIMD): the SIMDs' issue
+// slots are the bound, and moving the per-(t, d) work to helper waves does not remove it from them -- it only adds two
+// waves per workgroup that land 3 : 2 on the SIMDs (10 waves over 4 SIMDs), and the barrier waits for the fuller ones.
+// The specialised form pays only where SIMDs would otherwise idle (d_state <= 16 at small batch).
+// d_state > 16 (E6 / E8: 64), the kernel north_star names.  scan_fwd_lds_kernel above makes every wave do three jobs per
+// 16-step chunk -- prepare two of the chunk's rows (softplus, delta u: phase A), walk its 8 states through the 16 steps
+// (phase B), sum the 8 per-wave partial results of two rows, gate and store them (phase C) -- with two workgroup barriers;
+// it measured 0.56 of the update loop's issue roof (bench.py scan rows).  Here the roles of scan_fwd_ws_kernel /
+// scan_bwd_ws_kernel are split over waves: NW CONSUMER waves do nothing but the recurrence (per step 6 LDS reads, 24
+// packed / transcendental ops, one partial-sum write), a LOADER wave owns the way in (rows of u / delta / z and the B_t / C_t
+// tile one unit ahead in registers; softplus, delta u, D u, silu(z) once per (t, d) into LDS) and a FINISHER wave the way
+// out, one unit behind (sum of the NW partial sums + D u, gate, store).  Unit = the 8 steps between two saved states; one
+// barrier per unit.  In interval i the loader writes operand slot (i + 1) & 1 / finisher-operand slot (i + 1) % 3, the
+// consumers read slot i & 1 and write partial-sum slot i & 1, the finisher reads partial sums (i - 1) & 1 and its
+// operands (i - 1) % 3.
+template <int NW, typename TIO>
+__global__ __launch_bounds__((NW + 2) * 64) void scan_fwd_ws3_kernel(const ScanParams p) {
+  constexpr int NP = NW * NS;                    // padded state count
+  constexpr int BCE = SUB * 2 * NP / 64;         // B / C tile elements per loader lane and unit
+  __shared__ __attribute__((aligned(8))) float2 s_op[2][SUB][64];     // {dt, dt * u}; 0 for masked steps / lanes
+  __shared__ __attribute__((aligned(8))) float2 s_fin[3][SUB][64];    // {D u, silu gate}
+  __shared__ float s_y[2][NW][SUB][64];                               // per-wave sum_n C x
+  __shared__ __attribute__((aligned(16))) float s_bc[2][SUB][2 * NP];
+
+  const int lane = threadIdx.x & 63;
+  const int w = uniform(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const int d = blockIdx.x * 64 + lane;
+  const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
+  const bool dok = d < Dm;
+  const int dc = dok ? d : Dm - 1;
+  const int nu = (L + SUB - 1) / SUB;            // units
+  const int nchunks = p.nchunks;
+  const bool has_z = p.z != nullptr;
+
+  if (w == NW) {
+    // ------------------------------------------------------------------------------------------------ loader
+    const float Dd = p.D ? p.D[dc] : 0.f;
+    const float bias = p.bias ? p.bias[dc] : 0.f;
+    const TIO *ub = static_cast<const TIO *>(p.u) + b * p.s.u_sb;
+    const TIO *db = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb;
+    const TIO *zb = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb : ub;
+    const int u_lo = dc * (int)p.s.u_sd, d_lo = dc * (int)p.s.dt_sd, z_lo = has_z ? dc * (int)p.s.z_sd : u_lo;
+    const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
+    const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
+    const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
+    const int softplus = p.s.delta_softplus;
+    float ru[SUB], rdt[SUB], rz[SUB], rbc[BCE];
+    auto load_rows = [&](int h) {
+      const int t0 = h * SUB;
+      const bool full = t0 + SUB <= L;            // wave-uniform: the clamps below are scalar selects
+      const TIO *u0 = ub + (int64_t)t0 * u_sl, *d0 = db + (int64_t)t0 * dt_sl, *z0 = zb + (int64_t)t0 * z_sl;
+#pragma unroll
+      for (int k = 0; k < SUB; ++k) {
+        const int kk = full ? k : ((t0 + k < L) ? k : L - 1 - t0);
+        ru[k] = (float)u0[kk * u_sl + u_lo];
+        rdt[k] = (float)d0[kk * dt_sl + d_lo];
+        rz[k] = (float)z0[kk * z_sl + z_lo];
+      }
+#pragma unroll
+      for (int k = 0; k < BCE; ++k) {
+        const int e = lane + 64 * k;
+        const int tl = e / (2 * NP), j = e % (2 * NP);
+        int t = t0 + tl;
+        if (!full) t = t < L ? t : L - 1;
+        const bool isC = j >= NP;
+        const int n = isC ? j - NP : j;
+        const int nc = n < N ? n : N - 1;
+        const float v = isC ? Cb[t * C_sl + nc * C_sn] : Bb[t * B_sl + nc * B_sn];
+        rbc[k] = n < N ? v : 0.f;
+      }
+    };
+    auto prepare = [&](int h, int i) {            // the rows in registers are unit h's -> slots of interval i
+      const int t0 = h * SUB;
+#pragma unroll
+      for (int k = 0; k < SUB; ++k) {
+        const bool ok = dok && t0 + k < L;
+        float v = rdt[k] + bias;
+        if (softplus) v = softplus20(v);
+        v = ok ? v : 0.f;                         // steps past the end leave the state alone (a = 1, b = 0)
+        const float zv = rz[k];
+        s_op[i & 1][k][lane] = make_float2(v, v * ru[k]);
+        s_fin[i % 3][k][lane] = make_float2(Dd * ru[k], has_z ? zv * sigmoidf_(zv) : 1.f);
+      }
+#pragma unroll
+      for (int k = 0; k < BCE; ++k) (&s_bc[i & 1][0][0])[lane + 64 * k] = rbc[k];
+    };
+    load_rows(0);
+    prepare(0, 0);
+    if (nu > 1) load_rows(1);
+    for (int i = 0; i < nu + 1; ++i) {
+      __syncthreads();
+      if (i + 1 < nu) {
+        prepare(i + 1, i + 1);
+        if (i + 2 < nu) load_rows(i + 2);
+      }
+    }
+    return;
+  }
+
+  if (w == NW + 1) {
+    // ------------------------------------------------------------------------------------------------ finisher
+    TIO *ob = static_cast<TIO *>(p.out) + b * p.s.o_sb;
+    const int o_lo = dc * (int)p.s.o_sd, o_sl = (int)p.s.o_sl;
+    auto finish = [&](int h) {                    // unit h was walked in interval h
+      const int t0 = h * SUB, ps = h & 1, fs = h % 3;
+      TIO *o0 = ob + (int64_t)t0 * o_sl;
+#pragma unroll
+      for (int k = 0; k < SUB; ++k) {
+        const float2 f = s_fin[fs][k][lane];
+        float y = f.x;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) y += s_y[ps][ww][k][lane];
+        if (dok && t0 + k < L) o0[k * o_sl + o_lo] = (TIO)(y * f.y);
+      }
+    };
+    for (int i = 0; i < nu + 1; ++i) {
+      __syncthreads();
+      if (i > 0) finish(i - 1);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- consumers
+  const int n0 = w * NS;
+  const int nvalid = (N - n0) < NS ? (N - n0) : NS;
+  f2 Ap[NS / 2], x[NS / 2];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int jj = j < nvalid ? j : nvalid - 1;
+    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
+    x[j / 2][j % 2] = 0.f;
+  }
+  for (int i = 0; i < nu + 1; ++i) {
+    __syncthreads();
+    if (i >= nu) break;                           // (the drain interval belongs to the finisher)
+    const int slot = i & 1;
+    if (p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, i >> 1, i & 1, NW, w, Dm, d), x);
+    float4 b0 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][n0]), b1 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][n0 + 4]);
+    float4 c0 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][NP + n0]), c1 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][NP + n0 + 4]);
+    float2 op = s_op[slot][0][lane];
+#pragma unroll
+    for (int k = 0; k < SUB; ++k) {
+      float4 nb0 = b0, nb1 = b1, nc0 = c0, nc1 = c1;
+      float2 nop = op;
+      if (k + 1 < SUB) {
+        nb0 = *reinterpret_cast<const float4 *>(&s_bc[slot][k + 1][n0]);
+        nb1 = *reinterpret_cast<const float4 *>(&s_bc[slot][k + 1][n0 + 4]);
+        nc0 = *reinterpret_cast<const float4 *>(&s_bc[slot][k + 1][NP + n0]);
+        nc1 = *reinterpret_cast<const float4 *>(&s_bc[slot][k + 1][NP + n0 + 4]);
+        nop = s_op[slot][k + 1][lane];
+      }
+      const f2 bv[NS / 2] = {f2{b0.x, b0.y}, f2{b0.z, b0.w}, f2{b1.x, b1.y}, f2{b1.z, b1.w}};
+      const f2 cv[NS / 2] = {f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, f2{c1.z, c1.w}};
+      const float dt = op.x, du = op.y;
+      f2 y = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NS / 2; ++j) {
+        const f2 e = dt * Ap[j];
+        f2 a;
+        a.x = __builtin_amdgcn_exp2f(e.x);
+        a.y = __builtin_amdgcn_exp2f(e.y);
+        x[j] = a * x[j] + du * bv[j];
+        y = cv[j] * x[j] + y;
+      }
+      s_y[slot][w][k][lane] = y.x + y.y;
+      __builtin_amdgcn_sched_barrier(0);
+      b0 = nb0; b1 = nb1; c0 = nc0; c1 = nc1; op = nop;
+    }
+  }
+  if (p.last_state && dok) {
+    float *ls = p.last_state + ((int64_t)b * Dm + d) * N + n0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (j < nvalid) ls[j] = x[j / 2][j % 2];
+  }
+}
+
+#endif  // CUM_AB
+
 // selective_state_update: one thread per (stream b, channel d); state row of N floats.
 __global__ void state_update_kernel(int batch, int dim, int N, float *__restrict__ state, const float *__restrict__ x,
                                     const float *__restrict__ dt, const float *__restrict__ A,
@@ -701,6 +885,13 @@ static int launch_fwd_io(const ScanParams &p, hipStream_t st) {
     CUM_CHECK_LAUNCH();
     return CUM_OK;
   }
+#endif
+#ifdef CUM_AB   // CUM_SCAN_FWD_WS3=1: loader / consumer / finisher waves (scan_fwd_ws3_kernel: measured 49 % slower at N = 64)
+    if (cum_knob("CUM_SCAN_FWD_WS3", 0) == 1) {
+      hipLaunchKernelGGL((scan_fwd_ws3_kernel<NW, TIO>), grid, dim3((NW + 2) * 64), 0, st, p);
+      CUM_CHECK_LAUNCH();
+      return CUM_OK;
+    }
 #endif
     hipLaunchKernelGGL((scan_fwd_lds_kernel<NW, TIO>), grid, block, 0, st, p);
     CUM_CHECK_LAUNCH();

@@ -181,10 +181,12 @@ class TrainStep:
             else:
                 # several ranks: no collective inside a capture.  Graph 1 leaves this rank's gradient in the flat buffer,
                 # the exchange runs eagerly between the replays, graph 2 is the optimizer section.
-                with torch.cuda.graph(graph):
+                # (thread_local: the process group's watchdog thread may query events while this thread captures;
+                #  in the default "global" mode such a call from another thread invalidates the capture)
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     loss = self._micro_steps(g["clean"], g["noisy"], exchange=False)
                 optim_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(optim_graph, pool=graph.pool()):
+                with torch.cuda.graph(optim_graph, pool=graph.pool(), capture_error_mode="thread_local"):
                     norm = self.optimizer_step(write_lr=False)
                 g.update(graph=graph, optim_graph=optim_graph, loss=loss, norm=norm)
         except Exception as exc:          # noqa: BLE001 - capture is an optimisation; stay eager

@@ -193,9 +193,10 @@ class PackPlan:
         self.total = off
         self.reqs = {}                        # (key, ptr, dtype) -> (global index (cpu), shape)
         self.dirty = False
-        self.gidx = {}                        # dtype -> (device index tensor, [(reqkey, start, numel, shape)])
+        self.gidx = {}                        # (dtype, late) -> (device index tensor, [(reqkey, start, numel, shape)])
         self.current = {}
-        self.big = {}                         # dtype -> the flat buffer all packed operands of that dtype are views of
+        self.big = {}                         # (dtype, late) -> the flat buffer all packed operands of that group are views of
+        self.late_event = None                # side-stream gather of the backward-only operands still to be joined
 
     @staticmethod
     def _shared_buffer(params):
@@ -220,10 +221,22 @@ class PackPlan:
         self.reqs[rk] = (g.to(torch.int32), shape)
         self.dirty = True
 
+    # layouts only the backward reads (data-gradient operands): skipped without autograd
+    LATE = ("conv_dgrad", "convt_dgrad", "glu_dgrad", "plain_dgrad", "proj_t")
+    # "1": gather them on a side stream beside the forward's GEMMs.  Measured on the E8 train step (same box, two runs
+    # each): 21.44 / 21.48 ms with the side stream against 21.23 / 21.25 ms without -- the gather's scattered reads slow
+    # the concurrent GEMMs by more than the 0.3 ms it takes when run alone (as the round-2 attempt to run weight-gradient
+    # GEMMs on a second stream: every launch already fills the chip).  Off.
+    SIDE_STREAM = os.environ.get("CUM_PACK_SIDE_STREAM", "0") == "1"
+
     def refresh(self):
         """Recompute every recorded pack from the current parameter values.  While the set of recorded packs is
         unchanged the packed operands are rewritten IN PLACE: a captured streaming hop (CleanUMamba._hop) replays
-        kernels that hold their addresses."""
+        kernels that hold their addresses.
+
+        The operands of the data-gradient GEMMs (``LATE`` keys, about half of the packed bytes) are not needed before the
+        backward: with autograd off they are not gathered at all (``SIDE_STREAM``: see above)."""
+        grad_on = torch.is_grad_enabled()
         if not self.reqs:
             self.current = {}
             return
@@ -232,30 +245,61 @@ class PackPlan:
         dev = self.params[0].device
         if self.dirty:
             self.gidx = {}
-            by_dt = {}
+            groups = {}
             for rk, (g, shape) in self.reqs.items():
-                by_dt.setdefault(rk[2], []).append((rk, g, shape))
-            for dt, items in by_dt.items():
+                groups.setdefault((rk[2], rk[0][0] in self.LATE), []).append((rk, g, shape))
+            for gk, items in groups.items():
                 metas, parts, start = [], [], 0
                 for rk, g, shape in items:
                     metas.append((rk, start, g.numel(), shape))
                     parts.append(g)
                     start += g.numel()
-                self.gidx[dt] = (torch.cat(parts).to(dev), metas)
+                self.gidx[gk] = (torch.cat(parts).to(dev), metas)
             self.dirty = False
+        self.late_event = None
         with torch.no_grad():
             flat = self.source if self.source is not None else torch.cat([p.detach().reshape(-1) for p in self.params])
-            for dt, (gi, metas) in self.gidx.items():
+            cast, side = {}, None
+            for gk, (gi, metas) in self.gidx.items():
+                dt, late = gk
+                if late and not grad_on:
+                    for rk, _, _, _ in metas:         # not needed without a backward: a stale copy must not be served
+                        self.current.pop(rk, None)
+                    self.big.pop(gk, None)
+                    continue
                 if self.source is None and flat.dtype != dt:
                     # cast first: the gather then reads 2-byte elements of a source that stays cache-resident
-                    flat_dt = flat.to(dt)
+                    if dt not in cast:
+                        cast[dt] = flat.to(dt)
+                    flat_dt = cast[dt]
                 else:
                     flat_dt = flat                    # flat parameter buffer: converted inside the gather
-                big = gather(flat_dt, gi, dt, out=self.big.get(dt))
-                if self.big.get(dt) is not big:
-                    self.big[dt] = big
+                out = self.big.get(gk)
+                if out is None:
+                    out = torch.empty(gi.numel(), dtype=dt, device=dev)
+                if late and self.SIDE_STREAM:
+                    if side is None:
+                        side = self.__dict__.get("_side")
+                        if side is None:
+                            side = self.__dict__["_side"] = torch.cuda.Stream(device=dev)
+                        side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        big = gather(flat_dt, gi, dt, out=out)
+                else:
+                    big = gather(flat_dt, gi, dt, out=out)
+                if self.big.get(gk) is not big:
+                    self.big[gk] = big
                     for rk, start, n, shape in metas:
                         self.current[rk] = big[start:start + n].view(shape)
+            if side is not None:
+                self.late_event = side.record_event()
+
+    def join(self):
+        """First backward-side use of a late operand: the current stream waits for the side-stream gather."""
+        ev = self.late_event
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.late_event = None
 
 
 _ACTIVE_PLAN = None
@@ -272,6 +316,8 @@ def take(src, key, build, dtype=None):
     if plan is not None and src.data_ptr() in plan.offset:
         hit = plan.current.get((key, src.data_ptr(), dtype if dtype is not None else src.dtype))
         if hit is not None:
+            if plan.late_event is not None and key[0] in plan.LATE:
+                plan.join()
             return hit
     ent = _INDEX_CACHE.get((key, src.device))
     if ent is None:

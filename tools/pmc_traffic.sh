@@ -37,7 +37,7 @@ for i in range(8):
     else:
         shapes.append((f"enc{i}.conv+relu", 2 * M * (2 * Cin + H) + 2 * H * 4 * Cin, 2.0 * M * H * 4 * Cin))
         shapes.append((f"enc{i}.1x1+glu", 2 * M * (H + H) + 2 * 2 * H * H, 2.0 * M * 2 * H * H))
-main = ("gemm_tn_kernel", "gemm_tn8_kernel") if mode == "tn" else ("gemm_nt",)
+main = ("gemm_tn_kernel", "gemm_tn8_kernel", "gemm_tn9_kernel") if mode == "tn" else ("gemm_nt",)
 def per_shape(c):
     out, cur, cnt = [], 0.0, 0
     for _, k, v in seq[c]:

@@ -46,11 +46,12 @@ import csv, glob, json, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
 rows.sort()
-tn = [i for i, r in enumerate(rows) if "gemm_tn_kernel" in r[2] or "gemm_tn8_kernel" in r[2]]
+is_tn = lambda k: "gemm_tn" in k and "reduce" not in k        # gemm_tn_kernel / gemm_tn8_kernel / gemm_tn9_kernel
+tn = [i for i, r in enumerate(rows) if is_tn(r[2])]
 n = 10 * 13          # the MFMA-bound group the roofline object is quoted on: the last 10 of the 16 shapes (enc3-enc7)
 first = tn[-n]
 seg = rows[first:]
-g = [e - s for s, e, k in seg if "gemm_tn_kernel" in k or "gemm_tn8_kernel" in k]
+g = [e - s for s, e, k in seg if is_tn(k)]
 red = [e - s for s, e, k in seg if "tn_reduce_kernel" in k]
 d = json.load(open(sys.argv[2]))
 print("last %d gemm_tn launches: mean %.1f us; tn_reduce launches in that span: %d, %.1f us per gemm_tn call" %

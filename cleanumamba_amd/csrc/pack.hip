@@ -56,9 +56,92 @@ __global__ __launch_bounds__(256) void gather_kernel(const TS *__restrict__ src,
   }
 }
 
+// ---------------------------------------------------------------- index-free re-pack of SEPARABLE layouts
+// Every weight layout of the conv stack and of the projections is a 2-D matrix whose source offset separates:
+//   dst[r][c] = src[rowoff[r] + coloff[c]]      (either table entry = PACK_PAD: zero padding)
+// (permutations of (h, c, tap) with zero-padded channel counts, GLU row interleaves, transposes).  Two small tables per
+// operand replace the 4-byte-per-element index of gather_kernel, and where consecutive ROWS of the destination are the
+// near neighbours in the source (the data-gradient layouts: transposes) the 64 x 64 tile goes through LDS so that both
+// the reads and the writes are coalesced.  One launch packs every operand of a group: workgroup -> (job, tile) from a
+// tile list built once per model.
+constexpr int PACK_PAD = -2147483647 - 1;
+struct PackJob {
+  int64_t dst_off;      // elements from the start of the group's buffer
+  int32_t rows, cols;   // destination matrix (cols: multiple of 8)
+  int32_t row_tab, col_tab;   // positions of the two tables in `tables`
+  int32_t transpose;    // 1: source is fast along destination rows
+  int32_t pad_;
+};
+
+template <typename TD>
+__global__ __launch_bounds__(256) void pack2d_kernel(const float *__restrict__ src, const PackJob *__restrict__ jobs,
+                                                    const int32_t *__restrict__ tiles, const int32_t *__restrict__ tables,
+                                                    TD *__restrict__ dst) {
+  typedef typename Vec4<TD>::type V;
+  __shared__ __attribute__((aligned(16))) TD tile[64][72];
+  const int tid = threadIdx.x;
+  const PackJob j = jobs[tiles[3 * blockIdx.x]];
+  const int r0 = tiles[3 * blockIdx.x + 1] * 64, c0 = tiles[3 * blockIdx.x + 2] * 64;
+  const int32_t *rt = tables + j.row_tab, *ct = tables + j.col_tab;
+  TD *out = dst + j.dst_off;
+  if (j.transpose) {
+    // read phase: lanes along destination rows (near neighbours in the source), wave w takes columns 16 w .. 16 w + 15
+    const int r = r0 + (tid & 63), cw = c0 + 16 * (tid >> 6);
+    const int ro = r < j.rows ? rt[r] : PACK_PAD;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      const int c = cw + cc;
+      const int co = c < j.cols ? ct[c] : PACK_PAD;
+      const float v = (ro == PACK_PAD || co == PACK_PAD) ? 0.f : src[(int64_t)ro + co];
+      tile[tid & 63][16 * (tid >> 6) + cc] = (TD)v;
+    }
+    __syncthreads();
+  }
+  // write phase: a thread owns 8 consecutive columns of rows (tid / 8) and (tid / 8) + 32
+  const int cg = 8 * (tid & 7);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int rl = (tid >> 3) + 32 * h, r = r0 + rl, c = c0 + cg;
+    if (r >= j.rows || c >= j.cols) continue;
+    if (j.transpose) {
+      *reinterpret_cast<uint4 *>(out + (int64_t)r * j.cols + c) = *reinterpret_cast<const uint4 *>(&tile[rl][cg]);
+      if constexpr (sizeof(TD) == 4)
+        *reinterpret_cast<uint4 *>(out + (int64_t)r * j.cols + c + 4) = *reinterpret_cast<const uint4 *>(&tile[rl][cg + 4]);
+    } else {
+      const int ro = rt[r];
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int co = ct[c + i];
+        v[i] = (ro == PACK_PAD || co == PACK_PAD) ? 0.f : src[(int64_t)ro + co];
+      }
+      *reinterpret_cast<V *>(out + (int64_t)r * j.cols + c) = Vec4<TD>::make(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<V *>(out + (int64_t)r * j.cols + c + 4) = Vec4<TD>::make(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
 }  // namespace cum
 
 using namespace cum;
+
+extern "C" int cum_pack2d(const float *src, const void *jobs, const int32_t *tiles, int32_t n_tiles, const int32_t *tables,
+                          int32_t dst_dtype, void *dst, void *stream) {
+  CUM_REQUIRE(dtype_ok(dst_dtype), "pack2d: dst dtype must be CUM_F32 / CUM_BF16 / CUM_F16");
+  CUM_REQUIRE(n_tiles >= 0, "pack2d: negative tile count");
+  if (n_tiles == 0) return CUM_OK;
+  CUM_REQUIRE(src && jobs && tiles && tables && dst && ((uintptr_t)dst & 15) == 0, "pack2d: null or misaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const PackJob *pj = static_cast<const PackJob *>(jobs);
+  if (dst_dtype == CUM_F16)
+    hipLaunchKernelGGL(pack2d_kernel<f16>, dim3(n_tiles), dim3(256), 0, st, src, pj, tiles, tables, (f16 *)dst);
+  else if (dst_dtype == CUM_BF16)
+    hipLaunchKernelGGL(pack2d_kernel<__bf16>, dim3(n_tiles), dim3(256), 0, st, src, pj, tiles, tables, (__bf16 *)dst);
+  else
+    hipLaunchKernelGGL(pack2d_kernel<float>, dim3(n_tiles), dim3(256), 0, st, src, pj, tiles, tables, (float *)dst);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
 
 extern "C" int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n, int32_t dst_dtype,
                           void *dst, void *stream) {

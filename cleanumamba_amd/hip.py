@@ -82,6 +82,7 @@ SIGNATURES = {
     "cum_stft_loss_bwd": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P, _P]),
     "cum_stft_fold": (c_i32, [_P, c_i64, c_i64, c_i32, c_i32, c_i32, _P, c_i64, _P, c_i64, c_i32, _P]),
     "cum_gather": (c_i32, [c_i32, _P, _P, c_i64, c_i32, _P, _P]),
+    "cum_pack2d": (c_i32, [_P, _P, _P, c_i32, _P, c_i32, _P, _P]),
     "cum_add_layernorm_fwd": (c_i32, [c_i32, c_i32, c_i64, c_i32, c_i32, _P, c_i64, c_i64, _P, _P, _P, ctypes.c_float,
                                       _P, _P, _P, _P, _P]),
     "cum_add_layernorm_bwd_workspace_elems": (c_i64, [c_i32]),

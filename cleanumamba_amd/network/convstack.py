@@ -170,6 +170,31 @@ def _ids(shape):
     return torch.arange(1, n + 1, dtype=torch.int64).view(shape)      # 0 is reserved for "zero padding"
 
 
+PACK_PAD = -2 ** 31
+
+
+def _separable(g2):
+    """g2: [R, C] int64 global source index of a packed operand (-1 = zero padding).  Returns (rowoff, coloff, transpose)
+    with g2[r][c] == rowoff[r] + coloff[c] wherever both are valid (PACK_PAD marks padding), or None if the layout does not
+    separate.  transpose: neighbouring destination ROWS are the near neighbours in the source."""
+    valid = g2 >= 0
+    rv, cv = valid.any(1), valid.any(0)
+    if not bool(rv.any()) or not torch.equal(valid, rv[:, None] & cv[None, :]):
+        return None
+    r0, c0 = int(rv.nonzero()[0]), int(cv.nonzero()[0])
+    coloff = g2[r0] - g2[r0, c0]
+    rowoff = g2[:, c0].clone()
+    if not torch.equal((rowoff[:, None] + coloff[None, :])[valid], g2[valid]):
+        return None
+    if int(rowoff[rv].max()) + int(coloff[cv].abs().max()) >= 2 ** 31 - 1:
+        return None
+    dr = (rowoff[rv][1:] - rowoff[rv][:-1]).abs().float().median() if int(rv.sum()) > 1 else torch.tensor(float("inf"))
+    dc = (coloff[cv][1:] - coloff[cv][:-1]).abs().float().median() if int(cv.sum()) > 1 else torch.tensor(float("inf"))
+    rowoff = torch.where(rv, rowoff, torch.full_like(rowoff, PACK_PAD))
+    coloff = torch.where(cv, coloff, torch.full_like(coloff, PACK_PAD))
+    return rowoff.to(torch.int32), coloff.to(torch.int32), bool(dr < dc)
+
+
 class PackPlan:
     """Batches every weight / bias pack of one model into two gathers per forward.
 
@@ -249,18 +274,49 @@ class PackPlan:
             for rk, (g, shape) in self.reqs.items():
                 groups.setdefault((rk[2], rk[0][0] in self.LATE), []).append((rk, g, shape))
             for gk, items in groups.items():
-                metas, parts, start = [], [], 0
+                # separable 2-D layouts first (index-free cum_pack2d: two small tables per operand), the rest (bias
+                # vectors, anything irregular) behind them through the per-element index of cum_gather
+                metas, start = [], 0
+                jobs, tiles, tables, tab_pos = [], [], [], 0
+                rest = []
                 for rk, g, shape in items:
+                    sep = None
+                    if _PACK2D and len(shape) == 2 and shape[1] % 8 == 0 and self.source is not None:
+                        sep = _separable(g.view(shape).to(torch.int64))
+                    if sep is None:
+                        rest.append((rk, g, shape))
+                        continue
+                    ro, co, tr = sep
+                    jobs.append((start, shape[0], shape[1], tab_pos, tab_pos + shape[0], int(tr)))
+                    tables += [ro, co]
+                    tab_pos += shape[0] + shape[1]
+                    for tr_ in range((shape[0] + 63) // 64):
+                        for tc_ in range((shape[1] + 63) // 64):
+                            tiles.append((len(jobs) - 1, tr_, tc_))
+                    metas.append((rk, start, g.numel(), shape))
+                    start += (g.numel() + 7) // 8 * 8
+                rest_start, parts = start, []
+                for rk, g, shape in rest:
                     metas.append((rk, start, g.numel(), shape))
                     parts.append(g)
                     start += g.numel()
-                self.gidx[gk] = (torch.cat(parts).to(dev), metas)
+                pack2d = None
+                if jobs:
+                    import numpy as np
+                    jb = np.zeros(len(jobs), dtype=[("off", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("rt", "<i4"), ("ct", "<i4"),
+                                                    ("tr", "<i4"), ("pad", "<i4")])
+                    for i, (off, r, c, rt, ct, tr) in enumerate(jobs):
+                        jb[i] = (off, r, c, rt, ct, tr, 0)
+                    pack2d = (torch.from_numpy(jb.view(np.uint8)).to(dev), torch.tensor(tiles, dtype=torch.int32).to(dev),
+                              torch.cat(tables).to(dev), len(tiles))
+                gi = torch.cat(parts).to(dev) if parts else None
+                self.gidx[gk] = (gi, metas, pack2d, rest_start, start)
             self.dirty = False
         self.late_event = None
         with torch.no_grad():
             flat = self.source if self.source is not None else torch.cat([p.detach().reshape(-1) for p in self.params])
             cast, side = {}, None
-            for gk, (gi, metas) in self.gidx.items():
+            for gk, (gi, metas, pack2d, rest_start, total) in self.gidx.items():
                 dt, late = gk
                 if late and not grad_on:
                     for rk, _, _, _ in metas:         # not needed without a backward: a stale copy must not be served
@@ -274,9 +330,19 @@ class PackPlan:
                     flat_dt = cast[dt]
                 else:
                     flat_dt = flat                    # flat parameter buffer: converted inside the gather
-                out = self.big.get(gk)
-                if out is None:
-                    out = torch.empty(gi.numel(), dtype=dt, device=dev)
+                big = self.big.get(gk)
+                fresh = big is None
+                if fresh:
+                    big = torch.zeros(max(total, 8), dtype=dt, device=dev)
+
+                def run():
+                    if pack2d is not None:
+                        jb, tl, tb, ntiles = pack2d
+                        with torch.cuda.device(dev):
+                            hip.check(hip.lib().cum_pack2d(hip.ptr(flat), hip.ptr(jb), hip.ptr(tl), ntiles, hip.ptr(tb),
+                                                           hip.dtype_code(dt), hip.ptr(big), hip.stream_ptr()))
+                    if gi is not None:
+                        gather(flat_dt, gi, dt, out=big[rest_start:rest_start + gi.numel()])
                 if late and self.SIDE_STREAM:
                     if side is None:
                         side = self.__dict__.get("_side")
@@ -284,10 +350,10 @@ class PackPlan:
                             side = self.__dict__["_side"] = torch.cuda.Stream(device=dev)
                         side.wait_stream(torch.cuda.current_stream(dev))
                     with torch.cuda.stream(side):
-                        big = gather(flat_dt, gi, dt, out=out)
+                        run()
                 else:
-                    big = gather(flat_dt, gi, dt, out=out)
-                if self.big.get(gk) is not big:
+                    run()
+                if fresh:
                     self.big[gk] = big
                     for rk, start, n, shape in metas:
                         self.current[rk] = big[start:start + n].view(shape)
@@ -302,6 +368,7 @@ class PackPlan:
             self.late_event = None
 
 
+_PACK2D = os.environ.get("CUM_PACK2D", "1") != "0"      # "0": every packed operand through the per-element index (A/B)
 _ACTIVE_PLAN = None
 
 

@@ -259,6 +259,15 @@ int cum_stft_fold(const float *dframes, int64_t batch, int64_t len, int32_t n_ff
 int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n, int32_t dst_dtype, void *dst,
                void *stream);
 
+/* cum_pack2d: the same re-pack without a per-element index, for layouts that separate into dst[r][c] =
+ * src[rowoff[r] + coloff[c]] (all weight layouts of the conv stack and the projections: network/convstack.py PackPlan).
+ * jobs: device array of { int64 dst_off; int32 rows, cols (multiple of 8), row_tab, col_tab, transpose, pad } -- dst_off
+ * in elements (multiple of 8) from `dst`, row_tab / col_tab positions in `tables` (int32, INT32_MIN = zero padding),
+ * transpose = 1 when the source is fast along destination rows (the 64 x 64 tile then goes through LDS).
+ * tiles: device array of n_tiles x { job, tile row, tile column }.  src: f32. */
+int cum_pack2d(const float *src, const void *jobs, const int32_t *tiles, int32_t n_tiles, const int32_t *tables,
+               int32_t dst_dtype, void *dst, void *stream);
+
 /* Batched 1-D real FFTs for the STFT loss, on hipFFT / rocFFT (torch.stft's transform, src/util/stft_loss.py:29-33, and
  * its autograd).  Unnormalised in both directions.  The INPUT buffer may be overwritten (rocFFT's real transforms
  * do that for some lengths): pass scratch.  cum_rfft: in [batch][n] real -> out [batch][n/2+1] interleaved complex;

@@ -267,3 +267,51 @@ def test_fused_first_encoder_layer(cuda, tin, dtype, monkeypatch):
     for k in keys:
         assert record(tag + ".d" + k, rel_l2(g_f[k], ref[k].grad)) < btol, k
         assert rel_l2(g_f[k], g_g[k]) < btol, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_index_free_repack_equals_index_gather(cuda, dtype):
+    """cum_pack2d (row / column offset tables, LDS transpose) against cum_gather over the same layouts, bit for bit:
+    straight and transposed sources, padded rows and columns, ragged tile edges, several jobs in one launch."""
+    from cleanumamba_amd import hip
+    from cleanumamba_amd.network import convstack as cs
+    import numpy as np
+    gen = torch.Generator().manual_seed(3)
+    src = torch.randn(200_000, generator=gen).to(cuda)
+    cases = []                                         # (g2 [R, C] int64 with -1 padding)
+    # conv weight [Cout=70, Cin=33, K=4] at offset 1234, packed [72, 4 * 40] tap-major
+    g = torch.full((72, 160), -1, dtype=torch.int64)
+    o, t, i = torch.meshgrid(torch.arange(70), torch.arange(4), torch.arange(33), indexing="ij")
+    g[o.reshape(-1), (t * 40 + i).reshape(-1)] = (1234 + (o * 33 + i) * 4 + t).reshape(-1)
+    cases.append(g)
+    cases.append(g.t().contiguous()[:, :72])            # its transpose (source fast along destination rows)
+    # linear weight [N=130, K=96] at 50000 as-is and transposed with zero-padded tail columns
+    w = 50000 + torch.arange(130 * 96).view(130, 96)
+    cases.append(w.clone())
+    wt = torch.full((96, 136), -1, dtype=torch.int64)
+    wt[:, :130] = w.t()
+    cases.append(wt)
+    jobs, tiles, tables, pos, off = [], [], [], 0, 0
+    for g2 in cases:
+        sep = cs._separable(g2)
+        assert sep is not None
+        ro, co, tr = sep
+        R_, C_ = g2.shape
+        jobs.append((off, R_, C_, pos, pos + R_, int(tr), 0))
+        tables += [ro, co]
+        pos += R_ + C_
+        tiles += [(len(jobs) - 1, a, b) for a in range((R_ + 63) // 64) for b in range((C_ + 63) // 64)]
+        off += (R_ * C_ + 7) // 8 * 8
+    assert [j[5] for j in jobs] == [0, 1, 0, 1]
+    jb = np.array(jobs, dtype=[("off", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("rt", "<i4"), ("ct", "<i4"), ("tr", "<i4"),
+                               ("pad", "<i4")])
+    jbt = torch.from_numpy(jb.view(np.uint8).copy()).to(cuda)
+    tl = torch.tensor(tiles, dtype=torch.int32, device=cuda)
+    tb = torch.cat(tables).to(cuda)
+    out = torch.full((off,), 7.0, dtype=dtype, device=cuda)
+    hip.check(hip.lib().cum_pack2d(hip.ptr(src), hip.ptr(jbt), hip.ptr(tl), len(tiles), hip.ptr(tb), hip.dtype_code(dtype),
+                                   hip.ptr(out), hip.stream_ptr()))
+    for g2, j in zip(cases, jobs):
+        want = cs.gather(src, g2.reshape(-1).to(torch.int32).to(cuda), dtype)
+        got = out[j[0]:j[0] + g2.numel()]
+        assert torch.equal(want, got), (g2.shape, j)

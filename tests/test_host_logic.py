@@ -207,3 +207,35 @@ def test_flat_adam_checkpoint_rules_and_sink_registry():
     del opt16c, c
     gc.collect()
     assert not any(ptr in fo._SINKS for ptr in ptrs)
+
+
+def test_pack_layouts_separate_into_row_and_column_tables():
+    """network/convstack.py _separable: the host-side decision behind the index-free weight re-pack (cum_pack2d)."""
+    from cleanumamba_amd.network.convstack import _separable, PACK_PAD
+    # a [Cout, Cin, K] conv weight packed as [Cout_padded, K * Cin_padded] (tap-major), at offset 1000 of the flat buffer
+    co, ci, k, cop, cip = 5, 3, 4, 8, 8
+    g = torch.full((cop, k * cip), -1, dtype=torch.int64)
+    for o in range(co):
+        for t in range(k):
+            for i in range(ci):
+                g[o, t * cip + i] = 1000 + (o * ci + i) * k + t
+    ro, cl, tr = _separable(g)
+    assert not tr                                     # source stride k along columns (inside a tap), k * ci along rows
+    full = ro.long()[:, None] + cl.long()[None, :]
+    ok = (ro != PACK_PAD)[:, None] & (cl != PACK_PAD)[None, :]
+    assert torch.equal(ok, g >= 0) and torch.equal(full[ok], g[ok])
+    # its transpose: rows are now the near neighbours
+    ro2, cl2, tr2 = _separable(g.t().contiguous())
+    gt = g.t()
+    full2 = ro2.long()[:, None] + cl2.long()[None, :]
+    ok2 = (ro2 != PACK_PAD)[:, None] & (cl2 != PACK_PAD)[None, :]
+    assert tr2 and torch.equal(ok2, gt >= 0) and torch.equal(full2[ok2], gt[ok2])
+    # not separable: one element moved
+    h = g.clone()
+    h[1, 1] += 1
+    assert _separable(h) is None
+    # a hole that is not a whole row / column
+    h = g.clone()
+    h[0, 0] = -1
+    assert _separable(h) is None
+    assert _separable(torch.full((4, 8), -1, dtype=torch.int64)) is None

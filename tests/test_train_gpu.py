@@ -281,6 +281,29 @@ def _net442(cuda):
     return net.to(cuda).train()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, None])
+def test_every_repacked_operand_equals_its_index_gather(cuda, dtype):
+    """After real train steps, every operand the per-step re-pack (PackPlan.refresh: cum_pack2d for the layouts that
+    separate into row + column offsets, cum_gather for the rest) serves to the GEMMs equals, bit for bit, the recorded
+    per-element index applied to the flat parameter buffer -- and nearly all packed bytes take the index-free route."""
+    from cleanumamba_amd.network import convstack as cs
+    from cleanumamba_amd.training.train_step import TrainStep
+    net = _net442(cuda)
+    step = TrainStep(net, optimization={"n_iters": 200}, autocast_dtype=dtype, use_graph=False)
+    for it in range(3):
+        clean, noisy = synth.waveform(2, 8000, seed=40 + it)
+        step(clean.to(cuda), noisy.to(cuda))
+    plan = net._pack_plans[dtype if dtype is not None else torch.float32]
+    assert plan.source is not None and plan.reqs
+    plan.refresh()                                     # from the weights as the last optimizer step left them
+    for rk, (gidx, shape) in plan.reqs.items():
+        want = cs.gather(plan.source, gidx.to(cuda), rk[2]).view(shape)
+        assert torch.equal(want, plan.current[rk]), rk[0]
+    through2d = sum(v[3] for v in plan.gidx.values())
+    total = sum(v[4] for v in plan.gidx.values())
+    assert through2d > 0.95 * total, (through2d, total)
+
+
 @pytest.mark.parametrize("dtype", [None, torch.bfloat16])
 def test_graph_replay_equals_eager_steps(cuda, dtype):
     """The captured train step (forward, loss, backward, clip + Adam in one hipGraph) against the same steps run

@@ -1,5 +1,6 @@
-"""Where the weight re-pack gather spends its time: the model's real index against an identity index and a plain cast."""
-import sys, torch
+"""The per-step weight re-pack of the benched model: index-free cum_pack2d (+ index gather for what does not separate)
+against the all-index gather (CUM_PACK2D=0), and each operand checked bit for bit against the index gather."""
+import os, sys, torch
 sys.path.insert(0, ".")
 import bench
 from cleanumamba_amd.network import Net, convstack as cs
@@ -13,12 +14,16 @@ clean = 0.05 * torch.randn(2, 1, 16000, generator=g, device=dev)
 for _ in range(2):
     step(clean, clean)
 plan = net._pack_plans[torch.float16]
-for gk, (gi, metas) in plan.gidx.items():
-    n = gi.numel()
-    src = plan.source
-    out = torch.empty(n, dtype=gk[0], device=dev)
-    t_real = bench._time(lambda: cs.gather(src, gi, gk[0], out=out))
-    ident = (torch.arange(n, device=dev, dtype=torch.int64) % src.numel()).to(torch.int32)
-    t_id = bench._time(lambda: cs.gather(src, ident, gk[0], out=out))
-    t_cast = bench._time(lambda: out.copy_(src[:n] if n <= src.numel() else src.repeat(3)[:n]))
-    print(gk, "elements", n, "real idx %.3f ms" % t_real, "identity idx %.3f ms" % t_id, "plain cast/copy %.3f ms" % t_cast, flush=True)
+plan.refresh()                     # from the weights as the last optimizer step left them
+bad = 0
+for rk, (gidx, shape) in plan.reqs.items():
+    want = cs.gather(plan.source, gidx.to(dev), rk[2]).view(shape)
+    got = plan.current[rk]
+    if not torch.equal(want, got):
+        bad += 1
+        print("MISMATCH", rk[0], shape, float((want.float() - got.float()).abs().max()))
+print("operands", len(plan.reqs), "mismatching", bad)
+for gk, (gi, metas, pack2d, rest_start, total) in plan.gidx.items():
+    print(gk, "elements", total, "through pack2d", rest_start, "tiles", pack2d[3] if pack2d else 0,
+          "transposed jobs", int(sum(1 for j in pack2d[0].cpu().numpy().view("<i4").reshape(-1, 8)[:, 6] if j)) if pack2d else 0)
+print("refresh (PACK2D=%s): %.3f ms" % (os.environ.get("CUM_PACK2D", "1"), bench._time(plan.refresh)))

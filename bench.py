@@ -9,7 +9,7 @@ N > 1), clip_grad_norm_(10), fused Adam, LR schedule -- on synthetic 10 s @ 16 k
 (BASELINE configs[2]/[3]), random-init E8 weights.  Rank 0 prints ONE JSON line.
 
 value = global_batch * 160000 * K / (max-over-ranks time of K steps).
-roofline: the kernel with the largest share of the step (rocprofv3 --stats: gemm_tn8_kernel + gemm_tn_kernel, the conv-stack weight
+roofline: the kernel VERDICT names (rocprofv3 --stats: gemm_tn9_kernel + gemm_tn_kernel, the conv-stack weight
 gradients), timed live with HIP events over the 16 encoder launch shapes of the step; each shape is priced against the
 roof that binds it, the headline is the MFMA-bound group (enc3-enc7) against the dense 16-bit MFMA peak.  `kernels` lists the other heavy kernels the same way
 (forward GEMMs; selective scan forward / backward with the SURVEY.md 8d byte counts and state updates / s);
@@ -61,8 +61,8 @@ MFMA_PEAK_TFS = 2500.0      # MI355X_MICROARCH.md: bf16 / f16 dense
 # HBM bytes per gemm_tn launch (kernel + slab reduce), mean over the 10 MFMA-bound encoder weight-gradient shapes the
 # roofline object is quoted on.  NOT measured in this run: a constant from separate `rocprofv3 --pmc FETCH_SIZE` /
 # `--pmc WRITE_SIZE` passes over tools/bench_gemm.py tn, corrected as MI355X_MICROARCH.md prescribes
-# (profiles/r02_gemm_tn_pmc.md: 339.3 MB fetched + 70.1 MB written against 218.1 MB algorithmic).
-TN_TRAFFIC_BYTES = 409.4e6
+# (profiles/r03_gemm_tn_pmc.md: 337.7 MB fetched + 71.1 MB written against 218.1 MB algorithmic).
+TN_TRAFFIC_BYTES = 408.8e6
 # selective-scan issue roof, MEASURED: the bare inner-loop instruction mix of the forward kernel (per state pair v_pk_mul,
 # 2 x v_exp_f32, v_pk_mul, 2 x v_pk_fma) on registers only, every SIMD of the chip busy (tools/clock_probe.hip)
 SCAN_ISSUE_ROOF = 8.6e12     # state updates / s: tools/clock_probe.hip on MI355X (profiles/r02_clock_probe.txt: 8.56-8.89 T/s
@@ -95,7 +95,7 @@ def _name(dt):
 
 
 def tn_roofline(dev, dt=torch.bfloat16):
-    """The kernel with the largest share of the step (rocprofv3: gemm_tn8_kernel + gemm_tn_kernel, 46 launches per step): weight
+    """The weight-gradient GEMM (rocprofv3: gemm_tn9_kernel + gemm_tn_kernel, 46 launches per step): weight
     gradients dW = dZ^T X of the conv stack.  Timed live with HIP events on the 16 launch shapes the ENCODER
     contributes to one E8 / B=16 step (conv and 1x1 of each layer; the decoder's 16 launches mirror them with the
     same M*N*K).  Every shape is priced against the roof that binds it: algorithmic bytes s*M*(N + ldx) + 4*N*K over
@@ -128,11 +128,11 @@ def tn_roofline(dev, dt=torch.bfloat16):
     n_mf = sum(r["bound"] == "mfma" for r in rows)
     tf = fl / ms / 1e9
     hb = grp["hbm"]
-    return {"bound": "mfma", "kernel": f"gemm_tn8_kernel<{_name(dt)}> + tn_reduce_kernel: the MFMA-bound weight-gradient "
+    return {"bound": "mfma", "kernel": f"gemm_tn9_kernel<{_name(dt)}> + tn_reduce_kernel: the MFMA-bound weight-gradient "
                                        f"launches of one E8 B=16 step ({n_mf} encoder shapes, enc3-enc7; mirrored by the decoder)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFS, 4),
             "traffic": TN_TRAFFIC_BYTES, "traffic_source": "constant: mean HBM bytes per launch over these 10 shapes from separate "
-                                                             "PMC passes (profiles/r02_gemm_tn_pmc.md: 1.88 x algorithmic), not "
+                                                             "PMC passes (profiles/r03_gemm_tn_pmc.md: 1.87 x algorithmic), not "
                                                              "measured in this run",
             "launch_ms": round(ms / n_mf, 4), "algorithmic_flops": fl / n_mf, "launches": n_mf,
             "hbm_bound_shapes": {"shapes": len(rows) - n_mf, "achieved_GBps": round(hb[1] / hb[2] / 1e6, 1),
@@ -233,7 +233,7 @@ def other_kernels(dev, dt=torch.bfloat16):
             fl_sum += 2.0 * M * N * K
             del A, W, y
     tf = fl_sum / ms_sum / 1e9
-    out.append({"kernel": f"gemm_nt8_kernel / gemm_nt_kernel<{_name(dt)}> (ReLU / GLU epilogues), the 16 encoder forward launches of one step",
+    out.append({"kernel": f"gemm_nt9_kernel / gemm_nt_kernel<{_name(dt)}> (ReLU / GLU epilogues), the 16 encoder forward launches of one step",
                 "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_PEAK_TFS, 4), "launch_ms": round(ms_sum / 16, 4)})
     return out

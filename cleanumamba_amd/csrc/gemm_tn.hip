@@ -36,6 +36,9 @@ struct TnParams {
   int N, K;          // valid columns of dZ / of an X row (multiples of 4)
   int Np, Kp;        // slab dims (multiples of 128)
   int rows_per_split, nsplit;
+#ifdef CUM_AB
+  int skip_store;    // timing experiment (CUM_TN_NOSTORE=1, tools/tn_intercept.py): the slabs are not written
+#endif
 };
 
 constexpr int TN_T = 128;  // output tile (n and k)
@@ -751,6 +754,9 @@ __global__ __launch_bounds__(512) void gemm_tn9_kernel(const TnParams p) {
 #undef CUM_BIAS
 #undef CUM_STAGE
 
+#ifdef CUM_AB
+  if (p.skip_store && acc[0][0][0][0] != 12345.f) return;
+#endif
   // ---- slab store: lane holds D[k = kb + 4g + j][n = nb + r]
   float *slab = p.slab + (int64_t)sp * p.Np * p.Kp;
 #pragma unroll
@@ -907,6 +913,9 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   p.nsplit = S;
   p.slab = workspace;
   p.bslab = db ? workspace + (int64_t)S * Np * Kp : nullptr;
+#ifdef CUM_AB
+  p.skip_store = (int)cum_knob("CUM_TN_NOSTORE", 0);
+#endif
   dim3 grid(8 * (Np / TN_T) * (Kp / TN_T) * ((S + 7) / 8)), block(256);
   if (tn_use8(M, N, K, dtype)) {
     const int items = (N / 256) * (K / 256) * S;
@@ -928,6 +937,9 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   else
     hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();
+#ifdef CUM_AB
+  if (cum_knob("CUM_TN_NOREDUCE", 0)) return CUM_OK;      // timing experiment: the slabs are not combined
+#endif
   // combine the slabs: one pass for few slabs, two passes (16 partial sums, then those) for many
   const int C = reduce_chunks(S);
   float *part = workspace + (int64_t)S * Np * Kp + (int64_t)S * Np;

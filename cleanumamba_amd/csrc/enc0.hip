@@ -13,15 +13,9 @@
 // MFMA against a ones operand),  dW1 / db1 += dY1 x taps (40 FMAs per lane: the layer has no input gradient).
 // Partial sums per workgroup go to f32 slabs, a second launch adds them in a fixed order (deterministic) and writes
 // the two weight-gradient slots of the conv stack's arena in the layouts cum_gemm_tn would have produced.
-#include "common.h"
+#include "outer_common.h"
 
 namespace cum {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 e0_bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 e0_f16x8;
-typedef __attribute__((ext_vector_type(4))) float e0_f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned e0_u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned e0_u32x2;
 
 constexpr int E0_H = 64;          // conv output channels
 constexpr int E0_J = 128;         // 1x1 output rows (packed GLU order: per 32 rows 16 a | 16 b)
@@ -40,30 +34,6 @@ struct Enc0BwdParams {
   int64_t M;           // output rows (clips x pitch)
   int pitch, valid;    // rows per clip, real rows per clip
 };
-
-template <typename T>
-__device__ __forceinline__ e0_f32x4 e0_mfma(e0_u32x4 a, e0_u32x4 b, e0_f32x4 c) {
-  if constexpr (__is_same(T, f16))
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(e0_f16x8, a), __builtin_bit_cast(e0_f16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(e0_bf16x8, a), __builtin_bit_cast(e0_bf16x8, b), c, 0, 0, 0);
-}
-
-// Row m0 + row is a real row of its clip (not one of the zero rows between clips, not past the end).  t0 = m0 mod pitch
-// is formed once per step on 32-bit values: a 64-bit `m % pitch` per lane is a ~100-instruction software division, which
-// made the first version of these kernels compute-bound at a third of their memory rate.
-__device__ __forceinline__ bool e0_row_ok(unsigned t0, int row, int64_t m0, const int64_t M, unsigned pitch, unsigned valid) {
-  unsigned tt = t0 + (unsigned)row;
-  while (tt >= pitch) tt -= pitch;                   // at most once for pitch >= 32
-  return m0 + row < M && tt < valid;
-}
-
-template <typename T>
-__device__ __forceinline__ unsigned e0_pack2(float a, float b) {
-  typedef T V2 __attribute__((ext_vector_type(2)));
-  V2 v = {(T)a, (T)b};
-  return __builtin_bit_cast(unsigned, v);
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void enc0_bwd_kernel(const Enc0BwdParams p) {

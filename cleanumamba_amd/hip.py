@@ -102,6 +102,10 @@ SIGNATURES = {
     "cum_enc0_bwd_workgroups": (c_i32, [c_i64]),
     "cum_enc0_bwd_workspace_elems": (c_i64, [c_i64]),
     "cum_enc0_bwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cum_dec7_fwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P]),
+    "cum_dec7_bwd_workgroups": (c_i32, [c_i64]),
+    "cum_dec7_bwd_workspace_elems": (c_i64, [c_i64]),
+    "cum_dec7_bwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P]),
     "cum_lp_loss_parts": (c_i32, [c_i64]),
     "cum_lp_loss_fwd": (c_i32, [c_i32, _P, _P, c_i64, _P, _P, _P]),
     "cum_lp_loss_bwd": (c_i32, [c_i32, _P, _P, c_i64, _P, _P, _P]),
@@ -133,7 +137,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 7:
+        if L.cum_abi_version() != 8:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

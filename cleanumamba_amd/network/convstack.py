@@ -1138,6 +1138,45 @@ def _enc0_bwd(dz, xbuf, w1, b1, w2, gm, go, slot_w1, slot_w2):
                                    ctypes.c_void_p(a1.data_ptr() + 4 * o1), hip.ptr(ws), hip.stream_ptr()))
 
 
+_DEC7_FUSED = os.environ.get("CUM_DEC7_FUSED", "1") != "0"     # "0": last decoder layer on the generic GEMM path (A/B)
+
+
+def _dec7_ok(w1, wt, gi, gg, go, dt):
+    """The fused last-layer kernels (csrc/dec7.hip): 64 -> 128 1x1 + GLU, then 64 -> 1 transposed conv, 16-bit activations."""
+    return (_DEC7_FUSED and dt in hip.HALF_TYPES and tuple(w1.shape) == (128, 64, 1) and tuple(wt.shape) == (64, 1, 4)
+            and gi.C == 64 and gg.C == 64 and go.C == 1 and go.Cp == 8 and gi.P >= 32 and w1.dtype == torch.float32
+            and wt.dtype == torch.float32)
+
+
+def _dec7_fwd(ubuf, w1, b1, wt, bt, gi, go):
+    dt, dev = ubuf.dtype, ubuf.device
+    wp = _enc0_w2p(w1, gi, dt)
+    bp = take(b1, ("glu_vec", w1.shape[0]), lambda: lay_glu_vec(w1.shape[0]), torch.float32)
+    ybuf = go.new(dt, dev)
+    with torch.cuda.device(dev):
+        hip.check(hip.lib().cum_dec7_fwd(hip.dtype_code(dt), gi.M, gi.P, gi.T, hip.ptr(ubuf), hip.ptr(wp), hip.ptr(bp),
+                                         hip.ptr(wt.detach()), hip.ptr(bt.detach()), hip.ptr(ybuf), go.tail, hip.stream_ptr()))
+    return ybuf
+
+
+def _dec7_bwd(dy, ubuf, mask_bits, w1, b1, wt, gi, slot_w1, slot_wt):
+    """-> (dU, dU gated by the ReLU below) as row buffers of geometry gi; the weight / bias gradients of the 1x1 and of
+    the transposed conv go to their arena slots ((buffer, offset)) in the layouts cum_gemm_tn writes."""
+    dt, dev = ubuf.dtype, ubuf.device
+    wp = _enc0_w2p(w1, gi, dt)
+    bp = take(b1, ("glu_vec", w1.shape[0]), lambda: lay_glu_vec(w1.shape[0]), torch.float32)
+    lib = hip.lib()
+    du, dpre = gi.new(dt, dev), gi.new(dt, dev)
+    ws = torch.empty(lib.cum_dec7_bwd_workspace_elems(gi.M), dtype=torch.float32, device=dev)
+    (a1, o1), (a2, o2) = slot_w1, slot_wt
+    with torch.cuda.device(dev):
+        hip.check(lib.cum_dec7_bwd(hip.dtype_code(dt), gi.M, gi.P, gi.T, hip.ptr(dy), hip.ptr(ubuf), hip.ptr(mask_bits),
+                                   hip.ptr(wp), hip.ptr(bp), hip.ptr(wt.detach()), hip.ptr(du), hip.ptr(dpre), gi.tail,
+                                   ctypes.c_void_p(a1.data_ptr() + 4 * o1), ctypes.c_void_p(a2.data_ptr() + 4 * o2),
+                                   hip.ptr(ws), hip.stream_ptr()))
+    return du, dpre
+
+
 class EncoderStack(torch.autograd.Function):
     """x -> (x_1, ..., x_E): every encoder layer [Conv1d k4 s2, ReLU, Conv1d 1x1, GLU]
     (src/network/CleanUMamba.py:108-113) on row buffers.  geos[i] = (g_in, g_mid, g_out); params = w1, b1, w2, b2
@@ -1275,11 +1314,22 @@ class DecoderStack(torch.autograd.Function):
         E = len(geos)
         skips, params = list(rest[:n_skips]) + [None] * (E - n_skips), rest[n_skips:]
         us, gs, zs, acts = [ubuf], [], [], []
+        fused_last = False
         for j, (gi, gg, go) in enumerate(geos):
             w1, b1, wt, bt = params[4 * j:4 * j + 4]
             assert gi.T == gg.T and go.P == 2 * gg.P and gg.C == wt.shape[0] and go.C == wt.shape[1]
-            g, z = _glu_fwd(us[-1], w1, b1, gi, gg, save_z)
             relu = j < E - 1
+            # last layer (64 -> 1): g and the gate are rebuilt from u where the backward needs them (csrc/dec7.hip); the
+            # fused backward takes the ReLU of the layer below as sign bits and writes into the stack's arena
+            if (j == E - 1 and skips[j] is None and _dec7_ok(w1, wt, gi, gg, go, ubuf.dtype)
+                    and (not save_z or (E >= 2 and skips[E - 2] is not None and _SIGN_MASK and _ARENA_BATCH))):
+                us.append(_dec7_fwd(us[-1], w1, b1, wt, bt, gi, go))
+                gs.append(None)
+                zs.append(None)
+                acts.append(None)
+                fused_last = True
+                continue
+            g, z = _glu_fwd(us[-1], w1, b1, gi, gg, save_z)
             y, act = _convt_fwd(g, wt, bt, skips[j], gg, go, relu)
             us.append(y)
             gs.append(g)
@@ -1287,8 +1337,8 @@ class DecoderStack(torch.autograd.Function):
             acts.append(act)
         ctx.geos, ctx.E, ctx.saved_z, ctx.n_skips = geos, E, save_z, n_skips
         ctx.has_act = [a is not None for a in acts]
-        ctx.save_for_backward(*us[:E], *gs, *[z for z in zs if z is not None], *[a for a in acts if a is not None],
-                              *params)
+        ctx.fused_last = fused_last
+        ctx.save_for_backward(*us[:E], *gs, *zs, *[a for a in acts if a is not None], *params)
         return us[E]
 
     @staticmethod
@@ -1314,16 +1364,24 @@ class DecoderStack(torch.autograd.Function):
                                                  hip.stream_ptr()))
             dpre = gated
         du = None
+        g32s = [32 * ((params[4 * j].shape[0] // 2 + 15) // 16) for j in range(E)]       # packed 1x1 rows (16 a | 16 b per 32)
         # arena slots: 2 j = 1x1+GLU of layer j (N = G*32, K = Cp_in), 2 j + 1 = its transposed conv (N = 2 Cp_out,
         # K = 2 Cp_glu)
         arena = None
         if _ARENA_BATCH:
-            arena = _WgradArena([nk for j in range(E) for nk in ((2 * zs[j].shape[1], geos[j][0].Cp),
+            arena = _WgradArena([nk for j in range(E) for nk in ((g32s[j], geos[j][0].Cp),
                                                                  (2 * geos[j][2].Cp, 2 * geos[j][1].Cp))], dev)
         for j in reversed(range(E)):
             gi, gg, go = geos[j]
             w1, b1, wt, bt = params[4 * j:4 * j + 4]
             sht = tuple(wt.shape)
+            if j == E - 1 and ctx.fused_last:
+                (ab, ao), nk = arena.out(2 * j + 1), 2 * go.Cp * 2 * gg.Cp
+                du, dpre = _dec7_bwd(dpre, us[j], acts[j - 1][gi.Cp // 4:], w1, b1, wt, gi, arena.out(2 * j), (ab, ao))
+                grads[4 * j + 3] = (ab[ao + nk:ao + nk + go.Cp] + ab[ao + nk + go.Cp:ao + nk + 2 * go.Cp])[:sht[1]].to(wt.dtype)
+                if j - 1 < ctx.n_skips:
+                    dskips[j - 1] = du
+                continue
             # transposed-conv weight gradient: pair rows of dpre against the 2*Cp contiguous inputs (rows m-1, m)
             dwp, dbp = wgrad(dpre, go.Cp, 2 * go.Cp, 2 * go.Cp, gs[j], 0, gg.Cp, 2 * gg.Cp, gg.M,
                              out=arena.out(2 * j + 1) if arena else None)
@@ -1369,12 +1427,12 @@ class DecoderStack(torch.autograd.Function):
                 for j in range(E):
                     gi, gg, go = geos[j]
                     sh1, sht = shapes[3 * j], shapes[3 * j + 2]
-                    G32 = 2 * zs[j].shape[1]
+                    G32 = g32s[j]
                     out.append(arena.dw_index(2 * j, _invert(lay_glu_fwd(sh1, G32, gi.Cp), sh1)))
                     out.append(arena.db_index(2 * j, _invert(lay_glu_vec(sh1[0]), (sh1[0],))))
                     out.append(arena.dw_index(2 * j + 1, _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)))
                 return out
-            key = ("dec", tuple(shapes), tuple((g[0].Cp, g[1].Cp, g[2].Cp) for g in geos), tuple(z.shape[1] for z in zs))
+            key = ("dec", tuple(shapes), tuple((g[0].Cp, g[1].Cp, g[2].Cp) for g in geos), tuple(g32s))
             three = [params[4 * j + k] for j in range(E) for k in range(3)]
             sink = grad_sink(three)
             if sink is not None:           # w1, b1, wt straight into the flat gradient buffer (bt keeps the autograd path)

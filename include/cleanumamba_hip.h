@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 7
+#define CUM_ABI_VERSION 8
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -378,6 +378,29 @@ int64_t cum_enc0_bwd_workspace_elems(int64_t M);
 int cum_enc0_bwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const void *dZ, const void *xin,
                  const float *w1, const float *b1, const void *w2p, float *slot_w2, float *slot_w1, float *workspace,
                  void *stream);
+
+/* The last decoder layer, fused:  Conv1d(64 -> 128, 1x1) + GLU + ConvTranspose1d(64 -> 1, k 4, s 2) of
+ * src/network/CleanUMamba.py:121-130 at channels_output = 1, channels_H = 64 (E6 / E8), 16-bit element types.  The GLU
+ * output is rebuilt from the layer input wherever it is needed instead of being stored.
+ *   u        the layer's input row buffer [1 + M + slack][64]; M rows = clips x pitch, rows with (m mod pitch) >= valid
+ *            are the zero rows between clips; pair row p <= valid of a clip produces output rows 2 p, 2 p + 1
+ *   w1p, b1p the 1x1 conv in the forward GEMM's packed operand order ([128][64] element type / [128] f32, per 32 rows
+ *            16 a-rows then the 16 b-rows of the same channels); wt (64, 1, 4), bt (1): the transposed conv as stored, f32
+ * cum_dec7_fwd: out = output row buffer [1 + 2 M + slack][8] (channel 0 = the signal, channels 1-7 zero; row 0 and
+ *   zero_tail elements behind row 2 M are cleared).
+ * cum_dec7_bwd: dY = gradient of that buffer (channel 0 is read), mask = sign bits of the ReLU of the layer below as
+ *   cum_gemm_nt writes them (16 bytes per row, data row 0 first) -> dU = gradient of u, dpre = dU where the bit is set
+ *   (row buffers [1 + M + slack][64]; row 0 and zero_tail elements behind row M cleared), slot_w1 = dW1 [128][64] then
+ *   db1 [128], slot_wt = dW [16][128] then db [16]: the layouts cum_gemm_tn writes for the 1x1 and for the transposed
+ *   conv taken as a GEMM (N = output-row parity x 8 channels, K = (row m - 1 | row m) x 64 channels).
+ *   workspace: cum_dec7_bwd_workspace_elems(M) f32.  Deterministic (slabs per workgroup, added in index order). */
+int cum_dec7_fwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const void *u, const void *w1p, const float *b1p,
+                 const float *wt, const float *bt, void *out, int64_t zero_tail, void *stream);
+int32_t cum_dec7_bwd_workgroups(int64_t M);
+int64_t cum_dec7_bwd_workspace_elems(int64_t M);
+int cum_dec7_bwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const void *dY, const void *u, const void *mask,
+                 const void *w1p, const float *b1p, const float *wt, void *dU, void *dpre, int64_t zero_tail,
+                 float *slot_w1, float *slot_wt, float *workspace, void *stream);
 
 /* ---- waveform ends of the train step (csrc/loss.hip).  All sums are per-workgroup partials in fixed order + one
  * finishing workgroup: deterministic, graph-capturable, nothing returns to the host.

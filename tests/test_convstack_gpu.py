@@ -315,3 +315,65 @@ def test_index_free_repack_equals_index_gather(cuda, dtype):
         want = cs.gather(src, g2.reshape(-1).to(torch.int32).to(cuda), dtype)
         got = out[j[0]:j[0] + g2.numel()]
         assert torch.equal(want, got), (g2.shape, j)
+
+
+@pytest.mark.parametrize("t", [15, 127, 1030])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_last_decoder_layer(cuda, t, dtype, monkeypatch):
+    """csrc/dec7.hip -- the last decoder layer (64 -> 128 1x1, GLU, 64 -> 1 transposed conv) with its GLU output rebuilt
+    from the layer input instead of stored (src/network/CleanUMamba.py:121-130 at channels_output 1, channels_H 64) --
+    through a two-layer DecoderStack (the layer below supplies the ReLU sign bits the fused backward gates with):
+    output, the last layer's four parameter gradients and the gradient of its input (= of the skip) against the f64
+    oracle (the per-layer bounds); every gradient of the stack against the generic GEMM route on the same inputs;
+    bit-reproducible; and really taken."""
+    from cleanumamba_amd.network import convstack as cs
+    tol, btol = LAYER_TOL[dtype]
+    B, h0, h1 = 3, 128, 64
+    sd = {k: v for k, v in _layer_params(h0, h0, h1, seed=21).items() if k.startswith("decoder")}
+    sd.update({k.replace("decoder.0", "decoder.1"): v for k, v in _layer_params(h1, h1, 1, seed=22).items() if k.startswith("decoder")})
+    keys = [f"decoder.{j}.{i}.{n}" for j in range(2) for i in (0, 2) for n in ("weight", "bias")]
+    t1, t2 = 2 * t + 2, 2 * (2 * t + 2) + 2
+    gen = torch.Generator().manual_seed(23)
+    x, skip, dout = torch.randn(B, h0, t, generator=gen), torch.randn(B, h1, t1, generator=gen), torch.randn(B, 1, t2, generator=gen)
+    g0 = (cs.Geo(B, t, h0), cs.Geo(B, t, h0), cs.Geo(B, t1, h1))
+    g1 = (cs.Geo(B, t1, h1), cs.Geo(B, t1, h1), cs.Geo(B, t2, 1))
+    calls = []
+    real_fwd, real_bwd = cs._dec7_fwd, cs._dec7_bwd
+    monkeypatch.setattr(cs, "_dec7_fwd", lambda *a, **k: (calls.append("fwd"), real_fwd(*a, **k))[1])
+    monkeypatch.setattr(cs, "_dec7_bwd", lambda *a, **k: (calls.append("bwd"), real_bwd(*a, **k))[1])
+
+    def run(fused):
+        monkeypatch.setattr(cs, "_DEC7_FUSED", fused)
+        dev = {k: sd[k].to(cuda).requires_grad_(True) for k in keys}
+        xd, sk = x.to(cuda).requires_grad_(True), skip.to(cuda).requires_grad_(True)
+        ybuf = cs.DecoderStack.apply(cs.to_rows(xd, g0[0], dtype), [g0, g1], True, 1, cs.to_rows(sk, g0[2], dtype),
+                                     *[dev[k] for k in keys])
+        go = g1[2]
+        y = cs.from_rows(ybuf, go).float()
+        rows = go.rows(ybuf)
+        assert float(rows[:, go.T:].abs().max()) == 0 and float(ybuf[0].abs().max()) == 0      # framing rows stay zero
+        assert float(rows[:, :, 1:].abs().max()) == 0                                             # padding channels too
+        (y * dout.to(cuda)).sum().backward()
+        return y.detach(), {**{k: dev[k].grad.detach() for k in keys}, "x": xd.grad.detach(), "skip": sk.grad.detach()}
+    y_f, g_f = run(True)
+    assert calls == ["fwd", "bwd"]
+    y_f2, g_f2 = run(True)
+    assert torch.equal(y_f, y_f2) and all(torch.equal(g_f[k], g_f2[k]) for k in g_f)              # deterministic
+    y_g, g_g = run(False)
+    assert calls == ["fwd", "bwd"] * 2                                                           # generic route: not called
+    tag = f"dec7_fused[{t}-{dtype}]"
+    assert record(tag + ".fwd_vs_generic", rel_l2(y_f, y_g)) < tol
+    for k in g_f:
+        assert record(tag + ".vs_generic.d" + k, rel_l2(g_f[k], g_g[k])) < btol, k
+    # oracle for the fused layer alone, on the input the kernels saw: u = round(relu(layer 0) + skip) taken from the
+    # generic route's arithmetic (rebuilt here in f64 from rounded operands)
+    ref = {k: (_rounded(v, dtype) if k.endswith("weight") else v.double()).requires_grad_(True) for k, v in sd.items()}
+    with torch.no_grad():
+        u = R.decoder_layer(ref, 0, _rounded(x, dtype), last=False, store=_store(dtype)) + _rounded(skip, dtype)
+    ur = _rounded(u.float(), dtype).requires_grad_(True)
+    yr = R.decoder_layer(ref, 1, ur, last=True, store=_store(dtype))
+    (yr * dout.double()).sum().backward()
+    assert record(tag + ".fwd", rel_l2(y_f, yr)) < tol
+    assert record(tag + ".dskip", rel_l2(g_f["skip"], ur.grad)) < btol
+    for k in keys[4:]:
+        assert record(tag + ".d" + k, rel_l2(g_f[k], ref[k].grad)) < btol, k

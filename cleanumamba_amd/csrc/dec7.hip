@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void dec7_fwd_kernel(const Dec7FwdParams p) {
       float pv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float gv = ok ? (float)(T)((da[rr] + ba[rr]) * sigmoidf_(db[rr] + bb[rr])) : 0.f;   // g as the GEMM would read it
+        const float gv = e0_keep(ok, (float)(T)((da[rr] + ba[rr]) * sigmoidf_(db[rr] + bb[rr])));   // g as the GEMM would read it
 #pragma unroll
         for (int k = 0; k < 4; ++k) pv[k] = fmaf(gv, wtr[rr][k], pv[k]);
       }
@@ -308,12 +308,12 @@ __global__ __launch_bounds__(256) void dec7_bwd_kernel(const Dec7BwdParams p) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const float sg = sigmoidf_(db[rr] + bb[rr]);
-        const float gv = ok ? (float)(T)((da[rr] + ba[rr]) * sg) : 0.f;        // the stored GLU output of the generic path
+        const float gv = e0_keep(ok, (float)(T)((da[rr] + ba[rr]) * sg));      // the stored GLU output of the generic path
         float dg = d0 * wtr[rr][0];
         dg = fmaf(d1, wtr[rr][1], dg);
         dg = fmaf(d2, wtr[rr][2], dg);
         dg = fmaf(d3, wtr[rr][3], dg);
-        za[rr] = ok ? dg * sg : 0.f;                     // da = d sig(b)
+        za[rr] = e0_keep(ok, dg * sg);                   // da = d sig(b)
         zb[rr] = dg * gv * (1.f - sg);                   // db = d y (1 - sig(b)), y = the rounded output (0 on padding rows)
         awt[rr][0] = fmaf(gv, d0, awt[rr][0]);
         awt[rr][1] = fmaf(gv, d1, awt[rr][1]);

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void enc0_fwd_kernel(const Enc0FwdParams p) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const float a = da[rr] + ba[rr], b = db[rr] + bb[rr];
-        o[rr] = ok ? a * sigmoidf_(b) : 0.f;
+        o[rr] = e0_keep(ok, a * sigmoidf_(b));
         gv[rr] = ok ? b : 0.f;
       }
       const int off = (16 * mt + r) * E0_YS + (16 * w + 4 * g) * 2;

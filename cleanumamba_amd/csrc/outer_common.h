@@ -23,8 +23,15 @@ __device__ __forceinline__ e0_f32x4 e0_mfma(e0_u32x4 a, e0_u32x4 b, e0_f32x4 c) 
 // made the first version of these kernels compute-bound at a third of their memory rate.
 __device__ __forceinline__ bool e0_row_ok(unsigned t0, int row, int64_t m0, const int64_t M, unsigned pitch, unsigned valid) {
   unsigned tt = t0 + (unsigned)row;
-  while (tt >= pitch) tt -= pitch;                   // at most once for pitch >= 32
+  tt = tt >= pitch ? tt - pitch : tt;                // t0 < pitch, row < 32 <= pitch: one conditional subtraction
   return m0 + row < M && tt < valid;
+}
+
+// `v` where ok, else 0 -- as a select on an already computed value: left to itself the compiler branches around the
+// transcendental-heavy expressions that are only used under `ok` (four exec-mask branches per 16-row tile).
+__device__ __forceinline__ float e0_keep(bool ok, float v) {
+  asm volatile("" : "+v"(v));
+  return ok ? v : 0.f;
 }
 
 template <typename T>

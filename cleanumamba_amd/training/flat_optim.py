@@ -126,9 +126,14 @@ class FlatParams:
     def slot(self, param):
         """(index, element offset) of ``param`` if its gradient view may be overwritten now, else None."""
         i = self.by_ptr.get(param.data_ptr())
-        if i is None or not self.fresh[i] or param.grad is not self.grad_views[i]:
+        if not self.armed or i is None or not self.fresh[i] or param.grad is not self.grad_views[i]:
             return None
         return i, self.offsets[i]
+
+    # The sink is taken only inside a backward that its owner started (TrainStep.micro_step arms it): any other
+    # backward -- torch.autograd.grad(loss, params), a user's own loss.backward() -- sees plain autograd semantics
+    # (gradients returned / accumulated by AccumulateGrad), not None results and silently overwritten .grad views.
+    armed = False
 
     def wrote(self, indices):
         """The gradients of these parameters now sit in their views (they are no longer fresh); tell the exchange."""

@@ -121,7 +121,12 @@ class TrainStep:
         loss = self._loss(clean_audio, noisy_audio)
         scaled = loss / self.repeats if self.repeats > 1 else loss
         if self.flat:
-            self.optimizer.scale_loss(scaled).backward()
+            fp = self.buckets.flat
+            fp.armed = True                    # kernels may write parameter gradients straight into the flat buffer
+            try:
+                self.optimizer.scale_loss(scaled).backward()
+            finally:
+                fp.armed = False
         elif self.scaler is not None:
             self.scaler.scale(scaled).backward()
         else:

@@ -370,6 +370,33 @@ def test_gradient_sink_equals_autograd_accumulation(cuda, monkeypatch):
     assert float(grads[True].abs().sum()) > 0
 
 
+def test_foreign_backward_sees_plain_autograd(cuda):
+    """The gradient sinks are armed only inside TrainStep's own backward: torch.autograd.grad on a flat-managed model
+    returns every gradient (none swallowed into the flat buffer) and leaves the flat gradient buffer untouched; a plain
+    loss.backward() accumulates into the views through AccumulateGrad and equals the armed route."""
+    from cleanumamba_amd.training.train_step import TrainStep
+    clean, noisy = synth.waveform(2, 8000, seed=5)
+    clean, noisy = clean.to(cuda), noisy.to(cuda)
+    net = _net442(cuda)
+    step = TrainStep(net, optimization={"n_iters": 100}, use_graph=False)
+    flat = step.buckets.flat
+    step.zero_grad()
+    params = [p for p in net.parameters() if p.requires_grad]
+    got = torch.autograd.grad(step._loss(clean, noisy), params, allow_unused=True)
+    assert all(g is not None for g in got)
+    assert float(flat.grad.abs().sum()) == 0 and all(flat.fresh)
+    step.zero_grad()
+    step._loss(clean, noisy).backward()                       # a user's own backward: unarmed
+    plain = flat.grad.clone()
+    assert float(plain.abs().sum()) > 0
+    for p, g in zip(params, got):
+        assert rel_l2(p.grad, g) < 1e-6
+    step.zero_grad()
+    step.micro_step(clean, noisy)                             # armed: kernels write into the flat buffer
+    assert any(not f for f in flat.fresh)
+    assert rel_l2(flat.grad, plain) < 1e-6
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

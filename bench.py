@@ -240,8 +240,9 @@ def other_kernels(dev, dt=torch.bfloat16):
 
 
 def layer_table(net, dev, dt):
-    """SURVEY.md 8(d) rows a5 / a12 on the E8 B=16 training shapes: per encoder / decoder layer the TWO forward launches
-    (conv + ReLU, 1x1 + GLU | 1x1 + GLU, transposed conv + ReLU + skip) summed, against the FUSED layer's algorithmic
+    """SURVEY.md 8(d) rows a5 / a12 on the E8 B=16 training shapes: per encoder / decoder layer the forward launches the
+    model runs -- ONE for the first encoder / last decoder layer (csrc/enc0.hip, dec7.hip), else TWO (conv + ReLU,
+    1x1 + GLU | 1x1 + GLU, transposed conv + ReLU + skip) -- summed, against the FUSED layer's algorithmic
     traffic s*B*(Cin*Tin + H*Tout) (+ weights; decoder: s*B*(2*H*T + Cout*(2T+2))) and flops 2*B*Tout*(4*Cin*H + 2*H^2).
     The H-channel intermediate and the saved gate pre-activation are real traffic of the two-launch form that the
     algorithmic figure does not count: hbm_frac is what a fused layer kernel could recover on the outer layers."""
@@ -261,7 +262,11 @@ def layer_table(net, dev, dt):
         for i, ((gi, gm, go), enc) in enumerate(zip(enc_geos, net.encoder)):
             x = (0.5 * torch.randn(gi.R, gi.Cp, device=dev)).to(dt)
 
+            fused = i == 0 and cs._enc0_ok(enc[0].weight, enc[2].weight, gi, gm, go, dt)      # what the model runs
+
             def run():
+                if fused:
+                    return cs._enc0_fwd(x, enc[0].weight, enc[0].bias, enc[2].weight, enc[2].bias, gm, go, True)
                 y1 = cs._conv_relu_fwd(x, enc[0].weight, enc[0].bias, gi, gm)
                 return cs._glu_fwd(y1, enc[2].weight, enc[2].bias, gm, go, True)
             run()
@@ -270,7 +275,7 @@ def layer_table(net, dev, dt):
             Cin, H = gi.C, gm.C
             byt = s * B * (Cin * gi.T + H * go.T) + s * (4 * Cin * H + 2 * H * H)
             fl = 2.0 * B * go.T * (4 * Cin * H + 2 * H * H)
-            rows.append(_layer_row(f"enc{i} {Cin}->{H} T {gi.T}->{go.T}", ms, byt, fl))
+            rows.append(_layer_row(f"enc{i} {Cin}->{H} T {gi.T}->{go.T}", ms, byt, fl, 1 if fused else 2))
             del x
         E = len(net.decoder)
         gi = enc_geos[-1][2]
@@ -280,7 +285,11 @@ def layer_table(net, dev, dt):
             u = (0.5 * torch.randn(gi.R, gi.Cp, device=dev)).to(dt)
             skip = (0.5 * torch.randn(go.R, go.Cp, device=dev)).to(dt) if j < E - 1 else None
 
+            fused = j == E - 1 and cs._dec7_ok(dec[0].weight, dec[2].weight, gi, gg, go, dt)
+
             def run():
+                if fused:
+                    return cs._dec7_fwd(u, dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, gi, go)
                 g, _ = cs._glu_fwd(u, dec[0].weight, dec[0].bias, gi, gg, True)
                 return cs._convt_fwd(g, dec[2].weight, dec[2].bias, skip, gg, go, j < E - 1)
             run()
@@ -289,16 +298,16 @@ def layer_table(net, dev, dt):
             H, Cout = gg.C, go.C
             byt = s * B * (H * gi.T + Cout * go.T * (2 if skip is not None else 1)) + s * (2 * H * H + 4 * H * Cout)
             fl = 2.0 * B * gi.T * (2 * H * H + 4 * H * Cout)
-            rows.append(_layer_row(f"dec{j} {H}->{Cout} T {gi.T}->{go.T}", ms, byt, fl))
+            rows.append(_layer_row(f"dec{j} {H}->{Cout} T {gi.T}->{go.T}", ms, byt, fl, 1 if fused else 2))
             gi = go
             del u, skip
     return rows
 
 
-def _layer_row(name, ms, byt, fl):
+def _layer_row(name, ms, byt, fl, launches=2):
     gbs, tf = byt / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
     hb, mf = gbs / HBM_PEAK_GBS, tf / MFMA_PEAK_TFS
-    return {"layer": name, "launches": 2, "ms": round(ms, 4), "algorithmic_bytes": int(byt), "algorithmic_flops": int(fl),
+    return {"layer": name, "launches": launches, "ms": round(ms, 4), "algorithmic_bytes": int(byt), "algorithmic_flops": int(fl),
             "achieved_GBps": round(gbs, 1), "hbm_frac": round(hb, 4), "achieved_TFLOPs": round(tf, 1),
             "mfma_frac": round(mf, 4), "bound": "hbm" if byt / (HBM_PEAK_GBS * 1e9) > fl / (MFMA_PEAK_TFS * 1e12) else "mfma"}
 

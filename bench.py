@@ -481,9 +481,13 @@ def main():
     from cleanumamba_amd.training.train_step import TrainStep
     hip.lib()
 
-    if world > 1:
+    # CUM_EXCHANGE_ALONE=1 at --gpus 1: a one-rank RCCL group whose collectives all run (GradBuckets.exchanging) -- the
+    # data-parallel step's own cost on one GPU: two graphs + one 165.5 MB all-reduce launch instead of one graph
+    alone = world == 1 and os.environ.get("CUM_EXCHANGE_ALONE") == "1"
+    if world > 1 or alone:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # RCCL over xGMI ("nccl" on ROCm).  CUM_DIST_BACKEND=gloo exists only to exercise this code path with
         # several ranks on a one-GPU box; it is never what the scaling numbers are measured with.
         backend = os.environ.get("CUM_DIST_BACKEND", "nccl")
@@ -494,7 +498,7 @@ def main():
 
     torch.manual_seed(0)                                 # reference seeds 0 (src/training/train.py:51-53)
     net = Net("CleanUMamba", E8).to(dev).train()
-    if world > 1:
+    if world > 1 or alone:
         net = apply_gradient_allreduce(net)
     ac = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": None}[args.dtype]
     step = TrainStep(net, autocast_dtype=ac, use_graph=not args.no_graph)
@@ -562,7 +566,7 @@ def main():
                           "parallelism": f"dp{world}", "weights": "random init (reference init, seed 0)"},
                "final_loss": round(final_loss, 5), "step_graph": graph_status, "optimizer": optim_info,
                "host_ms_per_step_by_rank": [round(h, 3) for h in host_ms_ranks],
-               "exchange": ("none" if world == 1 else
+               "exchange": ("none" if world == 1 and not alone else
                             "one all-reduce (AVG) of the flat 165.5 MB gradient buffer between the two captured graphs"
                             if graph_status == "captured" else "per-bucket all-reduce overlapped with the eager backward")}
         if not args.no_roofline:
@@ -583,11 +587,19 @@ def main():
                 out["c5_streaming"] = c5_streaming(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_clip)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        line = json.dumps(out)
+    # The JSON line is the LAST line this job writes: libraries loaded by the ranks (RCCL prints its "Librccl path" line
+    # through C stdio, which a pipe buffers until exit) are flushed first, by every rank, before the closing barrier.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if world > 1 or alone:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -58,6 +58,10 @@ class GradBuckets:
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self.use_avg = self.distributed and dist.get_backend(process_group) == "nccl"
+        # a gradient exchange takes place: several ranks -- or ONE rank of an initialised group with
+        # CUM_EXCHANGE_ALONE=1, which runs every collective of the data-parallel step (bucketed all-reduce in the eager
+        # backward, whole-buffer all-reduce between the two captured graphs) against the real backend on a one-GPU box
+        self.exchanging = self.world > 1 or (self.distributed and os.environ.get("CUM_EXCHANGE_ALONE") == "1")
         self.flat = flat if flat is not None else FlatParams(module)
         self.params = self.flat.params
         self.require_sync = True
@@ -75,7 +79,7 @@ class GradBuckets:
         self.flat.on_write = self._written
         # producers that can hand over part of their gradients before they are done with all of them do so when there is
         # an exchange to overlap with (network/convstack.py EncoderStack.backward)
-        self.flat.early_announce = self.world > 1
+        self.flat.early_announce = self.exchanging
 
     def _written(self, params):
         """Gradients a kernel wrote straight into the flat buffer (FlatParams.wrote): same bookkeeping as the hook."""
@@ -97,7 +101,7 @@ class GradBuckets:
 
     def _ready(self, p):
         idx = self.where[id(p)][0]
-        if self.world == 1 or not self.require_sync:
+        if not self.exchanging or not self.require_sync:
             return
         if not self._armed:
             self._armed = True
@@ -119,7 +123,7 @@ class GradBuckets:
         """Average the WHOLE flat gradient buffer over the ranks with one collective on the current stream (the form the
         captured train step uses between its two graphs: 165.5 MB at E8 in one call -- xGMI is point-to-point, a ring
         is per-link bound, so one large collective beats five 32 MiB ones when nothing overlaps them anyway)."""
-        if self.world == 1:
+        if not self.exchanging:
             return
         g = self.flat.grad
         if self.use_avg:

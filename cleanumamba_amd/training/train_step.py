@@ -179,7 +179,7 @@ class TrainStep:
         try:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            if self.world == 1:
+            if not (self.buckets is not None and self.buckets.exchanging):
                 with torch.cuda.graph(graph):
                     loss, norm = self._body(g["clean"], g["noisy"], write_lr=False)
                 g.update(graph=graph, loss=loss, norm=norm)

@@ -10,6 +10,7 @@ usage: ddp_worker.py RANK WORLD PORT OUTDIR MODEL(442k|narrow_e8|e8) DTYPE(f32|f
 
   e8     the real 41.4 M-parameter E8 of bench.py, one 1 s clip per rank, the DEFAULT 32 MiB buckets
   graph  TrainStep(use_graph=True): with two ranks that is [captured fwd+loss+bwd] -> all-reduce -> [captured optimizer]
+CUM_EXCHANGE_ALONE=1 with WORLD 1: a one-rank RCCL ("nccl") group whose collectives all run (see GradBuckets.exchanging).
 """
 import json
 import os
@@ -55,12 +56,13 @@ def main():
     from cleanumamba_amd.training.train_step import TrainStep
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    if world > 1:
-        init_distributed(rank, world, None, "gloo", f"tcp://127.0.0.1:{port}")
+    alone = os.environ.get("CUM_EXCHANGE_ALONE") == "1"      # one rank of a real RCCL group: every collective runs, over one rank
+    if world > 1 or alone:
+        init_distributed(rank, world, None, "nccl" if alone else "gloo", f"tcp://127.0.0.1:{port}")
     torch.manual_seed(1000 + rank)                  # ranks initialise differently: the broadcast must fix it
     net = build(model, dev)
     n_buckets = 0
-    if world > 1:
+    if world > 1 or alone:
         if model == "e8":
             net = apply_gradient_allreduce(net)                           # the bench's configuration: 32 MiB buckets
         else:
@@ -99,7 +101,7 @@ def main():
                 "skipped": float(step.optimizer.state_vec[9]), "announced": announced, "buckets": n_buckets,
                 "graph_status": step.graph_status, "numel": sum(p.numel() for p in net.parameters())},
                os.path.join(out, f"rank{rank}_of{world}.pt"))
-    if world > 1:
+    if world > 1 or alone:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -405,9 +405,9 @@ def _free_port():
     return port
 
 
-def _run_ranks(tmp, world, model, dtype, stft, steps, graph=False):
+def _run_ranks(tmp, world, model, dtype, stft, steps, graph=False, extra_env=None):
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUM_TEST_RANKS="2")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUM_TEST_RANKS="2", **(extra_env or {}))
     logs = [open(os.path.join(tmp, f"log_{world}_{dtype}_{r}.txt"), "w+") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), str(world), str(port),
                                str(tmp), model, dtype, str(stft), str(steps)] + (["graph"] if graph else []), env=env,
@@ -518,6 +518,27 @@ def test_two_ranks_captured_step_equals_eager(cuda, tmp_path):
         assert torch.equal(graph[0]["params"][k], graph[1]["params"][k]), f"ranks diverged on {k}"
         assert rel_l2(graph[0]["params"][k], eager[0]["params"][k]) < 1e-5, k
     assert max(abs(a - b) for a, b in zip(graph[0]["losses"], eager[0]["losses"])) < 1e-5 * max(eager[0]["losses"])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_one_rank_rccl_group_runs_every_collective(cuda, tmp_path, graph):
+    """The data-parallel step against the REAL backend (RCCL, "nccl"): a one-rank process group with
+    CUM_EXCHANGE_ALONE=1 runs the parameter broadcast, the bucketed all-reduces inside the eager backward (async handles
+    waited in the engine's callback) and -- captured -- [graph] -> one whole-buffer all-reduce(AVG) -> [graph], with RCCL's
+    watchdog thread alive beside the capture.  Over one rank every collective is the identity, so parameters and losses
+    must equal the plain single-process run.  (Two ranks cannot share this box's one GPU under RCCL: "Duplicate GPU
+    detected"; several ranks are covered over gloo above.)"""
+    one = tmp_path / "alone"
+    ref = tmp_path / "plain"
+    one.mkdir()
+    ref.mkdir()
+    (a,) = _run_ranks(str(one), 1, "442k", "f32", 1, 6, graph=graph, extra_env={"CUM_EXCHANGE_ALONE": "1"})
+    (b,) = _run_ranks(str(ref), 1, "442k", "f32", 1, 6, graph=graph)
+    assert a["buckets"] >= 2 and b["buckets"] == 0
+    assert a["graph_status"] == ("captured" if graph else "off"), a["graph_status"]
+    for k in b["params"]:
+        assert rel_l2(a["params"][k], b["params"][k]) < 1e-6, k
+    assert max(abs(x - y) for x, y in zip(a["losses"], b["losses"])) < 1e-5 * max(b["losses"])
 
 
 def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path):

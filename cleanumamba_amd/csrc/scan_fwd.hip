@@ -325,13 +325,17 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
 // current block is computed (PB * ~260 issue cycles ~ 2 us of cover), and the block's B_t / C_t rows are staged
 // through a wave-private LDS tile (written and read by the same wave: s_waitcnt, no barrier) and fetched back as
 // broadcast ds_read_b128.  Checkpoints are written in the layout of the NW-wave kernels, so the backward is shared.
-template <int NW, typename TIO>
+// PB = 16: a whole chunk of rows in flight (the wave that runs alone on its SIMD); PB = 8: half a chunk -- 48 registers
+// fewer (164 -> <= 128 at d_state 8), i.e. FOUR waves per SIMD instead of three, for grids that bring more than three
+// waves per SIMD anyway (batch 128 at D = 2048: 4096 waves = one resident round instead of a 3 + 1 split).
+template <int NW, typename TIO, int PB>
 __global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) {
-  constexpr int PB = 16;                 // steps per block == TB: checkpoints fall on block starts and middles
   constexpr int NPD = NW * NS;           // padded state count (8 or 16)
   constexpr int NP2 = NPD / 2;
   constexpr int BCE = PB * 2 * NPD / 64; // B and C elements per lane and block
-  static_assert(PB == TB, "checkpoint positions assume one block per chunk");
+  constexpr int NBLK = TB / PB;          // blocks per 16-step chunk: checkpoints fall on chunk starts and middles
+  static_assert(PB == TB || PB == SUB, "a block is a chunk or one of its halves");
+  static_assert(BCE >= 1, "the B / C tile of a block gives every lane at least one element");
   __shared__ __attribute__((aligned(16))) float s_bc[2][PB][2 * NPD];
 
   const int lane = threadIdx.x;
@@ -388,9 +392,11 @@ __global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) 
   };
   load_block(0);
 
-  for (int c = 0; c < nchunks; ++c) {
-    const int t0 = c * PB;
-    float (*tile)[2 * NPD] = s_bc[c & 1];
+  const int nblocks = nchunks * NBLK;
+  for (int blk = 0; blk < nblocks; ++blk) {
+    const int t0 = blk * PB;
+    const int c = blk / NBLK;
+    float (*tile)[2 * NPD] = s_bc[blk & 1];
     float cu[PB], cdt[PB], cz[PB];
 #pragma unroll
     for (int k = 0; k < PB; ++k) {
@@ -398,15 +404,16 @@ __global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) 
     }
 #pragma unroll
     for (int k = 0; k < BCE; ++k) (&tile[0][0])[lane + 64 * k] = rbc[k];
-    if (c + 1 < nchunks) load_block(t0 + PB);        // the next block's rows travel while this one is computed
+    if (blk + 1 < nblocks) load_block(t0 + PB);      // the next block's rows travel while this one is computed
     // (same wave wrote the tile: LDS operations of one wave complete in order, the reads below see the writes)
 #pragma unroll
     for (int k = 0; k < PB; ++k) {
-      if ((k == 0 || k == SUB) && p.ckpt && dok) {
+      if ((k == 0 || (PB == TB && k == SUB)) && p.ckpt && dok) {
+        const int half = PB == TB ? (k == 0 ? 0 : 1) : (blk % NBLK);
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
           const f2 (&xs)[NS / 2] = *reinterpret_cast<const f2 (*)[NS / 2]>(&x[w * (NS / 2)]);
-          ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, k == 0 ? 0 : 1, NW, w, Dm, d), xs);
+          ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, half, NW, w, Dm, d), xs);
         }
       }
       float dtv = cdt[k] + bias;
@@ -859,7 +866,13 @@ static int launch_fwd_io(const ScanParams &p, hipStream_t st) {
     const int v = (int)cum_knob("CUM_SCAN_SMALL", 1);
     const int64_t ws_max = cum_knob("CUM_SCAN_WS_MAX", NW == 1 ? 1024 : 512);
     if (v == 2 || (v == 1 && (int64_t)grid.x * grid.y > ws_max)) {
-      hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO>), grid, dim3(64), 0, st, p);
+      // more waves per SIMD (1024 SIMDs) than the whole-chunk form fits (3 at d_state <= 8, 2 at <= 16): the half-chunk
+      // form, which fits one more
+      const int64_t half_min = cum_knob("CUM_SCAN_SMALL_HALF_MIN", NW == 1 ? 3072 : 2048);
+      if ((int64_t)grid.x * grid.y > half_min)
+        hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO, SUB>), grid, dim3(64), 0, st, p);
+      else
+        hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO, TB>), grid, dim3(64), 0, st, p);
       CUM_CHECK_LAUNCH();
       return CUM_OK;
     }

@@ -45,7 +45,10 @@ def test_scan_fwd_bwd_vs_golden(cuda, idx, layout):
                                    # d_state <= 16: the wave-specialised backward (csrc/scan_bwd_small.hip) -- the d_state
                                    # values of the shipped checkpoints (8, 12, 13, 14, 16), lengths around the 8-step half
                                    (2, 130, 16, 41), (2, 70, 12, 23), (1, 200, 14, 8), (3, 64, 9, 7), (2, 136, 13, 64),
-                                   (1, 8, 8, 129), (2, 48, 8, 9)])
+                                   (1, 8, 8, 129), (2, 48, 8, 9),
+                                   # grids with more than 3 (2) waves per SIMD at d_state <= 8 (<= 16): the half-chunk form
+                                   # of the one-wave forward (scan_fwd_small_kernel<.., SUB>), ragged last half
+                                   (100, 2048, 8, 41), (70, 2000, 13, 23)])
 def test_scan_odd_shapes_vs_oracle(cuda, shape):
     """ragged sizes: channels not a multiple of 64, d_state not a multiple of 8, L not a multiple of 16."""
     from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn

@@ -80,3 +80,43 @@ def test_bucketed_allreduce_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
+def _alone_worker(port, out):
+    """One rank of an initialised group: without CUM_EXCHANGE_ALONE nothing is exchanged (world size 1); with it every
+    collective of the step runs over the one rank and the gradients stay what they were."""
+    from cleanumamba_amd.training.train_distributed import GradBuckets, init_distributed
+    torch.set_num_threads(1)
+    init_distributed(0, 1, None, "gloo", f"tcp://127.0.0.1:{port}")
+    torch.manual_seed(3)
+    x = torch.randn(4, 1, 20)
+    grads = {}
+    for alone in ("0", "1"):
+        os.environ["CUM_EXCHANGE_ALONE"] = alone
+        torch.manual_seed(4)
+        net = nn.Sequential(nn.Conv1d(1, 8, 4, 2), nn.ReLU(), nn.Conv1d(8, 16, 1))
+        buckets = GradBuckets(net, bucket_bytes=256)
+        assert buckets.world == 1 and buckets.exchanging == (alone == "1")
+        launched = []
+        real = buckets._launch
+        buckets._launch = lambda flat: (launched.append(flat.numel()), real(flat))[1]
+        buckets.zero_grad()
+        net(x).square().mean().backward()
+        assert bool(launched) == (alone == "1") and not buckets.handles
+        before = buckets.flat.grad.clone()
+        buckets.exchange_all()
+        assert torch.equal(buckets.flat.grad, before)
+        grads[alone] = before
+    assert torch.allclose(grads["0"], grads["1"], rtol=1e-6, atol=1e-8)
+    out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_exchanges_only_on_request():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_alone_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"

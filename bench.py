@@ -47,9 +47,11 @@ def parse():
                          "reference's own training mode -- torch.autocast('cuda') + GradScaler, configs/config.json:14, "
                          "src/training/train.py:158-160, 278-280; accumulation, the scan recurrence, parameters and "
                          "optimizer state are f32 in every mode")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="run the step eagerly instead of replaying hipGraphs (N > 1: eager backward with per-bucket "
-                         "all-reduce overlap instead of [graph] -> one all-reduce -> [graph])")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="N > 1 only: the captured step ([graph] -> one whole-buffer all-reduce -> [graph]) instead of the "
+                         "default eager backward with per-bucket all-reduce overlap (the captured form is opt-in until it "
+                         "has run on several real GPUs over RCCL; one GPU always replays one graph unless --no-graph)")
     ap.add_argument("--rank-timeout", type=float, default=1500.0, help="seconds the launcher waits for its ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -501,7 +503,8 @@ def main():
     if world > 1 or alone:
         net = apply_gradient_allreduce(net)
     ac = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": None}[args.dtype]
-    step = TrainStep(net, autocast_dtype=ac, use_graph=not args.no_graph)
+    # use_graph=None: TrainStep's default -- one graph for one process, the eager overlapped exchange for several ranks
+    step = TrainStep(net, autocast_dtype=ac, use_graph=False if args.no_graph else (True if args.graph else None))
 
     B = args.batch_per_gpu
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

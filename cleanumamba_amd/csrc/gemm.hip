@@ -1529,33 +1529,47 @@ static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   return CUM_OK;
 }
 
-template <typename T>
-static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
+// Tile choice of cum_gemm_nt for one problem (esz: element size).  64 = the small-M kernel (64 x 64 tiles, K split over
+// the four waves), 128 = 128 x 128, 256 = 256 x 128 (f32), 512 = 256 x 256 with the two wave groups in ping-pong (16-bit).
+// cum_gemm_nt_tile() reports it, so tests can tell which kernel a shape is verified on.
+static int choose_tile(const GemmParams &p, int esz) {
   const int64_t mb256 = (p.M + 255) / 256;
   const int64_t tiles_256x256 = mb256 * ((p.N + 255) / 256), tiles_256x128 = mb256 * ((p.N + 127) / 128);
   // AB build: CUM_NT_TILE=64|128|256|512 pins the tile (split-K 64x64 / 128x128 / 256x128 / 256x256)
   int tile = (int)cum_knob("CUM_NT_TILE", 0);
   // few tiles and a K axis worth splitting: the small-M kernel (64x64 tiles, K split over the four waves)
   const int64_t tiles_128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-  const int bk = sizeof(T) == 2 ? 64 : 32;
+  const int bk = esz == 2 ? 64 : 32;
   // (allow_split_k == 2: the caller asks for it whatever the tile count -- the narrow Mamba projections, N <= 256 with
   //  K = 2048, where 128-wide tiles waste half of their columns and 78 row tiles do not fill the chip)
-  if ((tile == 64 || (!tile && (p.allow_split_k == 2 || (p.allow_split_k && tiles_128 <= 64)))) && p.K >= 4 * bk)
-    return launch_gemm_splitk<T>(p, epi, st);
+  if ((tile == 64 || (!tile && (p.allow_split_k == 2 || (p.allow_split_k && tiles_128 <= 64)))) && p.K >= 4 * bk) return 64;
   if (tile == 64) tile = 128;
   if (!tile) {
     // 256x256 (one workgroup per CU) once it fills the chip and N wastes little of the 256-wide tile; K >= 256 so the
     // saved weight traffic matters (the outer layers are bound by their activation traffic, where the tile shape is
     // irrelevant) ... and enough work per byte for one workgroup per CU to pay off: at N K / (N + K) < 256 (the 256 /
     // 512-channel layers with 320 512 rows) four 128 x 128 workgroups per CU are 5-18 % faster (same-box per-call table)
-    if (sizeof(T) == 2 && p.K >= 256 && tiles_256x256 >= 224 && p.N % 256 == 0 &&
+    if (esz == 2 && p.K >= 256 && tiles_256x256 >= 224 && p.N % 256 == 0 &&
         (int64_t)p.N * p.K >= 256 * (int64_t)(p.N + p.K)) tile = 512;
     // f32 (the parity path): 256-row tiles while they still give every CU >= 2 workgroups per XCD-round.  16-bit types
     // never take this tile: the 128 x 128 kernel routes its epilogue through LDS, which the outer, HBM-bound layers gain
     // more from than from the taller tile.
-    else if (sizeof(T) == 4 && p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
+    else if (esz == 4 && p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
     else tile = 128;
   }
+  if (esz == 2) {
+#ifndef CUM_AB
+    if (tile == 256) tile = 128;
+#endif
+    return tile;
+  }
+  return tile == 512 ? 256 : tile;
+}
+
+template <typename T>
+static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
+  const int tile = choose_tile(p, (int)sizeof(T));
+  if (tile == 64) return launch_gemm_splitk<T>(p, epi, st);
   if constexpr (sizeof(T) == 2) {
     if (tile == 512) {
 #ifdef CUM_AB
@@ -1568,7 +1582,7 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
 #endif
     return launch_gemm_tile<T, 128, 128>(p, epi, st);
   } else {
-    if (tile == 256 || tile == 512) return launch_gemm_tile<T, 256, 128>(p, epi, st);
+    if (tile == 256) return launch_gemm_tile<T, 256, 128>(p, epi, st);
     return launch_gemm_tile<T, 128, 128>(p, epi, st);
   }
 }
@@ -1611,6 +1625,13 @@ extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W,
   if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);
   if (d->dtype == CUM_F16) return launch_gemm<f16>(p, d->epilogue, (hipStream_t)stream);
   return launch_gemm<float>(p, d->epilogue, (hipStream_t)stream);
+}
+
+extern "C" int cum_gemm_nt_tile(const cum_gemm_desc *d) {
+  CUM_REQUIRE(d && dtype_ok(d->dtype), "gemm_nt_tile: bad argument");
+  GemmParams p{};
+  p.M = d->M; p.N = d->N; p.K = d->K; p.allow_split_k = d->allow_split_k;
+  return choose_tile(p, is16(d->dtype) ? 2 : 4);
 }
 
 extern "C" int cum_glu_bwd_gate(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Bg, int64_t ldb,

@@ -890,6 +890,10 @@ extern "C" int64_t cum_gemm_tn_workspace_elems(int32_t dtype, int64_t M, int32_t
   return (int64_t)S * Np * Kp + (int64_t)S * Np + C * (int64_t)N * K + C * (int64_t)Np;
 }
 
+extern "C" int cum_gemm_tn_tile(int32_t dtype, int64_t M, int32_t N, int32_t K) {
+  return tn_use8(M, N, K, dtype) ? 256 : TN_T;
+}
+
 extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
                            int64_t ldx, float *dW, int64_t ldw, float *db, float *workspace, void *stream) {
   CUM_REQUIRE(dtype_ok(dtype), "gemm_tn: dtype must be CUM_F32, CUM_BF16 or CUM_F16");

@@ -69,6 +69,8 @@ SIGNATURES = {
     "cum_causal_conv1d_bwd": (c_i32, [ctypes.POINTER(ConvShape)] + [_P] * 5 + [c_i64] * 3 + [_P] * 4),
     "cum_causal_conv1d_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, c_i32, _P, _P]),
     "cum_gemm_nt": (c_i32, [ctypes.POINTER(GemmDesc)] + [_P] * 8),
+    "cum_gemm_nt_tile": (c_i32, [ctypes.POINTER(GemmDesc)]),
+    "cum_gemm_tn_tile": (c_i32, [c_i32, c_i64, c_i32, c_i32]),
     "cum_glu_bwd_gate": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P, c_i64, _P]),
     "cum_glu_bwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, _P]),
     "cum_relu_bwd": (c_i32, [c_i32, c_i64, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, c_i64, c_i64, _P]),
@@ -137,7 +139,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 8:
+        if L.cum_abi_version() != 9:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -852,7 +852,14 @@ def _gemm_rows(x2, Kp, tail_ok=False):
     runs into the next row (finite values times zero weights) -- or a zero-padded copy."""
     K = x2.shape[1]
     ok = x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
-    if ok and (K == Kp or x2.stride(0) >= Kp or tail_ok):
+    # "the over-read stays inside the same row": the view's first column may sit at an offset c0 inside the parent's row
+    # (a column slice), so the test is c0 + Kp <= row length, not row stride >= Kp -- else the last Kp - K elements come
+    # from the next row (and from past the storage on the last row).  Non-finite caveat: inf / NaN times a zero weight is
+    # NaN, so the over-read columns must hold finite values (x_dbl's B | C columns next to dt do; a step that has already
+    # overflowed in f16 is skipped by the loss scaler whatever this GEMM returns).
+    c0 = x2.storage_offset() % x2.stride(0) if x2.stride(0) > 0 else 0
+    inside = x2.stride(0) >= Kp and c0 + Kp <= x2.stride(0)
+    if ok and (K == Kp or inside or tail_ok):
         return x2
     if K == Kp:
         return x2.contiguous()

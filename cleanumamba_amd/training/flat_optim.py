@@ -238,7 +238,8 @@ class FlatAdam:
                                    "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
         g = dict(self.param_groups[0])
         g["params"] = list(range(len(f.params)))
-        return {"state": state, "param_groups": [g], "flat_state": self.state_vec.detach().clone()}
+        return {"state": state, "param_groups": [g], "flat_state": self.state_vec.detach().clone(),
+                "loss_scaling": bool(self.loss_scaling)}
 
     def load_state_dict(self, sd):
         """Moments and the step count come from the checkpoint; the loss scale and its growth tracker only when both the
@@ -262,7 +263,12 @@ class FlatAdam:
                 saved = saved.detach().float().cpu()
                 if step is None:
                     step = float(saved[ST_STEP])
-                if self.loss_scaling and float(saved[ST_SCALE]) > 1.0:      # the checkpoint scaled its loss too
+                # the checkpoint scaled its loss too: said by its flag (a scale that had backed off to <= 1.0 is still a
+                # loss scale and is restored); checkpoints written before the flag existed: inferred from scale > 1
+                scaled = sd.get("loss_scaling")
+                if scaled is None:
+                    scaled = float(saved[ST_SCALE]) > 1.0
+                if self.loss_scaling and scaled:
                     self.state_vec[ST_SCALE] = float(saved[ST_SCALE])
                     self.state_vec[ST_TRACKER] = float(saved[ST_TRACKER])
             if step is not None:

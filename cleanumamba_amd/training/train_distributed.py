@@ -132,6 +132,16 @@ class GradBuckets:
             dist.all_reduce(g, group=self.group)
             g /= self.world
 
+    def all_ranks_agree(self, ok):
+        """True iff ``ok`` holds on every rank (an eager MIN all-reduce of one flag; call it outside any capture, at
+        a point every rank reaches at the same step)."""
+        if not self.distributed:
+            return bool(ok)
+        dev = self.flat.grad.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
     def _launch(self, flat):
         if self.use_avg:
             self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))

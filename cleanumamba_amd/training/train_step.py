@@ -82,7 +82,12 @@ class TrainStep:
             self.mrstft = MultiResolutionSTFTLoss(**self.loss_cfg["stft_config"]).to(dev)
         world = self.buckets.world if self.buckets is not None else 1
         if use_graph is None:
-            use_graph = self.flat and dev.type == "cuda"
+            # One process: the whole step replays from one hipGraph.  Several ranks: the eager step, whose per-bucket
+            # all-reduce overlaps the backward -- the captured form ([graph] -> one whole-buffer all-reduce -> [graph],
+            # `use_graph=True`) trades that overlap for three host calls per step and has never run on two or more real
+            # GPUs over RCCL, so it stays opt-in until a multi-GPU run shows it correct and faster.
+            exchanging = self.buckets is not None and self.buckets.exchanging
+            use_graph = self.flat and dev.type == "cuda" and not exchanging
         if use_graph and not self.flat:
             raise ValueError("use_graph needs the flat optimizer")
         self.use_graph = bool(use_graph)
@@ -197,6 +202,15 @@ class TrainStep:
         except Exception as exc:          # noqa: BLE001 - capture is an optimisation; stay eager
             g = {"failed": repr(exc)}
             warnings.warn(f"TrainStep: hipGraph capture of the train step failed ({exc!r}); steps run eagerly")
+        if self.buckets is not None and self.buckets.exchanging:
+            # The replayed step issues ONE whole-buffer all-reduce, the eager step one per bucket: ranks that disagree
+            # about which of the two they run would pair different collectives (hang, or averages of the wrong buffers).
+            # Every rank reaches this point at the same step (the warm-up count is the same everywhere), so an eager
+            # MIN-reduction of "my capture worked" -- issued outside any capture -- makes the choice collective.
+            if not self.buckets.all_ranks_agree("graph" in g):
+                if "graph" in g:
+                    g = {"failed": "another rank could not capture the train step"}
+                    warnings.warn("TrainStep: another rank failed to capture the train step; every rank runs eagerly")
         self._graph = g
 
     def __call__(self, clean_audio, noisy_audio):
@@ -206,9 +220,17 @@ class TrainStep:
         if self.use_graph and g is None and self._eager_steps >= GRAPH_WARMUP_STEPS:
             self._capture(clean_audio, noisy_audio)       # capture does not execute: the replay below is this step
             g = self._graph
-        if self.use_graph and g is not None and "graph" in g \
-                and (g["clean"].shape, g["clean"].dtype) == (clean_audio.shape, clean_audio.dtype) \
-                and (g["noisy"].shape, g["noisy"].dtype) == (noisy_audio.shape, noisy_audio.dtype):
+        replay = self.use_graph and g is not None and "graph" in g
+        if replay and not ((g["clean"].shape, g["clean"].dtype) == (clean_audio.shape, clean_audio.dtype)
+                           and (g["noisy"].shape, g["noisy"].dtype) == (noisy_audio.shape, noisy_audio.dtype)):
+            if "optim_graph" in g:
+                # several ranks: falling back to the eager step on THIS rank alone would mismatch the collectives
+                raise RuntimeError(
+                    f"TrainStep: the captured multi-rank step takes batches of {tuple(g['clean'].shape)} "
+                    f"{g['clean'].dtype}; got {tuple(clean_audio.shape)} {clean_audio.dtype}.  Keep the batch shape "
+                    "fixed (drop the last partial batch) or build the step with use_graph=False")
+            replay = False
+        if replay:
             self.buckets.flat.require_intact()
             g["clean"].copy_(clean_audio)
             g["noisy"].copy_(noisy_audio)

@@ -78,7 +78,9 @@ def loss_fn(net, X, cross_entropy=None, ell_p=1, ell_p_lambda=1, stft_lambda=1, 
     denoised_audio = net(noisy_audio)
     if ell_p not in (1, 2):
         raise NotImplementedError
-    if denoised_audio.is_cuda:
+    plain = (denoised_audio.is_cuda and clean_audio.is_cuda and denoised_audio.shape == clean_audio.shape
+             and (torch.is_autocast_enabled() or (denoised_audio.dtype == clean_audio.dtype == torch.float32)))
+    if plain:
         # two launches with a fixed summation order; ATen's one-value reduction of 16 x 160 000 samples goes through a
         # staging buffer + semaphore that did not survive the replay of the captured train step (csrc/loss.hip)
         from ..network.convstack import LpLoss

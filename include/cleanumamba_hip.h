@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 8
+#define CUM_ABI_VERSION 9
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -197,6 +197,10 @@ typedef struct {
 
 int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias,
                 const void *res, void *out, void *aux, const void *aux2, void *stream);
+/* Which kernel cum_gemm_nt runs for this problem (only dtype, M, N, K, allow_split_k are read): 64 = 64 x 64 tiles with
+ * K split over the waves, 128 = 128 x 128, 256 = 256 x 128 (f32), 512 = 256 x 256 with two wave groups in ping-pong
+ * (16-bit).  Lets a parity test state which kernel a shape was verified on. */
+int cum_gemm_nt_tile(const cum_gemm_desc *d);
 
 /* GLU backward on the packed pre-activation Z [M][ldz] (n_groups x (16 a | 16 b));
  * dOut [M][ldo] has 16 channels per group (n_out valid columns); dZ has Z's layout. */
@@ -229,6 +233,8 @@ int64_t cum_gemm_tn_workspace_elems(int32_t dtype, int64_t M, int32_t N, int32_t
 int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz,
                 const void *X, int64_t ldx, float *dW, int64_t ldw, float *db, float *workspace,
                 void *stream);
+/* Output tile edge of the kernel cum_gemm_tn runs for this problem: 256 (ping-pong kernel) or 128. */
+int cum_gemm_tn_tile(int32_t dtype, int64_t M, int32_t N, int32_t K);
 
 /* ---- multi-resolution STFT loss around rocFFT (src/util/stft_loss.py:16-184) -------------------------------------
  * One resolution = (n_fft, hop, win_length, window[win_length]); torch.stft(center=True, reflect) framing:

@@ -72,6 +72,15 @@ def main():
     ac = {"f32": None, "f16": torch.float16, "bf16": torch.bfloat16}[dtype]
     step = TrainStep(net, optimization={"n_iters": 1000}, loss_config={"stft_lambda": int(stft)},
                      autocast_dtype=ac, use_graph=use_graph)
+    if os.environ.get("CUM_TEST_BREAK_CAPTURE") == str(rank):
+        # this rank's capture fails (the others' succeed): every rank must end up on the eager step
+        real_micro = step._micro_steps
+
+        def broken(*a, **k):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("capture broken on purpose (test)")
+            return real_micro(*a, **k)
+        step._micro_steps = broken
     if world > 1:
         clean, noisy = batch(rank, per_rank, length, dev)
     else:                                            # the single-process run sees the concatenated batch

@@ -140,8 +140,9 @@ def _ref_gemm(A, W, bias):
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 6e-3), (torch.float16, 8e-4)])   # output rounding only
 @pytest.mark.parametrize("M,N,K", [(300, 64, 64), (1000, 192, 512), (60001, 256, 256), (140003, 192, 256)])
 def test_gemm_backward_epilogues_against_torch(cuda, M, N, K, dtype, tol):
-    """The backward epilogues of cum_gemm_nt through the C ABI, ragged M (edge tiles); the four shapes make the
-    launcher pick the 128x128, 128x128, 256x256 and 256x128 tiles:
+    """The backward epilogues of cum_gemm_nt through the C ABI, ragged M (edge tiles).  All four shapes run the
+    128 x 128 kernel (asserted below; the 256 x 256 ping-pong kernel's epilogues are pinned by test_dispatch_map_gpu.py
+    on shapes the library reports as taking it):
     3 = ReLU gate from a full activation and from sign nibbles (+ ungated second output);
     4 = GLU backward from the packed (a | b) pre-activation and from the gate-only form (+ residual)."""
     from cleanumamba_amd import hip
@@ -151,6 +152,10 @@ def test_gemm_backward_epilogues_against_torch(cuda, M, N, K, dtype, tol):
     A = rn(M, K).to(cuda).to(dtype)
     W = (rn(N, K) / K ** 0.5).to(cuda).to(dtype)
     acc = _ref_gemm(A.cpu().float(), W.cpu().float(), None)            # what the MFMA accumulates (inputs already rounded)
+    import ctypes
+    desc = hip.GemmDesc()
+    desc.dtype, desc.M, desc.N, desc.K = hip.dtype_code(dtype), M, N, K
+    assert hip.lib().cum_gemm_nt_tile(ctypes.byref(desc)) == 128
 
     # ---- epilogue 3
     Y = rn(M, N).to(cuda).to(dtype)                                     # activation whose sign gates

@@ -64,6 +64,10 @@ def _worker(rank, world, port, out):
     assert not torch.allclose(local_only, want, rtol=1e-3, atol=1e-5), "ranks saw different data: local != averaged"
     loss = torch.tensor([float(rank + 1)])
     assert reduce_tensor(loss, world).item() == 1.5
+    # the ranks' choice between the replayed and the eager step is collective: one dissenting rank decides for all
+    assert net.grad_buckets.all_ranks_agree(True) is True
+    assert net.grad_buckets.all_ranks_agree(rank == 0) is False
+    assert net.grad_buckets.all_ranks_agree(False) is False
     out.put((rank, "ok"))
     dist.barrier()
     dist.destroy_process_group()

@@ -100,10 +100,14 @@ def test_autocast_gradients_vs_reference(cuda, name, dtype):
     record(f"autocast_grad_all[{name}-{dtype}].rel", rel_l2(grads["lo"], grads["f32"]))
     cos = torch.nn.functional.cosine_similarity(grads["lo"].double(), grads["f32"].double(), dim=0).item()
     record(f"autocast_grad_all[{name}-{dtype}].cos", cos)     # measured 0.75 / 0.95 (E8), 0.26 / 0.74 (E6) for bf16 / f16
-    # NOT a parity check: on random weights the ReLU gates that flip under 16-bit rounding decorrelate an end-to-end
-    # gradient whichever implementation computes it.  What is asserted for the full gradient is only that it is finite
-    # (above) and not degenerate; the parity statements of this test are the two `*_last` bounds.
-    assert float(grads["lo"].abs().max()) > 0
+    # Not a tight parity bound: on random weights the ReLU gates that flip under 16-bit rounding decorrelate an end-to-end
+    # gradient whichever implementation computes it (the parity statements of this test are the two `*_last` bounds).
+    # But a sign or scale error in any of the recomputing backward kernels (enc0 / dec7 / the fused outer layers / the
+    # one-node Mamba block) would turn the projection on the f32 gradient negative or tiny: bound = about half of the
+    # smallest value measured per configuration (profiles/r03_test_measured.jsonl).
+    cos_min = {("e2e_e8_synth", torch.bfloat16): 0.35, ("e2e_e8_synth", torch.float16): 0.45,
+               ("e2e_e6_synth", torch.bfloat16): 0.12, ("e2e_e6_synth", torch.float16): 0.35}[(name, dtype)]
+    assert cos > cos_min, (name, dtype, cos)
 
 
 def test_train_step_fp16_autocast_e8(cuda):
@@ -520,6 +524,24 @@ def test_two_ranks_captured_step_equals_eager(cuda, tmp_path):
     assert max(abs(a - b) for a, b in zip(graph[0]["losses"], eager[0]["losses"])) < 1e-5 * max(eager[0]["losses"])
 
 
+def test_two_ranks_agree_on_eager_when_one_capture_fails(cuda, tmp_path):
+    """a rank whose capture fails must not run the eager per-bucket exchange while the other replays its
+    graphs and issues the single whole-buffer all-reduce.  Rank 1's capture is broken on purpose: both ranks report a
+    failed capture, run every step eagerly, stay bit-identical and match the all-eager run."""
+    import warnings
+    (tmp_path / "g").mkdir()
+    (tmp_path / "e").mkdir()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        broken = _run_ranks(tmp_path / "g", 2, "442k", "f32", 1, 7, graph=True, extra_env={"CUM_TEST_BREAK_CAPTURE": "1"})
+    eager = _run_ranks(tmp_path / "e", 2, "442k", "f32", 1, 7)
+    assert broken[1]["graph_status"].startswith("failed") and "on purpose" in broken[1]["graph_status"]
+    assert broken[0]["graph_status"].startswith("failed") and "another rank" in broken[0]["graph_status"]
+    for k in broken[0]["params"]:
+        assert torch.equal(broken[0]["params"][k], broken[1]["params"][k]), f"ranks diverged on {k}"
+        assert rel_l2(broken[0]["params"][k], eager[0]["params"][k]) < 1e-5, k
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_one_rank_rccl_group_runs_every_collective(cuda, tmp_path, graph):
     """The data-parallel step against the REAL backend (RCCL, "nccl"): a one-rank process group with
@@ -541,15 +563,18 @@ def test_one_rank_rccl_group_runs_every_collective(cuda, tmp_path, graph):
     assert max(abs(x - y) for x, y in zip(a["losses"], b["losses"])) < 1e-5 * max(b["losses"])
 
 
-def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path):
+@pytest.mark.parametrize("captured", [False, True])
+def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path, captured):
     """`python bench.py --gpus 2 ...` with no rank environment must start its own two ranks (fresh processes, here both on
-    the one GPU with gradients over gloo), and print ONE JSON line for n_gpus = 2 -- the shape of the driver's command."""
+    the one GPU with gradients over gloo), and print ONE JSON line for n_gpus = 2 -- the shape of the driver's command.
+    Default for several ranks: the eager step with the per-bucket exchange overlapped with backward; `--graph` opts into
+    [graph] -> one all-reduce -> [graph]."""
     import json
     torch.cuda.empty_cache()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(CUM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline",
-           "--batch-per-gpu", "2", "--rank-timeout", "600"]
+           "--batch-per-gpu", "2", "--rank-timeout", "600"] + (["--graph"] if captured else [])
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=700)
     assert res.returncode == 0, res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -557,4 +582,5 @@ def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 4
     assert out["value"] > 0 and out["scaling"] == "weak" and len(out["host_ms_per_step_by_rank"]) == 2
-    assert out["step_graph"] == "captured", out["step_graph"]
+    assert out["step_graph"] == ("captured" if captured else "off"), out["step_graph"]
+    assert ("per-bucket" in out["exchange"]) == (not captured), out["exchange"]

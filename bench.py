@@ -172,6 +172,16 @@ def _scan_case(dev, bsz, dim, Ns, L, io, backward):
         with torch.no_grad():
             return fwd()
     t_i = _time(fwd_nograd)
+    from cleanumamba_amd import hip
+    from cleanumamba_amd.mamba_ssm.ops import selective_scan_interface as ssi
+    _scan_case.sequential_ms = None
+    if hip.lib().cum_scan_fwd_workspace_elems(bsz, dim, Ns, L) > 0:
+        # this shape takes the time-parallel forward (csrc/scan_seg.hip): the sequential kernels on the same box beside it
+        ssi.TIME_PARALLEL = False
+        try:
+            _scan_case.sequential_ms = _time(fwd_nograd)
+        finally:
+            ssi.TIME_PARALLEL = True
     t_b = None
     if backward:
         out = fwd()                      # checkpoints saved once; the op's backward node alone is replayed
@@ -195,11 +205,13 @@ def scan_rows(dev, dt):
              ("D=2048 N=16 L=2499 B=128, f32 I/O", 128, 2048, 16, 2499, torch.float32, False),
              ("D=2048 N=8 L=2499 B=128, f32 I/O", 128, 2048, 8, 2499, torch.float32, False),
              ("D=2048 N=8 L=2499 B=128", 128, 2048, 8, 2499, dt, False),
+             ("E8 bottleneck B=1 (file denoising) D=2048 N=64 L=624", 1, 2048, 64, 624, dt, False),
              ("442K model B=16 D=128 N=16 L=624", 16, 128, 16, 624, torch.float32, True),
              ("pruned-E8 block B=256 D=48 N=8 L=1875 (30 s)", 256, 48, 8, 1875, torch.float32, True)]
     rows = []
     for name, bsz, dim, Ns, L, io, bwd in cases:
         t_i, t_b = _scan_case(dev, bsz, dim, Ns, L, io, bwd)
+        seq_ms = _scan_case.sequential_ms
         sz = torch.empty((), dtype=io).element_size()
         upd = bsz * L * dim * Ns
         for kind, ms, byt in (("fwd", t_i, bsz * L * (sz * 4 * dim + 4 * 2 * Ns)),
@@ -212,6 +224,9 @@ def scan_rows(dev, dt):
                          "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "state_updates_T_per_s": round(ups / 1e12, 3),
                          "issue_roof_frac": round(ups / issue_roof, 4) if kind == "fwd" else None,
                          "binding_roof": "hbm" if byt / (HBM_PEAK_GBS * 1e9) > upd / issue_roof else "v_exp_f32 issue"})
+            if kind == "fwd" and seq_ms is not None:
+                rows[-1].update(path="time-parallel (segments + carry, csrc/scan_seg.hip)",
+                                sequential_kernel_ms=round(seq_ms, 4), speedup_vs_sequential=round(seq_ms / ms, 2))
     return rows
 
 

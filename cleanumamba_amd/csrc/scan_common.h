@@ -37,6 +37,9 @@ struct ScanParams {
   void *du, *ddelta, *dz;
   float *ws_dA, *ws_dD, *ws_dbias, *ws_dB, *ws_dC;
   int nchunks, ngroups;
+  // segmented (time-parallel) forward, scan_seg.hip: nseg segments of seg_chunks chunks; carry = its workspace
+  int nseg, seg_chunks;
+  float *carry;
 };
 
 // Checkpoint buffer: the NS states a lane (channel d) of wave w holds, entering half h of chunk c of clip b, as
@@ -80,6 +83,11 @@ __device__ __forceinline__ void load_bc(const float *base, int sn, int nvalid, f
 }
 
 int scan_check_shape(const cum_scan_shape *s);
+// time-parallel forward for grids that do not fill the chip (scan_seg.hip): plan (nseg == 1: sequential kernels),
+// workspace size in f32 elements, launcher
+void scan_seg_plan(int batch, int dim, int dstate, int len, int *nseg, int *seg_chunks);
+int64_t scan_seg_carry_elems(int batch, int dim, int dstate, int nseg);
+int launch_fwd_segmented(const ScanParams &p, hipStream_t st);
 // d_state <= 16: wave-specialised backward (scan_bwd_small.hip); the caller runs scan_bwd_finalize_kernel afterwards
 int launch_bwd_small(const ScanParams &p, hipStream_t st);
 

@@ -948,10 +948,24 @@ extern "C" int64_t cum_scan_ckpt_elems(int32_t batch, int32_t dim, int32_t dstat
   return 2 * (int64_t)batch * nchunks * nw * dim * NS;   // the state entering each 8-step half of every chunk
 }
 
+extern "C" int64_t cum_scan_fwd_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len) {
+  if (batch <= 0 || dim <= 0 || dstate <= 0 || dstate > 64 || len <= 0) return 0;
+  int nseg, sc;
+  scan_seg_plan(batch, dim, dstate, len, &nseg, &sc);
+  return nseg > 1 ? scan_seg_carry_elems(batch, dim, dstate, nseg) : 0;
+}
+
 extern "C" int cum_selective_scan_fwd(const cum_scan_shape *s, const void *u, const void *delta, const float *A,
                                       const float *Bm, const float *Cm, const float *D, const void *z,
                                       const float *delta_bias, void *out, float *last_state, float *ckpt,
                                       void *stream) {
+  return cum_selective_scan_fwd_ws(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last_state, ckpt, nullptr, stream);
+}
+
+extern "C" int cum_selective_scan_fwd_ws(const cum_scan_shape *s, const void *u, const void *delta, const float *A,
+                                         const float *Bm, const float *Cm, const float *D, const void *z,
+                                         const float *delta_bias, void *out, float *last_state, float *ckpt,
+                                         float *workspace, void *stream) {
   if (int rc = scan_check_shape(s)) return rc;
   if (s->batch == 0) return CUM_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -967,6 +981,13 @@ extern "C" int cum_selective_scan_fwd(const cum_scan_shape *s, const void *u, co
   p.out = out; p.last_state = last_state; p.ckpt = ckpt;
   p.nchunks = (s->len + TB - 1) / TB;
   p.ngroups = (s->dim + 63) / 64;
+  if (workspace) {          // the caller offers the segmented path its workspace: taken when the plan splits the sequence
+    scan_seg_plan(s->batch, s->dim, s->dstate, s->len, &p.nseg, &p.seg_chunks);
+    if (p.nseg > 1) {
+      p.carry = workspace;
+      return launch_fwd_segmented(p, st);
+    }
+  }
   switch ((s->dstate + NS - 1) / NS) {
     case 1: return launch_fwd<1>(p, st);
     case 2: return launch_fwd<2>(p, st);

@@ -60,6 +60,8 @@ SIGNATURES = {
     "cum_scan_chunk": (c_i32, []),
     "cum_scan_ckpt_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "cum_selective_scan_fwd": (c_i32, [ctypes.POINTER(ScanShape)] + [_P] * 12),
+    "cum_scan_fwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "cum_selective_scan_fwd_ws": (c_i32, [ctypes.POINTER(ScanShape)] + [_P] * 13),
     "cum_scan_bwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "cum_selective_scan_bwd": (c_i32, [ctypes.POINTER(ScanShape), ctypes.POINTER(ScanGradStrides)] + [_P] * 20),
     "cum_selective_state_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, _P, c_i64, _P, c_i64,

@@ -129,10 +129,7 @@ class _MambaInnerFn(torch.autograd.Function):
         if save:
             ckpt = torch.empty(max(lib.cum_scan_ckpt_elems(Bn, Dn, N, L), 1), dtype=torch.float32, device=dev)
         ss = ssi._shape(xcT, dtT, zv, yT, Bm, Cm, True)
-        with torch.cuda.device(dev):
-            hip.check(lib.cum_selective_scan_fwd(ctypes.byref(ss), hip.ptr(xcT), hip.ptr(dtT), hip.ptr(A), hip.ptr(Bm),
-                                                 hip.ptr(Cm), hip.ptr(Df), hip.ptr(zv), hip.ptr(bias), hip.ptr(yT), None,
-                                                 hip.ptr(ckpt), hip.stream_ptr()))
+        ssi.scan_forward(ss, xcT, dtT, A, Bm, Cm, Df, zv, bias, yT, None, ckpt, ssi.TIME_PARALLEL)
         ctx.save_for_backward(xz, w2, cb, xc, x_dbl, dt, bc, A, Df, bias, ckpt, xw, dtw)
         ctx.params = (conv_w, conv_b, xw, dtw, dt_bias, A_log, Dp)
         ctx.cd, ctx.dims = cd, (Bn, L, Dn, N, R)

@@ -53,6 +53,24 @@ def _shape(u, delta, z, out, Bm, Cm, softplus):
     return s
 
 
+def scan_forward(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last, ckpt, time_parallel=True):
+    """Launch the forward scan described by ``s`` (a hip.ScanShape).  Where the sequential grid -- batch * ceil(dim / 64)
+    * ceil(d_state / 8) waves -- would leave most of the chip idle (batch-1 file denoising, the 442K model, the pruned
+    checkpoints), the library asks for a workspace and runs its time-parallel form (csrc/scan_seg.hip: segments walked
+    from zero, composed with the scan's associative operator, re-walked from their true entering states).
+    ``time_parallel=False`` pins the sequential kernels (tests compare the two)."""
+    lib = hip.lib()
+    n = lib.cum_scan_fwd_workspace_elems(s.batch, s.dim, s.dstate, s.len) if time_parallel else 0
+    ws = torch.empty(n, dtype=torch.float32, device=u.device) if n > 0 else None
+    with torch.cuda.device(u.device):
+        hip.check(lib.cum_selective_scan_fwd_ws(ctypes.byref(s), hip.ptr(u), hip.ptr(delta), hip.ptr(A), hip.ptr(Bm),
+                                                hip.ptr(Cm), hip.ptr(D), hip.ptr(z), hip.ptr(delta_bias), hip.ptr(out),
+                                                hip.ptr(last), hip.ptr(ckpt), hip.ptr(ws), hip.stream_ptr()))
+
+
+TIME_PARALLEL = True        # module switch for tests / A-B timing: False pins the sequential forward kernels
+
+
 class SelectiveScanFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
@@ -78,11 +96,7 @@ class SelectiveScanFn(torch.autograd.Function):
             ckpt = torch.empty(max(lib.cum_scan_ckpt_elems(bsz, dim, N, L), 1), dtype=torch.float32, device=u.device)
         last = torch.empty(bsz, dim, N, dtype=torch.float32, device=u.device) if return_last_state else None
         s = _shape(u, delta, z, out, Bm, Cm, delta_softplus)
-        with torch.cuda.device(u.device):
-            hip.check(lib.cum_selective_scan_fwd(ctypes.byref(s), hip.ptr(u), hip.ptr(delta), hip.ptr(A),
-                                                 hip.ptr(Bm), hip.ptr(Cm), hip.ptr(D), hip.ptr(z),
-                                                 hip.ptr(delta_bias), hip.ptr(out), hip.ptr(last), hip.ptr(ckpt),
-                                                 hip.stream_ptr()))
+        scan_forward(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last, ckpt, TIME_PARALLEL)
         ctx.delta_softplus = bool(delta_softplus)
         ctx.has_z = z is not None
         ctx.b4 = (B.dim() == 4, C.dim() == 4)

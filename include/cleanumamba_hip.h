@@ -80,6 +80,20 @@ int cum_selective_scan_fwd(const cum_scan_shape *s, const void *u, const void *d
                            const void *z, const float *delta_bias, void *out,
                            float *last_state, float *ckpt, void *stream);
 
+/* The same op with a workspace, which lets the library take its TIME-PARALLEL form where the sequential grid
+ * (batch * ceil(dim/64) * ceil(dstate/8) waves) does not fill the chip -- file denoising at batch 1
+ * (src/examples/denoise.py), the 442K model, the pruned checkpoints: the sequence is cut into segments, every segment is
+ * walked from a zero state, the segments' (decay, end state) pairs are composed with the scan's associative operator
+ * (a, b) o (a', b') = (a' a, a' b + b'), and every segment is re-walked from its true entering state (scan_seg.hip).
+ * Outputs, last_state and the checkpoints have the same meaning and layout; results equal the sequential kernels' up to
+ * f32 rounding of the segment decay.  workspace: f32, cum_scan_fwd_workspace_elems() elements -- 0 means the sequential
+ * kernels run (pass NULL); a NULL workspace always selects them. */
+int64_t cum_scan_fwd_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len);
+int cum_selective_scan_fwd_ws(const cum_scan_shape *s, const void *u, const void *delta,
+                              const float *A, const float *Bm, const float *Cm, const float *D,
+                              const void *z, const float *delta_bias, void *out,
+                              float *last_state, float *ckpt, float *workspace, void *stream);
+
 /* Strides (batch, dim, len) of the three per-element gradient outputs. */
 typedef struct {
   int64_t du_sb, du_sd, du_sl;

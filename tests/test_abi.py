@@ -33,6 +33,11 @@ def test_size_queries_and_argument_errors():
     assert lib.cum_scan_ckpt_elems(1, 5, 13, 16) == 2 * 1 * 1 * 2 * 5 * 8
     assert lib.cum_scan_bwd_workspace_elems(2, 100, 13, 7) == 2 * 100 * 13 + 2 * 2 * 100 + 2 * 2 * 2 * 7 * 13
     assert lib.cum_conv_bwd_workspace_elems(2, 10, 33, 4) == 2 * 3 * 5 * 10
+    # time-parallel forward scan: a workspace is asked for only where the sequential grid leaves the chip mostly idle
+    assert lib.cum_scan_fwd_workspace_elems(16, 2048, 64, 624) == 0             # E8 training shape: 4 096 waves
+    # batch-1 E8: 256 waves -> 13 segments of 3 chunks; per segment 8 waves x 2048 channels x 8 states + 2048 sums
+    assert lib.cum_scan_fwd_workspace_elems(1, 2048, 64, 624) == 13 * (8 * 2048 * 8 + 2048)
+    assert lib.cum_scan_fwd_workspace_elems(1, 128, 16, 61) == 0                # four chunks: nothing to split
     # bad arguments are rejected before any launch (works without a GPU)
     s = hip.ScanShape()
     s.batch, s.dim, s.dstate, s.len = 1, 4, 200, 4

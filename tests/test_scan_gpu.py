@@ -72,6 +72,86 @@ def test_scan_odd_shapes_vs_oracle(cuda, shape):
         assert rel_l2(dev[k].grad, ref[k].grad) < BWD_TOL, k
 
 
+def _segments(shape):
+    from cleanumamba_amd import hip
+    return hip.lib().cum_scan_fwd_workspace_elems(*shape)
+
+
+@pytest.mark.parametrize("io", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape,opts", [
+    ((1, 2048, 64, 624), "plain"),          # file denoising at batch 1, E8 bottleneck (src/examples/denoise.py)
+    ((16, 128, 16, 624), "plain"),          # the 442K model at the training batch
+    ((8, 48, 8, 500), "plain"),             # a pruned-E8 block (d_inner 48, d_state 8)
+    ((2, 70, 13, 257), "no_z"),             # ragged everything: channels, states, last chunk, last segment
+    ((1, 100, 37, 200), "no_softplus_no_bias"),
+    ((3, 8, 8, 129), "no_D"),
+    ((2, 136, 12, 97), "plain")])
+def test_time_parallel_scan_vs_oracle_and_sequential(cuda, shape, opts, io):
+    """SURVEY 8 row a9' (north_star: "wavefront shuffle / prefix-sum for the scan recurrence"): the segmented forward
+    (csrc/scan_seg.hip) on grids the sequential kernels would leave mostly idle -- against the f64 oracle (output,
+    last_state, and EVERY gradient through the unchanged backward kernels, which consume the checkpoints the segmented
+    pass wrote) and against the sequential kernels on the same inputs."""
+    from cleanumamba_amd.mamba_ssm.ops import selective_scan_interface as ssi
+    bsz, dim, N, L = shape
+    assert _segments(shape) > 0, "the plan does not segment this shape"
+    gen = torch.Generator().manual_seed(sum(shape))
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    cpu = dict(u=rn(bsz, L, dim).transpose(1, 2), delta=0.5 * rn(bsz, L, dim).transpose(1, 2),
+               A=-torch.exp(0.5 * rn(dim, N)), B=rn(bsz, L, N).transpose(1, 2), C=rn(bsz, L, N).transpose(1, 2),
+               D=rn(dim), z=rn(bsz, L, dim).transpose(1, 2), delta_bias=0.5 * rn(dim))
+    if opts == "no_softplus_no_bias":
+        cpu["delta"] = cpu["delta"].abs()
+    drop = {"plain": (), "no_z": ("z",), "no_softplus_no_bias": ("delta_bias",), "no_D": ("D",)}[opts]
+    softplus = opts != "no_softplus_no_bias"
+    for k in ("u", "delta", "z"):
+        cpu[k] = cpu[k].to(io).float()                      # the values the kernels read
+    dout = rn(bsz, L, dim).transpose(1, 2)
+
+    def run(t, fn, cast=None):
+        c = (lambda v: v.to(cast)) if cast is not None else (lambda v: v)
+        y, last = fn(c(t["u"]), c(t["delta"]), t["A"], t["B"], t["C"], t.get("D"), z=None if "z" not in t else c(t["z"]),
+                     delta_bias=t.get("delta_bias"), delta_softplus=softplus, return_last_state=True)
+        return y, last
+    ref = {k: v.double().detach().requires_grad_(True) for k, v in cpu.items() if k not in drop}
+    yr, lastr = run(ref, M.selective_scan_ref)
+    (yr * dout.double()).sum().backward()
+    out = {}
+    for mode in (True, False):
+        ssi.TIME_PARALLEL = mode
+        try:
+            dev = {k: v.to(cuda).requires_grad_(True) for k, v in cpu.items() if k not in drop}
+            y, last = run(dev, ssi.selective_scan_fn, cast=io)
+            (y.float() * dout.to(cuda)).sum().backward()
+        finally:
+            ssi.TIME_PARALLEL = True
+        out[mode] = (y.float(), last, {k: dev[k].grad.float() for k in dev})
+    y, last, grads = out[True]
+    ftol, btol = (FWD_TOL, BWD_TOL) if io == torch.float32 else (6e-4, 2e-3)      # f16: output / gradient rounding
+    assert rel_l2(y, yr) < ftol
+    assert rel_l2(last, lastr) < FWD_TOL
+    for k in grads:
+        assert rel_l2(grads[k], ref[k].grad) < btol, k
+    # against the sequential kernels: only the rounding of the segment decay exp2(A' sum delta') differs
+    ys, lasts, gs = out[False]
+    assert rel_l2(y, ys) < (3e-6 if io == torch.float32 else 6e-4) and rel_l2(last, lasts) < 3e-6
+    for k in grads:
+        assert rel_l2(grads[k], gs[k]) < (3e-5 if io == torch.float32 else 2e-3), k
+    # bit-reproducible
+    ssi.TIME_PARALLEL = True
+    dev = {k: v.to(cuda) for k, v in cpu.items() if k not in drop}
+    y2, last2 = run(dev, ssi.selective_scan_fn, cast=io)
+    assert torch.equal(y2.float(), y) and torch.equal(last2, last)
+
+
+def test_time_parallel_plan():
+    """The plan: segmented when the sequential grid brings fewer than two waves per SIMD and the sequence has at least
+    three segments of two 16-step chunks; never for the training shapes that fill the chip."""
+    assert _segments((16, 2048, 64, 624)) == 0 and _segments((32, 2048, 64, 2499)) == 0      # E8 / E6 training
+    assert _segments((1, 2048, 64, 624)) > 0 and _segments((16, 128, 16, 624)) > 0 and _segments((256, 48, 8, 1875)) > 0
+    assert _segments((1, 128, 16, 61)) == 0                                                      # 4 chunks: too short
+    assert _segments((0, 8, 8, 100)) == 0 and _segments((1, 8, 8, 0)) == 0
+
+
 @pytest.mark.parametrize("N", [8, 16])
 @pytest.mark.parametrize("opts", ["plain", "no_z", "no_softplus_no_bias", "no_D"])
 def test_scan_small_state_optional_arguments(cuda, N, opts):

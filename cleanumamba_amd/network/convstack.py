@@ -1030,7 +1030,10 @@ def _glu_fwd(xbuf, w, b, gi, go, save_z):
     return ybuf, z
 
 
-def _conv_relu_fwd(xbuf, w, b, gi, go):
+def _conv_relu_fwd(xbuf, w, b, gi, go, want_bits=False):
+    """Conv1d(k4, s2) + ReLU.  ``want_bits``: also -> the SIGN of every output element, four channels per byte (row buffer
+    geometry): the backward's ReLU gate then reads 1/8 of the bytes of the activation itself (EPI_MASK with mask_bits;
+    the activation is still kept -- it is the 1x1's weight-gradient operand)."""
     dt, dev = xbuf.dtype, xbuf.device
     H = w.shape[0]
     Np, Kp = rup(H, 16), rup(4 * gi.Cp, bk_of(dt))
@@ -1038,8 +1041,13 @@ def _conv_relu_fwd(xbuf, w, b, gi, go):
     wp = take(w, ("conv_fwd", sh, gi.Cp, Np, Kp), lambda: lay_conv_fwd(sh, gi.Cp, Np, Kp), dt)
     bp = take(b, ("vec", H, Np), lambda: lay_vec(H, Np), torch.float32)
     ybuf = go.new(dt, dev)
+    if want_bits and _SIGN_MASK and dt in hip.HALF_TYPES and go.Cp % 16 == 0:
+        bits = torch.empty(go.R * go.Cp // 4, dtype=torch.uint8, device=dev)
+        gemm(xbuf, gi.Cp, 2 * gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_RELU, go.Cp, geo=go,
+             aux=bits[go.Cp // 4:], x_off=0, ldz=go.Cp, mask_bits=True)
+        return ybuf, bits
     gemm(xbuf, gi.Cp, 2 * gi.Cp, wp, bp, ybuf, go.Cp, go.Cp, go.M, go.P, go.T, hip.EPI_RELU, go.Cp, geo=go)
-    return ybuf
+    return (ybuf, None) if want_bits else ybuf
 
 
 def _convt_fwd(xbuf, w, b, skip, gi, go, relu):
@@ -1102,6 +1110,7 @@ def _glu_dgrad_weights(w, gi, G32, dt):
                 lambda: torch.nn.functional.pad(lay_glu_fwd(sh, G32, Nd).t(), (0, Kd - G32)), dt)
 
 
+_ENC_BITS = os.environ.get("CUM_ENC_BITS", "1") != "0"           # "0": the encoder's ReLU gates read the activation (A/B)
 _ENC0_FUSED = os.environ.get("CUM_ENC0_FUSED", "1") != "0"     # "0": first encoder layer on the generic GEMM path (A/B)
 
 
@@ -1191,21 +1200,25 @@ class EncoderStack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xbuf, geos, save_z, *params):
-        bufs, y1s, zs = [xbuf], [], []
+        bufs, y1s, zs, bits = [xbuf], [], [], []
         for i, (gi, gm, go) in enumerate(geos):
             w1, b1, w2, b2 = params[4 * i:4 * i + 4]
             assert gi.P == 2 * gm.P and gm.T == go.T and gi.C == w1.shape[1] and gm.C == w1.shape[0] == w2.shape[1]
+            sb = None
             if i == 0 and _enc0_ok(w1, w2, gi, gm, go, xbuf.dtype):
                 y1 = None                      # rebuilt from the input where the backward needs it (csrc/enc0.hip)
                 y, z = _enc0_fwd(xbuf, w1, b1, w2, b2, gm, go, save_z)
             else:
-                y1 = _conv_relu_fwd(bufs[-1], w1, b1, gi, gm)
+                # with a backward to come, the ReLU's sign bits ride along: its gate then reads 1/8 of y1's bytes
+                y1, sb = _conv_relu_fwd(bufs[-1], w1, b1, gi, gm, want_bits=save_z and _ENC_BITS)
                 y, z = _glu_fwd(y1, w2, b2, gm, go, save_z)
             bufs.append(y)
             y1s.append(y1)
             zs.append(z)
+            bits.append(sb)
         ctx.geos, ctx.E, ctx.saved_z = geos, len(geos), save_z
-        ctx.save_for_backward(*bufs, *y1s, *[z for z in zs if z is not None], *params)
+        ctx.has_bits = [sb is not None for sb in bits]
+        ctx.save_for_backward(*bufs, *y1s, *[z for z in zs if z is not None], *params, *[sb for sb in bits if sb is not None])
         return tuple(bufs[1:])
 
     @staticmethod
@@ -1214,7 +1227,9 @@ class EncoderStack(torch.autograd.Function):
             raise RuntimeError("EncoderStack was run without save_z; backward is unavailable")
         E, geos = ctx.E, ctx.geos
         t = ctx.saved_tensors
-        bufs, y1s, zs, params = t[:E + 1], t[E + 1:2 * E + 1], t[2 * E + 1:3 * E + 1], t[3 * E + 1:]
+        bufs, y1s, zs, params = t[:E + 1], t[E + 1:2 * E + 1], t[2 * E + 1:3 * E + 1], t[3 * E + 1:7 * E + 1]
+        kept = list(t[7 * E + 1:])
+        bits = [kept.pop(0) if h else None for h in ctx.has_bits]
         dt, dev = bufs[0].dtype, bufs[0].device
         grads = [None] * (4 * E)
         dz, dx0 = None, None
@@ -1270,8 +1285,12 @@ class EncoderStack(torch.autograd.Function):
             # 1x1 data gradient, gated by the ReLU below it in the epilogue
             wt = _glu_dgrad_weights(w2, gm, G32, dt)
             dzc = gm.new(dt, dev)
-            gemm(dz, 0, G32, wt, None, dzc, gm.Cp, gm.Cp, gm.M, gm.P, gm.T, hip.EPI_MASK, gm.Cp,
-                 res=y1, r_off=gm.Cp, ldr=gm.Cp, geo=gm)
+            if bits[i] is not None:
+                gemm(dz, 0, G32, wt, None, dzc, gm.Cp, gm.Cp, gm.M, gm.P, gm.T, hip.EPI_MASK, gm.Cp,
+                     res=bits[i][gm.Cp // 4:], r_off=0, ldr=gm.Cp, geo=gm, mask_bits=True)
+            else:
+                gemm(dz, 0, G32, wt, None, dzc, gm.Cp, gm.Cp, gm.M, gm.P, gm.T, hip.EPI_MASK, gm.Cp,
+                     res=y1, r_off=gm.Cp, ldr=gm.Cp, geo=gm)
             # conv weight gradient: X row m = the 4*Cp contiguous inputs of output row m
             sh = tuple(w1.shape)
             dwp, dbp = wgrad(dzc, gm.Cp, gm.Cp, gm.Cp, bufs[i], gi.Cp, 2 * gi.Cp, 4 * gi.Cp, gm.M,

@@ -11,7 +11,7 @@
 //   pass 1  (scan_seg_kernel<.., 1>, grid x S): every segment is walked from a ZERO state: x_end^0[d, n], and
 //           sum_t delta'_t[d].  The segment's decay needs no product over time: a_t = exp(delta'_t A), so
 //           prod_t a_t = exp(A sum_t delta'_t).
-//   carry   (scan_carry_kernel): per (b, d, n), sequentially over the S segments: X_0 = 0,
+//   carry   (prologue of pass 2): per (b, d, n), sequentially over the earlier segments: X_0 = 0,
 //           X_{s+1} = exp2(A log2e * sum delta'_s) X_s + x_end^0_s  -- the true state entering every segment.
 //   pass 2  (scan_seg_kernel<.., 2>, grid x S): every segment re-walked from X_s with outputs, the z gate, the saved
 //           states of the backward (same checkpoint layout: scan_bwd*.hip are unchanged) and last_state.
@@ -24,7 +24,7 @@
 
 namespace cum {
 
-// carry buffer: [(b, seg, w, d)][NS] f32 (x_end^0 after pass 1, entering state X_s after the carry kernel), then the
+// carry buffer: [(b, seg, w, d)][NS] f32 (x_end^0 of every segment but the last, written by pass 1), then the
 // per-segment sums of delta' [(b, seg, d)]
 __device__ __forceinline__ int64_t carry_slot(int b, int nseg, int seg, int NW, int w, int Dm, int d) {
   return ((((int64_t)b * nseg + seg) * NW + w) * Dm + d) * NS;
@@ -65,7 +65,25 @@ __global__ __launch_bounds__(NW * 64) void scan_seg_kernel(const ScanParams p) {
     Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
     x[j / 2][j % 2] = 0.f;
   }
-  if (OUT && seg > 0) ckpt_load(p.carry, carry_slot(b, nseg, seg, NW, w, Dm, dc), x);     // the true entering state
+  if constexpr (OUT) {
+    // The true entering state: compose the (decay, end state) pairs of all earlier segments, in order.  seg - 1 dependent
+    // exp2 + fma per state on loads that do not depend on each other (a separate carry launch between the passes cost
+    // more than these few L2 reads: its own prologue, a launch boundary, and a second trip of the states through memory).
+#pragma unroll 4
+    for (int sp = 0; sp < seg; ++sp) {
+      f2 e[NS / 2];
+      ckpt_load(p.carry, carry_slot(b, nseg, sp, NW, w, Dm, dc), e);
+      const float ds = xsum[((int64_t)b * nseg + sp) * Dm + dc];
+#pragma unroll
+      for (int j = 0; j < NS / 2; ++j) {
+        const f2 t = ds * Ap[j];
+        f2 a;
+        a.x = __builtin_amdgcn_exp2f(t.x);
+        a.y = __builtin_amdgcn_exp2f(t.y);
+        x[j] = a * x[j] + e[j];
+      }
+    }
+  }
   const float Dd = p.D ? p.D[dc] : 0.f;
   const float bias = p.bias ? p.bias[dc] : 0.f;
   const TIO *up = static_cast<const TIO *>(p.u) + b * p.s.u_sb + dc * p.s.u_sd;
@@ -214,32 +232,12 @@ __global__ __launch_bounds__(NW * 64) void scan_seg_kernel(const ScanParams p) {
   }
 }
 
-// carry[b][s] := state entering segment s.  One thread per (b, w, d, j) walks the S segments: S - 1 exp2 + fma.
-__global__ __launch_bounds__(256) void scan_carry_kernel(float *__restrict__ carry, const float *__restrict__ A, int batch,
-                                                         int nseg, int NW, int Dm, int N) {
-  const int64_t total = (int64_t)batch * NW * Dm * NS;
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int j = i % NS;
-  const int d = (i / NS) % Dm;
-  const int w = (i / ((int64_t)NS * Dm)) % NW;
-  const int b = i / ((int64_t)NS * Dm * NW);
-  const int n = w * NS + j;
-  const float *xsum = carry + (int64_t)batch * nseg * NW * Dm * NS;
-  const float Ap = n < N ? A[(int64_t)d * N + n] * kLog2e : 0.f;
-  float X = 0.f;
-  for (int s = 0; s < nseg; ++s) {
-    float *slot = carry + carry_slot(b, nseg, s, NW, w, Dm, d) + j;
-    const bool more = s + 1 < nseg;              // pass 1 does not walk the last segment: nothing enters after it
-    const float e = more ? *slot : 0.f;
-    *slot = X;
-    if (more) X = __builtin_amdgcn_exp2f(Ap * xsum[((int64_t)b * nseg + s) * Dm + d]) * X + e;
-  }
-}
-
-// Segment plan.  waves = what the sequential kernels launch.  Target: about four waves per SIMD (4 096 on 256 CUs);
-// at least two 16-step chunks per segment; segmented only when that gives >= 3 segments and the sequential grid
-// brings fewer than two waves per SIMD.
+// Segment plan.  waves = what the sequential kernels launch.  Target (segment-count sweep on MI355X, same box,
+// gpurun_out/r04_scan_tp_sweep.txt): d_state > 16 -- ONE 8-wave workgroup per CU (2 048 waves: batch-1 E8, 32 groups ->
+// 8 segments = 40.9 us against 45.8 us at 13 and 50.2 us at 20; the kernel is issue-bound from two waves per SIMD, more
+// co-resident workgroups only lengthen every chunk); d_state <= 16 -- small workgroups, about four waves per SIMD
+// (4 096: the 442K model 25.8 us at 20 segments against 35.3 us at 8).  At least two 16-step chunks per segment;
+// segmented only when that gives >= 3 segments.
 void scan_seg_plan(int batch, int dim, int dstate, int len, int *nseg, int *seg_chunks) {
   const int64_t NW = (dstate + NS - 1) / NS, groups = (dim + 63) / 64;
   const int64_t waves = (int64_t)batch * groups * NW;
@@ -248,8 +246,14 @@ void scan_seg_plan(int batch, int dim, int dstate, int len, int *nseg, int *seg_
   *seg_chunks = nchunks;
   const int64_t force = cum_knob("CUM_SCAN_SEGMENTS", -1);       // AB build: 0 = never, n > 1 = that many segments
   if (force == 0 || waves <= 0 || nchunks < 6) return;
-  if (force < 0 && waves >= 2048) return;
-  int64_t want = force > 1 ? force : (4096 + waves - 1) / waves;
+  // Measured on MI355X (bench.py scan rows, same box): at d_state > 16 the sequential kernel runs 8 waves per 64 channels and
+  // the segmented form pays from < 1 wave per SIMD (batch <= 3 at D = 2048); at d_state <= 16 the sequential kernels are
+  // the wave-specialised ones (producer + consumer waves: already two waves per SIMD at 512 "waves" here) and the
+  // segmented form, which uses the generic chunk structure, only wins while the grid is <= 256 waves (B = 16, D = 2048,
+  // N = 16: 0.56 ms sequential against 0.64 ms segmented -- not taken).
+  if (force < 0 && waves >= (NW > 2 ? 1024 : 257)) return;
+  const int64_t target = NW > 2 ? 2048 : 4096;
+  int64_t want = force > 1 ? force : (target + waves - 1) / waves;
   int sc = (int)((nchunks + want - 1) / want);
   if (sc < 2) sc = 2;
   const int S = (nchunks + sc - 1) / sc;
@@ -267,10 +271,6 @@ template <int NW, typename TIO>
 static int launch_seg_io(const ScanParams &p, hipStream_t st) {
   dim3 grid(p.ngroups, p.s.batch, p.nseg), grid1(p.ngroups, p.s.batch, p.nseg - 1), block(NW * 64);
   hipLaunchKernelGGL((scan_seg_kernel<NW, TIO, 1>), grid1, block, 0, st, p);
-  CUM_CHECK_LAUNCH();
-  const int64_t total = (int64_t)p.s.batch * NW * p.s.dim * NS;
-  hipLaunchKernelGGL(scan_carry_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.carry, p.A, p.s.batch,
-                     p.nseg, NW, p.s.dim, p.s.dstate);
   CUM_CHECK_LAUNCH();
   hipLaunchKernelGGL((scan_seg_kernel<NW, TIO, 2>), grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();

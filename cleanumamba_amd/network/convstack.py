@@ -1210,7 +1210,8 @@ class EncoderStack(torch.autograd.Function):
                 y, z = _enc0_fwd(xbuf, w1, b1, w2, b2, gm, go, save_z)
             else:
                 # with a backward to come, the ReLU's sign bits ride along: its gate then reads 1/8 of y1's bytes
-                y1, sb = _conv_relu_fwd(bufs[-1], w1, b1, gi, gm, want_bits=save_z and _ENC_BITS)
+                y1, sb = _conv_relu_fwd(bufs[-1], w1, b1, gi, gm, want_bits=True) if (save_z and _ENC_BITS) else \
+                    (_conv_relu_fwd(bufs[-1], w1, b1, gi, gm), None)
                 y, z = _glu_fwd(y1, w2, b2, gm, go, save_z)
             bufs.append(y)
             y1s.append(y1)

@@ -166,6 +166,12 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         self.stft_losses = torch.nn.ModuleList(
             [STFTLoss(fs, ss, wl, window, band) for fs, ss, wl in zip(fft_sizes, hop_sizes, win_lengths)])
 
+    def components(self, x, y):
+        """[(sc, mag)] per resolution, uncombined (the caller folds them into its loss in one launch: util.loss_fn)."""
+        if x.dim() == 3:
+            x, y = x.reshape(-1, x.size(2)), y.reshape(-1, y.size(2))
+        return [f(x, y) for f in self.stft_losses]
+
     def forward(self, x, y):
         if x.dim() == 3:
             x, y = x.reshape(-1, x.size(2)), y.reshape(-1, y.size(2))

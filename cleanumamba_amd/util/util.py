@@ -65,6 +65,31 @@ class LinearWarmupCosineDecay:
         return lr
 
 
+class _Combine(torch.autograd.Function):
+    """out = W @ [v_0 .. v_{n-1}] for 0-dim device scalars v_i and a constant matrix W (k x n): the linear combinations
+    of loss terms that loss_fn forms (src/util/util.py:300-327: term * lambda, sums over the three STFT resolutions, / 3,
+    the total) as three small launches forward and two backward instead of ~40 one-element kernels with their autograd
+    nodes (each a launch boundary inside the replayed step)."""
+
+    _W = {}
+
+    @staticmethod
+    def forward(ctx, rows, *vals):
+        dev = vals[0].device
+        key = (rows, dev)
+        W = _Combine._W.get(key)
+        if W is None:
+            W = _Combine._W[key] = torch.tensor(rows, dtype=torch.float32, device=dev)
+        v = torch.stack([t.float() for t in vals])
+        ctx.W = W
+        return (W * v).sum(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        gv = (ctx.W * g[:, None].float()).sum(0)
+        return (None,) + tuple(gv.unbind())
+
+
 def loss_fn(net, X, cross_entropy=None, ell_p=1, ell_p_lambda=1, stft_lambda=1, mrstftloss=None, kd_p=1,
             min_max=(-1, 1), teacher_net=None, student_teacher_adapter_layers=None, **kwargs):
     """loss = ell_p(denoised, clean) * ell_p_lambda + (sc + mag) * stft_lambda.
@@ -89,13 +114,25 @@ def loss_fn(net, X, cross_entropy=None, ell_p=1, ell_p_lambda=1, stft_lambda=1, 
         ae_loss = F.mse_loss(denoised_audio, clean_audio)
     else:
         ae_loss = F.l1_loss(denoised_audio, clean_audio)
+    if stft_lambda > 0 and mrstftloss is None:
+        mrstftloss = MultiResolutionSTFTLoss(sc_lambda=0.5, mag_lambda=0.5, band="high",
+                                             hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200],
+                                             fft_sizes=[512, 1024, 2048]).to(denoised_audio.device)
+    if plain and stft_lambda > 0 and hasattr(mrstftloss, "components"):
+        # every term on the GPU kernels: one combination instead of a chain of one-element multiplies and adds
+        pairs = mrstftloss.components(denoised_audio.squeeze(1), clean_audio.squeeze(1))
+        n = len(pairs)
+        cs_, cm_ = stft_lambda * mrstftloss.sc_lambda / n, stft_lambda * mrstftloss.mag_lambda / n
+        sc_w, mag_w = [cs_, 0.0] * n, [0.0, cm_] * n
+        rows = ((float(ell_p_lambda),) + tuple(a + b for a, b in zip(sc_w, mag_w)),     # the loss
+                (float(ell_p_lambda),) + (0.0,) * (2 * n),                              # "reconstruct"
+                (0.0,) + tuple(sc_w), (0.0,) + tuple(mag_w))                            # "stft_sc", "stft_mag"
+        out = _Combine.apply(rows, ae_loss, *[t for pair in pairs for t in pair])
+        output_dic["reconstruct"], output_dic["stft_sc"], output_dic["stft_mag"] = out[1].detach(), out[2].detach(), out[3].detach()
+        return out[0], output_dic
     loss = ae_loss * ell_p_lambda
     output_dic["reconstruct"] = ae_loss.data * ell_p_lambda
     if stft_lambda > 0:
-        if mrstftloss is None:
-            mrstftloss = MultiResolutionSTFTLoss(sc_lambda=0.5, mag_lambda=0.5, band="high",
-                                                 hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200],
-                                                 fft_sizes=[512, 1024, 2048]).to(denoised_audio.device)
         sc_loss, mag_loss = mrstftloss(denoised_audio.squeeze(1), clean_audio.squeeze(1))
         loss = loss + (sc_loss + mag_loss) * stft_lambda
         output_dic["stft_sc"] = sc_loss.data * stft_lambda

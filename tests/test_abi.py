@@ -35,8 +35,9 @@ def test_size_queries_and_argument_errors():
     assert lib.cum_conv_bwd_workspace_elems(2, 10, 33, 4) == 2 * 3 * 5 * 10
     # time-parallel forward scan: a workspace is asked for only where the sequential grid leaves the chip mostly idle
     assert lib.cum_scan_fwd_workspace_elems(16, 2048, 64, 624) == 0             # E8 training shape: 4 096 waves
-    # batch-1 E8: 256 waves -> 13 segments of 3 chunks; per segment 8 waves x 2048 channels x 8 states + 2048 sums
-    assert lib.cum_scan_fwd_workspace_elems(1, 2048, 64, 624) == 13 * (8 * 2048 * 8 + 2048)
+    # batch-1 E8: 256 waves -> 8 segments of 5 chunks (one workgroup per CU); per segment 8 waves x 2048 channels x 8
+    # states + 2048 sums of delta
+    assert lib.cum_scan_fwd_workspace_elems(1, 2048, 64, 624) == 8 * (8 * 2048 * 8 + 2048)
     assert lib.cum_scan_fwd_workspace_elems(1, 128, 16, 61) == 0                # four chunks: nothing to split
     # bad arguments are rejected before any launch (works without a GPU)
     s = hip.ScanShape()

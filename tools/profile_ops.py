@@ -16,7 +16,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = torch.device("cuda")
 torch.manual_seed(0)
 net = Net("CleanUMamba", E8).to(dev).train()
-step = TrainStep(net, autocast_dtype=torch.bfloat16)
+step = TrainStep(net, autocast_dtype=torch.float16, use_graph=False)
 g = torch.Generator(device=dev).manual_seed(1234)
 clean = 0.05 * torch.randn(16, 1, CLIP, generator=g, device=dev)
 noisy = clean + 0.05 * torch.randn(16, 1, CLIP, generator=g, device=dev)

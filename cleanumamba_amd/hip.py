@@ -97,9 +97,9 @@ SIGNATURES = {
     "cum_stream_window_update": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, c_i64, c_i64, c_i32, _P, _P, c_i64, _P]),
     "cum_stream_tail_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, _P, c_i64, c_i32, _P, c_i64, _P]),
     "cum_stream_overlap_add": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i64, _P, c_i64, c_i32, _P]),
-    "cum_rfft": (c_i32, [c_i32, c_i64, _P, _P, _P]),
-    "cum_irfft": (c_i32, [c_i32, c_i64, _P, _P, _P]),
-    "cum_cfft": (c_i32, [c_i32, c_i64, _P, _P, c_i32, _P]),
+    "cum_fft_plan_create": (c_i32, [c_i32, c_i32, c_i64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i64)]),
+    "cum_fft_plan_destroy": (c_i32, [_P]),
+    "cum_fft_exec": (c_i32, [_P, _P, _P, c_i32, _P, _P]),
     "cum_stft_loss_fwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P]),
     "cum_stft_loss_bwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P, _P, _P]),
     "cum_enc0_fwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P, _P]),
@@ -188,3 +188,36 @@ def stream_ptr():
 
 def scan_chunk():
     return lib().cum_scan_chunk()
+
+
+# ---- FFT plans: the library holds no plan cache (include/cleanumamba_hip.h); the caller -- this module -- owns the plan
+# objects and their work areas.  One plan per (device, kind, n, batch); a plan's work area is a tensor kept beside it, so
+# its address is stable across hipGraph replays.
+FFT_R2C, FFT_C2R, FFT_C2C = 0, 1, 2
+_fft_plans = {}
+
+
+class _FftPlan:
+    def __init__(self, kind, n, batch, device):
+        self.handle, wb = ctypes.c_void_p(), c_i64()
+        with torch.cuda.device(device):
+            check(lib().cum_fft_plan_create(kind, n, batch, ctypes.byref(self.handle), ctypes.byref(wb)))
+            self.work = torch.empty(max(int(wb.value), 16), dtype=torch.uint8, device=device) if wb.value > 0 else None
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().cum_fft_plan_destroy(self.handle)
+        except Exception:          # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def fft(kind, n, batch, src, dst, inverse=False):
+    """One batched transform through a cached, caller-owned plan (src, dst: float32 tensors, see cum_fft_exec)."""
+    dev = src.device
+    key = (dev.index, kind, int(n), int(batch))
+    plan = _fft_plans.get(key)
+    if plan is None:
+        plan = _fft_plans[key] = _FftPlan(kind, int(n), int(batch), dev)
+    with torch.cuda.device(dev):
+        check(lib().cum_fft_exec(plan.handle, ptr(src), ptr(dst), int(bool(inverse)), ptr(plan.work), stream_ptr()))

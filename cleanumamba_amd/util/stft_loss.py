@@ -6,7 +6,7 @@ ParallelWaveGAN): per resolution a spectral-convergence term
 averaged over resolutions and weighted by sc_lambda / mag_lambda.
 
 On the GPU one resolution is: cum_stft_frames (window + reflect padding, both signals) -> one batched
-rocFFT complex FFT of n_fft/2 points over the frames read as packed complex numbers (cum_cfft) ->
+rocFFT complex FFT of n_fft/2 points over the frames read as packed complex numbers (cum_fft_exec) ->
 cum_stft_loss_fwd_packed (recovers the real-input spectrum, both terms, deterministic tree sums); backward is
 cum_stft_loss_bwd_packed -> one unnormalised inverse complex FFT -> cum_stft_fold (overlap-add gather).  The reference's ~25 elementwise passes per
 resolution and direction never touch HBM.  CPU tensors take the plain torch.stft route below (host-side
@@ -65,7 +65,7 @@ class STFTLossFn(torch.autograd.Function):
             if _PACKED:
                 # frames read as (n_fft / 2) complex numbers, transformed in place by one batched complex FFT
                 tw = _twiddle(n_fft, x.device)
-                hip.check(lib.cum_cfft(n_fft // 2, 2 * bsz * n_frames, hip.ptr(frames), hip.ptr(frames), 0, st))
+                hip.fft(hip.FFT_C2C, n_fft // 2, 2 * bsz * n_frames, frames, frames)
                 hip.check(lib.cum_stft_loss_fwd_packed(hip.ptr(frames[0]), hip.ptr(frames[1]), bsz, n_frames, n_fft,
                                                        frame0, hip.ptr(tw), hip.ptr(ws), hip.ptr(stats), st))
                 spec = frames
@@ -73,7 +73,7 @@ class STFTLossFn(torch.autograd.Function):
                 # rocFFT, one batched r2c for both signals; `frames` is scratch and may be overwritten
                 spec = torch.empty(2, bsz, n_frames, bins, dtype=torch.complex64, device=x.device)
                 sr = torch.view_as_real(spec)
-                hip.check(lib.cum_rfft(n_fft, 2 * bsz * n_frames, hip.ptr(frames), hip.ptr(sr), st))
+                hip.fft(hip.FFT_R2C, n_fft, 2 * bsz * n_frames, frames, sr)
                 del frames
                 hip.check(lib.cum_stft_loss_fwd(hip.ptr(sr[0]), hip.ptr(sr[1]), bsz, n_frames, bins, frame0,
                                                 hip.ptr(ws), hip.ptr(stats), st))
@@ -103,14 +103,14 @@ class STFTLossFn(torch.autograd.Function):
                 hip.check(lib.cum_stft_loss_bwd_packed(hip.ptr(spec[0]), hip.ptr(spec[1]), bsz, n_frames, n_fft, frame0,
                                                        hip.ptr(stats), hip.ptr(g_sc), hip.ptr(g_mag), hip.ptr(tw),
                                                        hip.ptr(dframes), st))
-                hip.check(lib.cum_cfft(n_fft // 2, bsz * n_frames, hip.ptr(dframes), hip.ptr(dframes), 1, st))
+                hip.fft(hip.FFT_C2C, n_fft // 2, bsz * n_frames, dframes, dframes, inverse=True)
             else:
                 sr = torch.view_as_real(spec)
                 z = torch.empty(bsz, n_frames, bins, dtype=torch.complex64, device=spec.device)
                 hip.check(lib.cum_stft_loss_bwd(hip.ptr(sr[0]), hip.ptr(sr[1]), bsz, n_frames, bins, frame0,
                                                 hip.ptr(stats), hip.ptr(g_sc), hip.ptr(g_mag),
                                                 hip.ptr(torch.view_as_real(z)), st))
-                hip.check(lib.cum_irfft(n_fft, bsz * n_frames, hip.ptr(torch.view_as_real(z)), hip.ptr(dframes), st))
+                hip.fft(hip.FFT_C2R, n_fft, bsz * n_frames, torch.view_as_real(z), dframes)
             hip.check(lib.cum_stft_fold(hip.ptr(dframes), bsz, L, n_fft, hop, win_length, hip.ptr(window), n_frames,
                                         hip.ptr(dx), dx.stride(0), 0, st))
         return dx, None, None, None, None, None, None

@@ -288,22 +288,24 @@ int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n
 int cum_pack2d(const float *src, const void *jobs, const int32_t *tiles, int32_t n_tiles, const int32_t *tables,
                int32_t dst_dtype, void *dst, void *stream);
 
-/* Batched 1-D real FFTs for the STFT loss, on hipFFT / rocFFT (torch.stft's transform, src/util/stft_loss.py:29-33, and
- * its autograd).  Unnormalised in both directions.  The INPUT buffer may be overwritten (rocFFT's real transforms
- * do that for some lengths): pass scratch.  cum_rfft: in [batch][n] real -> out [batch][n/2+1] interleaved complex;
- * cum_irfft: in [batch][n/2+1] complex -> out [batch][n] real.  Plans (and their hipFFT work areas) are created on
- * first use of a (device, n, batch, direction) and cached for the life of the process. */
-int cum_rfft(int32_t n, int64_t batch, float *in, float *out, void *stream);
-int cum_irfft(int32_t n, int64_t batch, float *in, float *out, void *stream);
-
-/* Complex FFT of length n, batch transforms, unnormalised in both directions; in == out allowed. */
-int cum_cfft(int32_t n, int64_t batch, float *in, float *out, int32_t inverse, void *stream);
+/* Batched 1-D FFTs for the STFT loss, on hipFFT / rocFFT (torch.stft's transform, src/util/stft_loss.py:29-33, and its
+ * autograd).  Unnormalised in both directions.  The library keeps NO plan cache and allocates NO device memory for a
+ * transform: a plan is an object the caller creates once per (kind, n, batch), keeps, and destroys; its work area is
+ * caller memory passed to every cum_fft_exec (size returned by cum_fft_plan_create; may be 0).
+ *   kind 0: real -> complex, in [batch][n] real, out [batch][n/2+1] interleaved complex;
+ *   kind 1: complex -> real, in [batch][n/2+1] complex, out [batch][n] real;
+ *   kind 2: complex -> complex, [batch][n] interleaved complex, `inverse` selects the direction, in == out allowed.
+ * The INPUT of the real transforms may be overwritten (rocFFT does that for some lengths): pass scratch.
+ * A plan is not re-entrant (one stream / one thread at a time); cum_fft_exec is graph-capturable. */
+int cum_fft_plan_create(int32_t kind, int32_t n, int64_t batch, void **plan, int64_t *work_bytes);
+int cum_fft_plan_destroy(void *plan);
+int cum_fft_exec(void *plan, float *in, float *out, int32_t inverse, void *work, void *stream);
 
 /* The same loss on PACKED transforms: a frame's n_fft real samples are read as n_fft/2 complex numbers
- * (even samples real, odd imaginary) and transformed by cum_cfft; zx / zy: [batch * n_frames][n_fft / 2] complex.  The
+ * (even samples real, odd imaginary) and transformed by a kind-2 plan (cum_fft_exec); zx / zy: [batch * n_frames][n_fft / 2] complex.  The
  * real-input spectrum X[k], k = 0..n_fft/2, is recovered inside the kernels (twiddle: [n_fft/2 + 1] complex,
  * e^{-2 pi i k / n_fft}).  cum_stft_loss_bwd_packed writes gz = dL/dRe(Z) + i dL/dIm(Z); an unnormalised inverse
- * cum_cfft of gz is the gradient wrt the frames (what cum_stft_fold takes).  Replaces rocFFT's r2c post- / c2r
+ * complex transform of gz is the gradient wrt the frames (what cum_stft_fold takes).  Replaces rocFFT's r2c post- / c2r
  * pre-processing passes. */
 int cum_stft_loss_fwd_packed(const float *zx, const float *zy, int64_t batch, int64_t n_frames, int32_t n_fft,
                              int64_t frame0, const float *twiddle, float *workspace, float *stats, void *stream);

@@ -25,37 +25,38 @@ def test_gather_with_zero_padding(cuda, src_dt, dst_dt, n):
 
 @pytest.mark.parametrize("n_fft", [512, 1024, 2048])
 def test_rfft_irfft_match_torch_fft(cuda, n_fft):
-    """cum_rfft / cum_irfft (hipFFT, unnormalised, inputs may be overwritten) vs torch.fft on a copy."""
+    """Real transforms through caller-owned plans (cum_fft_plan_create / cum_fft_exec: hipFFT, unnormalised, inputs may be
+    overwritten, work area passed in) vs torch.fft on a copy."""
     from cleanumamba_amd import hip
     batch = 37
     x = torch.randn(batch, n_fft, generator=torch.Generator().manual_seed(n_fft)).to(cuda)
     want = torch.fft.rfft(x.clone(), dim=-1)
     spec = torch.empty(batch, n_fft // 2 + 1, dtype=torch.complex64, device=cuda)
     scratch = x.clone()
-    hip.check(hip.lib().cum_rfft(n_fft, batch, hip.ptr(scratch), hip.ptr(torch.view_as_real(spec)), hip.stream_ptr()))
+    hip.fft(hip.FFT_R2C, n_fft, batch, scratch, torch.view_as_real(spec))
     assert rel_l2(torch.view_as_real(spec), torch.view_as_real(want)) < 1e-6
     back_want = torch.fft.irfft(want.clone(), n=n_fft, dim=-1, norm="forward")
     back = torch.empty(batch, n_fft, device=cuda)
     z = want.clone()
-    hip.check(hip.lib().cum_irfft(n_fft, batch, hip.ptr(torch.view_as_real(z)), hip.ptr(back), hip.stream_ptr()))
+    hip.fft(hip.FFT_C2R, n_fft, batch, torch.view_as_real(z), back)
     assert rel_l2(back, back_want) < 1e-6
     assert rel_l2(back / n_fft, x) < 1e-5                            # round trip
 
 
 @pytest.mark.parametrize("n", [256, 1024])
 def test_cfft_matches_torch_fft(cuda, n):
-    """cum_cfft (hipFFT c2c, in place, unnormalised both ways) against torch.fft in float64."""
+    """Complex plan (hipFFT c2c, in place, unnormalised both ways) against torch.fft in float64."""
     from cleanumamba_amd import hip
     g = torch.Generator().manual_seed(n)
     z = torch.randn(37, n, 2, generator=g)
     ref = torch.fft.fft(torch.view_as_complex(z.double()))
     buf = z.to(cuda).contiguous()
     with torch.cuda.device(cuda):
-        hip.check(hip.lib().cum_cfft(n, 37, hip.ptr(buf), hip.ptr(buf), 0, hip.stream_ptr()))
+        hip.fft(hip.FFT_C2C, n, 37, buf, buf)
     got = torch.view_as_complex(buf.double().cpu())
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
     with torch.cuda.device(cuda):
-        hip.check(hip.lib().cum_cfft(n, 37, hip.ptr(buf), hip.ptr(buf), 1, hip.stream_ptr()))
+        hip.fft(hip.FFT_C2C, n, 37, buf, buf, inverse=True)
     back = buf.cpu() / n
     assert float((back - z).abs().max()) < 1e-5
 

@@ -296,6 +296,310 @@ __global__ __launch_bounds__(256) void stft_fold_kernel(const float *__restrict_
   *o = accumulate ? *o + acc : acc;
 }
 
+
+// ================================================================ fused form: framing + FFT + loss in ONE kernel
+// The pipeline above moves every frame through HBM four times per signal (frames written, transformed in place by
+// rocFFT: read + write, read again by the loss kernel): ~1.7 GB forward and ~1.7 GB backward per step at the training
+// shape (16 clips x 160 000 samples x three resolutions), 1.0 ms -- for an op whose inputs are two 10 MB waveforms.  Here a
+// wave owns a frame end to end: it reads the frame's samples of x and y straight from the waveforms (window in
+// registers), transforms both at once in LDS (a float4 per point: x.re, x.im, y.re, y.im -- one instruction stream, one
+// set of twiddles for both signals), and consumes the spectrum where it stands.  Forward: loss partial sums, nothing else
+// leaves the CU.  Backward: the two transforms are REBUILT (cheaper than keeping 560 MB of spectra), the gradient spectrum
+// overwrites them in place, an inverse transform in LDS yields the frame gradient, of which only the window's support is
+// written for cum_stft_fold.
+//
+// Transform: the frame's n_fft real samples as H = n_fft / 2 complex points (packed_bin above), in-place radix-4
+// decimation in frequency (one leading radix-2 stage when log2 H is odd); the output stands in base-4 digit-reversed order,
+// X[k] at fused_pos(k) -- consumed in that order, never sorted.  The inverse is the exact transpose (decimation in time on
+// the digit-reversed layout, conjugate twiddles), unnormalised like the rocFFT path.  LDS slot of point e: e + (e >> 4)
+// (one pad slot per 16: the late stages' stride-4 / stride-16 accesses would otherwise meet on 4 of the 16 bank groups).
+// Validated against numpy's FFT as a scalar model before it was written (index maps, twiddle exponents, the transpose).
+template <int H>
+struct FusedFft {
+  static constexpr int LOGH = H == 256 ? 8 : H == 512 ? 9 : 10;
+  static constexpr bool LEAD2 = (LOGH & 1) != 0;
+  static constexpr int PER = H / 64;                 // points per lane
+  static constexpr int SLOTS = H + H / 16;
+  // butterflies of one stage a lane keeps in flight: H = 1024 fits two waves per SIMD (LDS capacity), which need some
+  // instruction-level overlap of their own; the smaller sizes run four waves per SIMD on <= 128 registers
+  static constexpr int UNR = H == 1024 ? 2 : 1;
+
+  __device__ static __forceinline__ int pad(int e) { return e + (e >> 4); }
+
+  // position of bin k in the transform's output order
+  __device__ static __forceinline__ int pos(int k) {
+    int p = 0, rem = k, L = H;
+    if constexpr (LEAD2) {
+      p = (rem & 1) * (H / 2);
+      rem >>= 1;
+      L = H / 2;
+    }
+#pragma unroll
+    for (int s = 0; s < (LOGH / 2); ++s) {
+      p += (rem & 3) * (L >> 2);
+      rem >>= 2;
+      L >>= 2;
+    }
+    return p;
+  }
+
+  // e^{-2 pi i e / L} from the table tw[m] = e^{-2 pi i m / (2H)}, m = 0..H
+  __device__ static __forceinline__ float2 twiddle(const float2 *tw, int e, int L) {
+    int m = e * (2 * H / L);
+    const bool neg = m > H;
+    m = neg ? m - H : m;
+    float2 w = tw[m];
+    if (neg) { w.x = -w.x; w.y = -w.y; }
+    return w;
+  }
+
+  __device__ static __forceinline__ float4 cmul4(float4 v, float2 w) {
+    return make_float4(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x, v.z * w.x - v.w * w.y, v.z * w.y + v.w * w.x);
+  }
+  __device__ static __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+  __device__ static __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+  // forward transform of both signals (wave-private buffer: the LDS executes a wave's accesses in order, no barrier)
+  __device__ static __forceinline__ void forward(float4 *buf, const float2 *tw, int lane) {
+    int L = H;
+    if constexpr (LEAD2) {
+#pragma unroll UNR
+      for (int i = 0; i < H / 128; ++i) {
+        const int j = lane + 64 * i;                       // H / 2 butterflies
+        const float4 a = buf[pad(j)], b = buf[pad(j + H / 2)];
+        buf[pad(j)] = add4(a, b);
+        buf[pad(j + H / 2)] = cmul4(sub4(a, b), twiddle(tw, j, H));
+      }
+      L = H / 2;
+    }
+#pragma unroll
+    for (int st = 0; st < LOGH / 2; ++st, L >>= 2) {
+      const int q4 = L >> 2;
+#pragma unroll UNR
+      for (int i = 0; i < H / 256; ++i) {
+        const int q = lane + 64 * i;                       // H / 4 butterflies
+        const int j = q & (q4 - 1), p = ((q - j) << 2) + j;   // group (q / q4) * L + j
+        const float4 a = buf[pad(p)], b = buf[pad(p + q4)], c = buf[pad(p + 2 * q4)], d = buf[pad(p + 3 * q4)];
+        const float4 t0 = add4(a, c), t1 = sub4(a, c), t2 = add4(b, d), u = sub4(b, d);
+        const float4 t3 = make_float4(u.y, -u.x, u.w, -u.z);                  // (b - d) * (-i)
+        buf[pad(p)] = add4(t0, t2);
+        if (L > 4) {
+          buf[pad(p + q4)] = cmul4(add4(t1, t3), twiddle(tw, j, L));
+          buf[pad(p + 2 * q4)] = cmul4(sub4(t0, t2), twiddle(tw, 2 * j, L));
+          buf[pad(p + 3 * q4)] = cmul4(sub4(t1, t3), twiddle(tw, 3 * j, L));
+        } else {                                                               // last stage: j = 0, twiddles are 1
+          buf[pad(p + q4)] = add4(t1, t3);
+          buf[pad(p + 2 * q4)] = sub4(t0, t2);
+          buf[pad(p + 3 * q4)] = sub4(t1, t3);
+        }
+      }
+    }
+  }
+
+  // unnormalised inverse of the .xy halves (input in the forward's output order, output in natural order)
+  __device__ static __forceinline__ void inverse_xy(float4 *buf, const float2 *tw, int lane) {
+    auto ld = [&](int e) { const float4 v = buf[pad(e)]; return make_float2(v.x, v.y); };
+    auto st2 = [&](int e, float2 v) { float2 *q = reinterpret_cast<float2 *>(&buf[pad(e)]); *q = v; };
+    auto cmulc = [](float2 v, float2 w) { return make_float2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y); };   // v * conj(w)
+    int L = 4;
+#pragma unroll
+    for (int stg = 0; stg < LOGH / 2; ++stg, L <<= 2) {
+      const int q4 = L >> 2;
+#pragma unroll UNR
+      for (int i = 0; i < H / 256; ++i) {
+        const int q = lane + 64 * i;
+        const int j = q & (q4 - 1), p = ((q - j) << 2) + j;
+        float2 a = ld(p), b = ld(p + q4), c = ld(p + 2 * q4), d = ld(p + 3 * q4);
+        if (L > 4) {
+          b = cmulc(b, twiddle(tw, j, L));
+          c = cmulc(c, twiddle(tw, 2 * j, L));
+          d = cmulc(d, twiddle(tw, 3 * j, L));
+        }
+        const float2 s0 = make_float2(a.x + c.x, a.y + c.y), s1 = make_float2(a.x - c.x, a.y - c.y);
+        const float2 s2 = make_float2(b.x + d.x, b.y + d.y), u = make_float2(b.x - d.x, b.y - d.y);
+        const float2 s3 = make_float2(-u.y, u.x);                              // i (b - d)
+        st2(p, make_float2(s0.x + s2.x, s0.y + s2.y));
+        st2(p + q4, make_float2(s1.x + s3.x, s1.y + s3.y));
+        st2(p + 2 * q4, make_float2(s0.x - s2.x, s0.y - s2.y));
+        st2(p + 3 * q4, make_float2(s1.x - s3.x, s1.y - s3.y));
+      }
+    }
+    if constexpr (LEAD2) {
+#pragma unroll UNR
+      for (int i = 0; i < H / 128; ++i) {
+        const int j = lane + 64 * i;
+        const float2 a = ld(j), b = cmulc(ld(j + H / 2), twiddle(tw, j, H));
+        st2(j, make_float2(a.x + b.x, a.y + b.y));
+        st2(j + H / 2, make_float2(a.x - b.x, a.y - b.y));
+      }
+    }
+  }
+};
+
+struct FusedStftParams {
+  const float *x, *y, *window, *tw;
+  int64_t len, x_sb, y_sb, n_frames, frame0, n_total;     // n_total = batch * n_frames
+  int hop, win_len;
+  float *partials;                                        // forward: [gridDim.x][3]
+  const float *stats, *g_sc, *g_mag;                      // backward
+  float inv_count;
+  float *dframes;                                         // backward: [batch][n_frames][n_fft]
+};
+
+// the frame's packed samples of both signals -> buf (the window is read where it is used: win_len floats that stay in L1)
+template <int H>
+__device__ __forceinline__ void fused_load_frame(const FusedStftParams &p, int64_t b, int64_t f, int lane, float4 *buf) {
+  typedef FusedFft<H> F;
+  const int n_fft = 2 * H, off = (n_fft - p.win_len) / 2;
+  const float *xb = p.x + b * p.x_sb, *yb = p.y + b * p.y_sb;
+  const int64_t s0 = f * p.hop - H;
+  // wave-uniform: no reflection and every pair 8-byte aligned (signals and window)
+  const bool inner = s0 >= 0 && s0 + n_fft <= p.len && ((off | p.win_len) & 1) == 0 &&
+                     ((((uintptr_t)(xb + s0)) | ((uintptr_t)(yb + s0)) | ((uintptr_t)p.window)) & 7) == 0;
+#pragma unroll 2
+  for (int i = 0; i < F::PER; ++i) {
+    const int m = lane + 64 * i, n = 2 * m;
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n + 1 >= off && n < off + p.win_len) {            // (the window is zero outside its support)
+      float x0, x1, y0, y1, w0, w1;
+      if (inner) {
+        const float2 xv = *reinterpret_cast<const float2 *>(xb + s0 + n), yv = *reinterpret_cast<const float2 *>(yb + s0 + n);
+        const float2 wv = *reinterpret_cast<const float2 *>(p.window + (n - off));
+        x0 = xv.x; x1 = xv.y; y0 = yv.x; y1 = yv.y; w0 = wv.x; w1 = wv.y;
+      } else {
+        const int64_t i0 = reflect_index(s0 + n, p.len), i1 = reflect_index(s0 + n + 1, p.len);
+        x0 = xb[i0]; x1 = xb[i1]; y0 = yb[i0]; y1 = yb[i1];
+        const int wi = n - off;
+        w0 = (wi >= 0 && wi < p.win_len) ? p.window[wi] : 0.f;
+        w1 = (wi + 1 >= 0 && wi + 1 < p.win_len) ? p.window[wi + 1] : 0.f;
+      }
+      z = make_float4(w0 * x0, w1 * x1, w0 * y0, w1 * y1);
+    }
+    buf[F::pad(m)] = z;
+  }
+}
+
+template <int H>
+__device__ __forceinline__ void fused_load_tables(const FusedStftParams &p, float2 *tw) {
+  for (int k = threadIdx.x; k <= H; k += blockDim.x) tw[k] = reinterpret_cast<const float2 *>(p.tw)[k];
+  __syncthreads();
+}
+
+constexpr int kFusedWaves = 4;
+
+template <int H>
+__global__ __launch_bounds__(64 * kFusedWaves) void stft_fused_fwd_kernel(const FusedStftParams p) {
+  typedef FusedFft<H> F;
+  __shared__ __attribute__((aligned(16))) float4 s_buf[kFusedWaves][F::SLOTS];
+  __shared__ float2 s_tw[H + 1];
+  __shared__ float s_red[3][kFusedWaves];
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  fused_load_tables<H>(p, s_tw);
+  float4 *buf = s_buf[wave];
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int64_t nw = (int64_t)gridDim.x * kFusedWaves;
+  for (int64_t fr = (int64_t)blockIdx.x * kFusedWaves + wave; fr < p.n_total; fr += nw) {
+    const int64_t b = fr / p.n_frames, f = fr - b * p.n_frames;
+    if (f < p.frame0) continue;
+    fused_load_frame<H>(p, b, f, lane, buf);
+    F::forward(buf, s_tw, lane);
+#pragma unroll 2
+    for (int i = 0; i <= F::PER; ++i) {
+      const int k = lane + 64 * i;
+      if (k > H) break;
+      const int a = k == H ? 0 : k, bb = k == 0 ? 0 : H - k;
+      const float4 za = buf[F::pad(F::pos(a))], zb = buf[F::pad(F::pos(bb))];
+      const float2 w = s_tw[k];
+      const LossTerms t = loss_terms(packed_bin(make_float2(za.x, za.y), make_float2(zb.x, zb.y), w),
+                                     packed_bin(make_float2(za.z, za.w), make_float2(zb.z, zb.w), w));
+      const float d = t.my - t.mx;
+      s1 += d * d;
+      s2 += t.my * t.my;
+      s3 += fabsf(logf(t.my) - logf(t.mx));
+    }
+  }
+  float v[3] = {s1, s2, s3};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v[j] += __shfl_xor(v[j], o, 64);
+    if (lane == 0) s_red[j][wave] = v[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFusedWaves; ++w) t += s_red[threadIdx.x][w];
+    p.partials[3 * (int64_t)blockIdx.x + threadIdx.x] = t;
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(64 * kFusedWaves) void stft_fused_bwd_kernel(const FusedStftParams p) {
+  typedef FusedFft<H> F;
+  __shared__ __attribute__((aligned(16))) float4 s_buf[kFusedWaves][F::SLOTS];
+  __shared__ float2 s_tw[H + 1];
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  fused_load_tables<H>(p, s_tw);
+  float4 *buf = s_buf[wave];
+  const float c_sc = p.g_sc[0] / (p.stats[2] * p.stats[3]);
+  const float c_mag = p.g_mag[0] * p.inv_count;
+  const int n_fft = 2 * H, off = (n_fft - p.win_len) / 2;
+  const int64_t nw = (int64_t)gridDim.x * kFusedWaves;
+  for (int64_t fr = (int64_t)blockIdx.x * kFusedWaves + wave; fr < p.n_total; fr += nw) {
+    const int64_t b = fr / p.n_frames, f = fr - b * p.n_frames;
+    float *dst = p.dframes + fr * n_fft;
+    if (f < p.frame0) {                                   // outside the band: no gradient, but cum_stft_fold reads the support
+#pragma unroll
+      for (int i = 0; i < F::PER; ++i) {
+        const int n = 2 * (lane + 64 * i);
+        if (n + 1 >= off && n < off + p.win_len) *reinterpret_cast<float2 *>(dst + n) = make_float2(0.f, 0.f);
+      }
+      continue;
+    }
+    fused_load_frame<H>(p, b, f, lane, buf);
+    F::forward(buf, s_tw, lane);
+    // gradient spectrum gz over the transforms, in place: lanes own disjoint (j, H - j) pairs
+#pragma unroll 1
+    for (int i = 0; i <= F::PER / 2; ++i) {
+      const int j = lane + 64 * i;
+      if (j > H / 2) break;
+      const int m = j == 0 ? 0 : H - j;
+      const int pj = F::pad(F::pos(j)), pm = F::pad(F::pos(m));
+      const float4 vj = buf[pj], vm = buf[pm];
+      const float2 xj = make_float2(vj.x, vj.y), yj = make_float2(vj.z, vj.w), xm = make_float2(vm.x, vm.y), ym = make_float2(vm.z, vm.w);
+      float2 oj, om = make_float2(0.f, 0.f);
+      if (j == 0) {
+        const float2 g0 = bin_grad(make_float2(xj.x + xj.y, 0.f), make_float2(yj.x + yj.y, 0.f), c_sc, c_mag);
+        const float2 gh = bin_grad(make_float2(xj.x - xj.y, 0.f), make_float2(yj.x - yj.y, 0.f), c_sc, c_mag);
+        oj = make_float2(g0.x + gh.x, g0.x - gh.x);
+      } else {
+        const float2 wj = s_tw[j], wm = s_tw[H - j];
+        const float2 gj = bin_grad(packed_bin(xj, xm, wj), packed_bin(yj, ym, wj), c_sc, c_mag);
+        const float2 gm = bin_grad(packed_bin(xm, xj, wm), packed_bin(ym, yj, wm), c_sc, c_mag);
+        const float2 c1j = make_float2(0.5f * (1.f + wj.y), 0.5f * wj.x), c2j = make_float2(0.5f * (1.f - wj.y), 0.5f * wj.x);
+        const float2 c1m = make_float2(0.5f * (1.f + wm.y), 0.5f * wm.x), c2m = make_float2(0.5f * (1.f - wm.y), 0.5f * wm.x);
+        const float2 a = cmul(c1j, gj), bq = cmul(c2m, conjf2(gm));
+        oj = make_float2(a.x + bq.x, a.y + bq.y);
+        const float2 c = cmul(c1m, gm), d = cmul(c2j, conjf2(gj));
+        om = make_float2(c.x + d.x, c.y + d.y);
+      }
+      *reinterpret_cast<float2 *>(&buf[pj]) = oj;
+      if (m != j) *reinterpret_cast<float2 *>(&buf[pm]) = om;
+    }
+    F::inverse_xy(buf, s_tw, lane);
+    // frame gradient: sample 2m in the real part, 2m + 1 in the imaginary part; only the window's support is ever read
+#pragma unroll
+    for (int i = 0; i < F::PER; ++i) {
+      const int mm = lane + 64 * i, n = 2 * mm;
+      if (n + 1 >= off && n < off + p.win_len) {
+        const float4 v = buf[F::pad(mm)];
+        *reinterpret_cast<float2 *>(dst + n) = make_float2(v.x, v.y);
+      }
+    }
+  }
+}
+
 }  // namespace cum
 
 using namespace cum;
@@ -396,6 +700,71 @@ extern "C" int cum_stft_loss_bwd_packed(const float *zx, const float *zy, int64_
   hipLaunchKernelGGL(stft_loss_grad_packed_kernel, dim3((unsigned)parts), dim3(256), 0, (hipStream_t)stream,
                      (const float2 *)zx, (const float2 *)zy, rows, n_frames, H, frame0, stats, g_sc, g_mag,
                      (float)(1.0 / count), (const float2 *)twiddle, (float2 *)gz);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+// ---- fused entries (n_fft in {512, 1024, 2048}: cum_stft_fused_supported)
+extern "C" int cum_stft_fused_supported(int32_t n_fft) { return n_fft == 512 || n_fft == 1024 || n_fft == 2048; }
+
+static int fused_grid(int64_t n_total) {
+  // a multiple of the CU count, enough waves to cover the frames at a few frames per wave; a function of the shape only,
+  // so the partial sums (one per workgroup, fixed order) are reproducible
+  const int64_t want = cdiv64(n_total, 4 * kFusedWaves);
+  const int64_t g = want < 256 ? (want < 1 ? 1 : want) : (want < 2048 ? cdiv64(want, 256) * 256 : 2048);
+  return (int)g;
+}
+
+extern "C" int64_t cum_stft_fused_workspace_elems(int64_t batch, int64_t n_frames) { return 3 * (int64_t)fused_grid(batch * n_frames); }
+
+static int fused_params(FusedStftParams &p, const float *x, const float *y, int64_t batch, int64_t len, int64_t x_sb,
+                        int64_t y_sb, int32_t n_fft, int32_t hop, int32_t win_length, const float *window,
+                        const float *twiddle, int64_t n_frames, int64_t frame0) {
+  CUM_REQUIRE(cum_stft_fused_supported(n_fft), "stft_fused: n_fft must be 512, 1024 or 2048");
+  CUM_REQUIRE(batch > 0 && batch < 65536 && frame0 >= 0 && frame0 < n_frames, "stft_fused: bad batch / frame0");
+  if (int rc = check_resolution(len, n_fft, hop, win_length, n_frames)) return rc;
+  CUM_REQUIRE(x && y && window && twiddle, "stft_fused: null pointer");
+  p.x = x; p.y = y; p.window = window; p.tw = twiddle;
+  p.len = len; p.x_sb = x_sb; p.y_sb = y_sb; p.n_frames = n_frames; p.frame0 = frame0; p.n_total = batch * n_frames;
+  p.hop = hop; p.win_len = win_length;
+  return CUM_OK;
+}
+
+extern "C" int cum_stft_fused_fwd(const float *x, const float *y, int64_t batch, int64_t len, int64_t x_stride_b,
+                                  int64_t y_stride_b, int32_t n_fft, int32_t hop, int32_t win_length, const float *window,
+                                  const float *twiddle, int64_t n_frames, int64_t frame0, float *workspace, float *stats,
+                                  void *stream) {
+  FusedStftParams p{};
+  if (int rc = fused_params(p, x, y, batch, len, x_stride_b, y_stride_b, n_fft, hop, win_length, window, twiddle, n_frames, frame0)) return rc;
+  CUM_REQUIRE(workspace && stats, "stft_fused_fwd: null pointer");
+  p.partials = workspace;
+  const int grid = fused_grid(p.n_total);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_fft == 512) hipLaunchKernelGGL(stft_fused_fwd_kernel<256>, dim3(grid), dim3(64 * kFusedWaves), 0, st, p);
+  else if (n_fft == 1024) hipLaunchKernelGGL(stft_fused_fwd_kernel<512>, dim3(grid), dim3(64 * kFusedWaves), 0, st, p);
+  else hipLaunchKernelGGL(stft_fused_fwd_kernel<1024>, dim3(grid), dim3(64 * kFusedWaves), 0, st, p);
+  CUM_CHECK_LAUNCH();
+  const double count = (double)batch * (double)(n_frames - frame0) * (double)(n_fft / 2 + 1);
+  hipLaunchKernelGGL(stft_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, workspace, (int64_t)grid, count, stats);
+  CUM_CHECK_LAUNCH();
+  return CUM_OK;
+}
+
+extern "C" int cum_stft_fused_bwd(const float *x, const float *y, int64_t batch, int64_t len, int64_t x_stride_b,
+                                  int64_t y_stride_b, int32_t n_fft, int32_t hop, int32_t win_length, const float *window,
+                                  const float *twiddle, int64_t n_frames, int64_t frame0, const float *stats,
+                                  const float *g_sc, const float *g_mag, float *dframes, void *stream) {
+  FusedStftParams p{};
+  if (int rc = fused_params(p, x, y, batch, len, x_stride_b, y_stride_b, n_fft, hop, win_length, window, twiddle, n_frames, frame0)) return rc;
+  CUM_REQUIRE(stats && g_sc && g_mag && dframes && ((uintptr_t)dframes & 7) == 0, "stft_fused_bwd: null or misaligned pointer");
+  p.stats = stats; p.g_sc = g_sc; p.g_mag = g_mag; p.dframes = dframes;
+  const double count = (double)batch * (double)(n_frames - frame0) * (double)(n_fft / 2 + 1);
+  p.inv_count = (float)(1.0 / count);
+  const int grid = fused_grid(p.n_total);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_fft == 512) hipLaunchKernelGGL(stft_fused_bwd_kernel<256>, dim3(grid), dim3(64 * kFusedWaves), 0, st, p);
+  else if (n_fft == 1024) hipLaunchKernelGGL(stft_fused_bwd_kernel<512>, dim3(grid), dim3(64 * kFusedWaves), 0, st, p);
+  else hipLaunchKernelGGL(stft_fused_bwd_kernel<1024>, dim3(grid), dim3(64 * kFusedWaves), 0, st, p);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }

@@ -100,6 +100,11 @@ SIGNATURES = {
     "cum_fft_plan_create": (c_i32, [c_i32, c_i32, c_i64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i64)]),
     "cum_fft_plan_destroy": (c_i32, [_P]),
     "cum_fft_exec": (c_i32, [_P, _P, _P, c_i32, _P, _P]),
+    "cum_stft_fused_supported": (c_i32, [c_i32]),
+    "cum_stft_fused_workspace_elems": (c_i64, [c_i64, c_i64]),
+    "cum_stft_fused_fwd": (c_i32, [_P, _P, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, _P, _P, c_i64, c_i64, _P, _P, _P]),
+    "cum_stft_fused_bwd": (c_i32, [_P, _P, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, _P, _P, c_i64, c_i64, _P, _P, _P,
+                                   _P, _P]),
     "cum_stft_loss_fwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P]),
     "cum_stft_loss_bwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P, _P, _P]),
     "cum_enc0_fwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P, _P]),

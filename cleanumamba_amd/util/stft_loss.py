@@ -5,7 +5,8 @@ ParallelWaveGAN): per resolution a spectral-convergence term
 ||Y - X||_F / ||Y||_F and a log-magnitude L1 term on sqrt(clamp(re^2 + im^2, 1e-7)),
 averaged over resolutions and weighted by sc_lambda / mag_lambda.
 
-On the GPU one resolution is: cum_stft_frames (window + reflect padding, both signals) -> one batched
+On the GPU one resolution is ONE kernel per direction where the fused form applies (n_fft 512 / 1024 / 2048:
+cum_stft_fused_fwd / _bwd + cum_stft_fold, own FFT in LDS); otherwise: cum_stft_frames (window + reflect padding, both signals) -> one batched
 rocFFT complex FFT of n_fft/2 points over the frames read as packed complex numbers (cum_fft_exec) ->
 cum_stft_loss_fwd_packed (recovers the real-input spectrum, both terms, deterministic tree sums); backward is
 cum_stft_loss_bwd_packed -> one unnormalised inverse complex FFT -> cum_stft_fold (overlap-add gather).  The reference's ~25 elementwise passes per
@@ -24,6 +25,11 @@ from .. import hip
 # loss kernels (cum_stft_loss_*_packed) -- rocFFT's separate r2c post- / c2r pre-processing passes disappear.
 # CUM_STFT_PACKED=0 keeps the r2c / c2r route (A/B timing).
 _PACKED = os.environ.get("CUM_STFT_PACKED", "1") != "0"
+# Fused path (default where n_fft is 512 / 1024 / 2048, the reference's three resolutions): framing, both transforms and
+# the loss terms in one kernel per direction, on the library's own in-LDS FFT (csrc/stft_loss.hip, cum_stft_fused_*): no
+# frame and no spectrum reaches HBM (the rocFFT route above moves ~1.7 GB per direction and step at the training shape).
+# CUM_STFT_FUSED=0 keeps the rocFFT route (A/B timing, cross-check in the tests).
+_FUSED = os.environ.get("CUM_STFT_FUSED", "1") != "0"
 _TWIDDLE = {}
 
 
@@ -54,8 +60,21 @@ class STFTLossFn(torch.autograd.Function):
         n_frames, bins = 1 + L // hop, n_fft // 2 + 1
         frame0 = n_frames // 2 if high_band else 0          # reference slices dim 1 of (B, frames, bins): frames
         lib = hip.lib()
-        frames = torch.empty(2, bsz, n_frames, n_fft, dtype=torch.float32, device=x.device)
         stats = torch.empty(4, dtype=torch.float32, device=x.device)
+        if _FUSED and lib.cum_stft_fused_supported(n_fft):
+            # framing + both transforms + loss terms in one kernel (own FFT in LDS): nothing but the waveforms is read
+            ws = torch.empty(lib.cum_stft_fused_workspace_elems(bsz, n_frames), dtype=torch.float32, device=x.device)
+            tw = _twiddle(n_fft, x.device)
+            with torch.cuda.device(x.device):
+                hip.check(lib.cum_stft_fused_fwd(hip.ptr(x), hip.ptr(y), bsz, L, x.stride(0), y.stride(0), n_fft, hop,
+                                                 win_length, hip.ptr(window), hip.ptr(tw), n_frames, frame0, hip.ptr(ws),
+                                                 hip.ptr(stats), hip.stream_ptr()))
+            ctx.save_for_backward(x, stats, window, y)
+            ctx.cfg = (bsz, L, n_fft, hop, win_length, n_frames, bins, frame0)
+            ctx.fused = True
+            return stats[0], stats[1]
+        ctx.fused = False
+        frames = torch.empty(2, bsz, n_frames, n_fft, dtype=torch.float32, device=x.device)
         ws = torch.empty(max(lib.cum_stft_loss_workspace_elems(bsz, n_frames), 1), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             st = hip.stream_ptr()
@@ -86,9 +105,25 @@ class STFTLossFn(torch.autograd.Function):
     def backward(ctx, g_sc, g_mag):
         if ctx.needs_input_grad[1]:
             raise NotImplementedError("stft loss: no gradient wrt the target signal")
-        spec, stats, window = ctx.saved_tensors
         bsz, L, n_fft, hop, win_length, n_frames, bins, frame0 = ctx.cfg
         lib = hip.lib()
+        if ctx.fused:
+            x, stats, window, y = ctx.saved_tensors
+            zero = torch.zeros((), dtype=torch.float32, device=x.device) if (g_sc is None or g_mag is None) else None
+            g_sc = zero if g_sc is None else g_sc.float().contiguous()
+            g_mag = zero if g_mag is None else g_mag.float().contiguous()
+            dx = torch.empty(bsz, L, dtype=torch.float32, device=x.device)
+            dframes = torch.empty(bsz, n_frames, n_fft, dtype=torch.float32, device=x.device)
+            tw = _twiddle(n_fft, x.device)
+            with torch.cuda.device(x.device):
+                st = hip.stream_ptr()
+                hip.check(lib.cum_stft_fused_bwd(hip.ptr(x), hip.ptr(y), bsz, L, x.stride(0), y.stride(0), n_fft, hop,
+                                                 win_length, hip.ptr(window), hip.ptr(tw), n_frames, frame0, hip.ptr(stats),
+                                                 hip.ptr(g_sc), hip.ptr(g_mag), hip.ptr(dframes), st))
+                hip.check(lib.cum_stft_fold(hip.ptr(dframes), bsz, L, n_fft, hop, win_length, hip.ptr(window), n_frames,
+                                            hip.ptr(dx), dx.stride(0), 0, st))
+            return dx, None, None, None, None, None, None
+        spec, stats, window = ctx.saved_tensors
         zero = None
         if g_sc is None or g_mag is None:
             zero = torch.zeros((), dtype=torch.float32, device=spec.device)

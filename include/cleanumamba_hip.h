@@ -313,6 +313,25 @@ int cum_stft_loss_bwd_packed(const float *zx, const float *zy, int64_t batch, in
                              int64_t frame0, const float *stats, const float *g_sc, const float *g_mag,
                              const float *twiddle, float *gz, void *stream);
 
+/* The same loss with framing, both transforms and the loss terms in ONE kernel per direction (n_fft 512 / 1024 / 2048:
+ * cum_stft_fused_supported): a wave reads a frame's samples of x and y from the waveforms, transforms both in LDS
+ * (n_fft / 2 packed complex points, in-place radix-4, spectrum consumed in digit-reversed order) and accumulates the
+ * loss partial sums -- no frame and no spectrum reaches HBM.  The backward rebuilds the two transforms, forms the gradient
+ * spectrum in place, inverts it in LDS and writes the frame gradient over the window's support only, which is what
+ * cum_stft_fold reads (dframes [batch][n_frames][n_fft], elements outside the support are left untouched).
+ * x, y: [batch][len] f32 with row strides x_stride_b / y_stride_b (any; 8-byte aligned frames load in pairs); window [win_length];
+ * twiddle [n_fft/2 + 1] complex e^{-2 pi i k / n_fft}; frame0 / stats / g_sc / g_mag as above.
+ * workspace: cum_stft_fused_workspace_elems() f32.  Same values as the rocFFT path up to f32 rounding of the transform. */
+int cum_stft_fused_supported(int32_t n_fft);
+int64_t cum_stft_fused_workspace_elems(int64_t batch, int64_t n_frames);
+int cum_stft_fused_fwd(const float *x, const float *y, int64_t batch, int64_t len, int64_t x_stride_b,
+                       int64_t y_stride_b, int32_t n_fft, int32_t hop, int32_t win_length, const float *window,
+                       const float *twiddle, int64_t n_frames, int64_t frame0, float *workspace, float *stats,
+                       void *stream);
+int cum_stft_fused_bwd(const float *x, const float *y, int64_t batch, int64_t len, int64_t x_stride_b,
+                       int64_t y_stride_b, int32_t n_fft, int32_t hop, int32_t win_length, const float *window,
+                       const float *twiddle, int64_t n_frames, int64_t frame0, const float *stats,
+                       const float *g_sc, const float *g_mag, float *dframes, void *stream);
 
 /* ---- residual add + LayerNorm of the Mamba blocks (mamba-ssm Block.forward with fused_add_norm=False as the reference
  * runs it, src/network/CleanUMamba.py:156-189, 288-294, and the final add + norm_f, :292-294):

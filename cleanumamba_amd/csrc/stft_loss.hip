@@ -321,7 +321,9 @@ struct FusedFft {
   static constexpr int PER = H / 64;                 // points per lane
   static constexpr int SLOTS = H + H / 16;
   // butterflies of one stage a lane keeps in flight: H = 1024 fits two waves per SIMD (LDS capacity), which need some
-  // instruction-level overlap of their own; the smaller sizes run four waves per SIMD on <= 128 registers
+  // instruction-level overlap of their own; the smaller sizes run four or five waves per SIMD on <= 106 registers.
+  // (Keeping each lane's stage twiddles in registers across its frames instead of looking them up in LDS was measured
+  //  slower at every size: the 18 ... 44 extra registers cost a wave per SIMD, 117 -> 130 us on the 1024-point backward.)
   static constexpr int UNR = H == 1024 ? 2 : 1;
 
   __device__ static __forceinline__ int pad(int e) { return e + (e >> 4); }
@@ -436,6 +438,29 @@ struct FusedFft {
   }
 };
 
+// Loss terms of one bin on the hardware's sqrt / log2 (1 ulp each; the HBM-bound kernels above use libm's, which would cost
+// as much here as the transform itself): d = |Y| - |X|, |Y|^2, |log|Y| - log|X|| -- the logs straight from the clamped
+// powers, log m = (ln 2 / 2) log2 p.
+__device__ __forceinline__ void fused_terms(float2 sx, float2 sy, float &s1, float &s2, float &s3) {
+  const float px = fmaxf(sx.x * sx.x + sx.y * sx.y, kClamp), py = fmaxf(sy.x * sy.x + sy.y * sy.y, kClamp);
+  const float d = __builtin_amdgcn_sqrtf(py) - __builtin_amdgcn_sqrtf(px);
+  s1 = fmaf(d, d, s1);
+  s2 += py;
+  s3 += (0.5f * kLn2) * fabsf(__builtin_amdgcn_logf(py) - __builtin_amdgcn_logf(px));
+}
+
+// bin_grad on the same instructions; sign(log|X| - log|Y|) = sign(|X|^2 - |Y|^2) on the clamped powers (no logarithm)
+__device__ __forceinline__ float2 fused_bin_grad(float2 vx, float2 vy, float c_sc, float c_mag) {
+  const float pxr = vx.x * vx.x + vx.y * vx.y;
+  if (!(pxr >= kClamp)) return make_float2(0.f, 0.f);
+  const float py = fmaxf(vy.x * vy.x + vy.y * vy.y, kClamp);
+  const float inv_mx = __builtin_amdgcn_rsqf(pxr);
+  const float mx = pxr * inv_mx, my = __builtin_amdgcn_sqrtf(py);
+  const float sgn = pxr > py ? 1.f : (pxr < py ? -1.f : 0.f);
+  const float dm = (c_sc * (mx - my) + c_mag * sgn * inv_mx) * inv_mx;
+  return make_float2(dm * vx.x, dm * vx.y);
+}
+
 struct FusedStftParams {
   const float *x, *y, *window, *tw;
   int64_t len, x_sb, y_sb, n_frames, frame0, n_total;     // n_total = batch * n_frames
@@ -497,25 +522,31 @@ __global__ __launch_bounds__(64 * kFusedWaves) void stft_fused_fwd_kernel(const 
   fused_load_tables<H>(p, s_tw);
   float4 *buf = s_buf[wave];
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const int64_t nw = (int64_t)gridDim.x * kFusedWaves;
-  for (int64_t fr = (int64_t)blockIdx.x * kFusedWaves + wave; fr < p.n_total; fr += nw) {
-    const int64_t b = fr / p.n_frames, f = fr - b * p.n_frames;
+  const int nw = gridDim.x * kFusedWaves, n_total = (int)p.n_total, n_frames = (int)p.n_frames;   // (< 2^31: checked on the host)
+  for (int fr = blockIdx.x * kFusedWaves + wave; fr < n_total; fr += nw) {
+    const int b = fr / n_frames, f = fr - b * n_frames;
     if (f < p.frame0) continue;
     fused_load_frame<H>(p, b, f, lane, buf);
     F::forward(buf, s_tw, lane);
-#pragma unroll 2
-    for (int i = 0; i <= F::PER; ++i) {
-      const int k = lane + 64 * i;
-      if (k > H) break;
-      const int a = k == H ? 0 : k, bb = k == 0 ? 0 : H - k;
-      const float4 za = buf[F::pad(F::pos(a))], zb = buf[F::pad(F::pos(bb))];
-      const float2 w = s_tw[k];
-      const LossTerms t = loss_terms(packed_bin(make_float2(za.x, za.y), make_float2(zb.x, zb.y), w),
-                                     packed_bin(make_float2(za.z, za.w), make_float2(zb.z, zb.w), w));
-      const float d = t.my - t.mx;
-      s1 += d * d;
-      s2 += t.my * t.my;
-      s3 += fabsf(logf(t.my) - logf(t.mx));
+    // bins in mirror pairs (j, H - j): both need exactly Z[j] and Z[H - j] -- one pair of LDS reads, two bins
+#pragma unroll 1
+    for (int i = 0; i <= F::PER / 2; ++i) {
+      const int j = lane + 64 * i;
+      if (j > H / 2) break;
+      const int m = j == 0 ? 0 : H - j;
+      const float4 vj = buf[F::pad(F::pos(j))], vm = buf[F::pad(F::pos(m))];
+      const float2 xj = make_float2(vj.x, vj.y), yj = make_float2(vj.z, vj.w), xm = make_float2(vm.x, vm.y), ym = make_float2(vm.z, vm.w);
+      if (j == 0) {                                       // X[0] = Re z + Im z, X[H] = Re z - Im z (both real)
+        fused_terms(make_float2(xj.x + xj.y, 0.f), make_float2(yj.x + yj.y, 0.f), s1, s2, s3);
+        fused_terms(make_float2(xj.x - xj.y, 0.f), make_float2(yj.x - yj.y, 0.f), s1, s2, s3);
+      } else {
+        const float2 wj = s_tw[j];
+        fused_terms(packed_bin(xj, xm, wj), packed_bin(yj, ym, wj), s1, s2, s3);
+        if (m != j) {
+          const float2 wm = s_tw[m];
+          fused_terms(packed_bin(xm, xj, wm), packed_bin(ym, yj, wm), s1, s2, s3);
+        }
+      }
     }
   }
   float v[3] = {s1, s2, s3};
@@ -545,10 +576,10 @@ __global__ __launch_bounds__(64 * kFusedWaves) void stft_fused_bwd_kernel(const 
   const float c_sc = p.g_sc[0] / (p.stats[2] * p.stats[3]);
   const float c_mag = p.g_mag[0] * p.inv_count;
   const int n_fft = 2 * H, off = (n_fft - p.win_len) / 2;
-  const int64_t nw = (int64_t)gridDim.x * kFusedWaves;
-  for (int64_t fr = (int64_t)blockIdx.x * kFusedWaves + wave; fr < p.n_total; fr += nw) {
-    const int64_t b = fr / p.n_frames, f = fr - b * p.n_frames;
-    float *dst = p.dframes + fr * n_fft;
+  const int nw = gridDim.x * kFusedWaves, n_total = (int)p.n_total, n_frames = (int)p.n_frames;
+  for (int fr = blockIdx.x * kFusedWaves + wave; fr < n_total; fr += nw) {
+    const int b = fr / n_frames, f = fr - b * n_frames;
+    float *dst = p.dframes + (int64_t)fr * n_fft;
     if (f < p.frame0) {                                   // outside the band: no gradient, but cum_stft_fold reads the support
 #pragma unroll
       for (int i = 0; i < F::PER; ++i) {
@@ -570,13 +601,13 @@ __global__ __launch_bounds__(64 * kFusedWaves) void stft_fused_bwd_kernel(const 
       const float2 xj = make_float2(vj.x, vj.y), yj = make_float2(vj.z, vj.w), xm = make_float2(vm.x, vm.y), ym = make_float2(vm.z, vm.w);
       float2 oj, om = make_float2(0.f, 0.f);
       if (j == 0) {
-        const float2 g0 = bin_grad(make_float2(xj.x + xj.y, 0.f), make_float2(yj.x + yj.y, 0.f), c_sc, c_mag);
-        const float2 gh = bin_grad(make_float2(xj.x - xj.y, 0.f), make_float2(yj.x - yj.y, 0.f), c_sc, c_mag);
+        const float2 g0 = fused_bin_grad(make_float2(xj.x + xj.y, 0.f), make_float2(yj.x + yj.y, 0.f), c_sc, c_mag);
+        const float2 gh = fused_bin_grad(make_float2(xj.x - xj.y, 0.f), make_float2(yj.x - yj.y, 0.f), c_sc, c_mag);
         oj = make_float2(g0.x + gh.x, g0.x - gh.x);
       } else {
         const float2 wj = s_tw[j], wm = s_tw[H - j];
-        const float2 gj = bin_grad(packed_bin(xj, xm, wj), packed_bin(yj, ym, wj), c_sc, c_mag);
-        const float2 gm = bin_grad(packed_bin(xm, xj, wm), packed_bin(ym, yj, wm), c_sc, c_mag);
+        const float2 gj = fused_bin_grad(packed_bin(xj, xm, wj), packed_bin(yj, ym, wj), c_sc, c_mag);
+        const float2 gm = fused_bin_grad(packed_bin(xm, xj, wm), packed_bin(ym, yj, wm), c_sc, c_mag);
         const float2 c1j = make_float2(0.5f * (1.f + wj.y), 0.5f * wj.x), c2j = make_float2(0.5f * (1.f - wj.y), 0.5f * wj.x);
         const float2 c1m = make_float2(0.5f * (1.f + wm.y), 0.5f * wm.x), c2m = make_float2(0.5f * (1.f - wm.y), 0.5f * wm.x);
         const float2 a = cmul(c1j, gj), bq = cmul(c2m, conjf2(gm));
@@ -721,7 +752,8 @@ static int fused_params(FusedStftParams &p, const float *x, const float *y, int6
                         int64_t y_sb, int32_t n_fft, int32_t hop, int32_t win_length, const float *window,
                         const float *twiddle, int64_t n_frames, int64_t frame0) {
   CUM_REQUIRE(cum_stft_fused_supported(n_fft), "stft_fused: n_fft must be 512, 1024 or 2048");
-  CUM_REQUIRE(batch > 0 && batch < 65536 && frame0 >= 0 && frame0 < n_frames, "stft_fused: bad batch / frame0");
+  CUM_REQUIRE(batch > 0 && batch < 65536 && frame0 >= 0 && frame0 < n_frames && batch * n_frames < 2147483647LL,
+              "stft_fused: bad batch / frame0");
   if (int rc = check_resolution(len, n_fft, hop, win_length, n_frames)) return rc;
   CUM_REQUIRE(x && y && window && twiddle, "stft_fused: null pointer");
   p.x = x; p.y = y; p.window = window; p.tw = twiddle;

@@ -256,11 +256,9 @@ def test_every_gemm_of_the_b16_step_against_f64(cuda, dtype):
     assert any(t == 128 for t in tiles.values()) and any(t == 64 for t in tiles.values())
     # ---- every distinct call against f64
     for i, key in enumerate(nt):
-        print("nt", i, key, tiles[key], flush=True)
         _check_nt(cuda, dtype, key, f"b16.nt[{i}:epi{key[0]}:{key[1]}x{key[2]}x{key[3]}:tile{tiles[key]}]")
         torch.cuda.empty_cache()
     for i, key in enumerate(tn):
-        print("tn", i, key, tn_tiles[key], flush=True)
         _check_tn(cuda, dtype, key, f"b16.tn[{i}:{key[0]}x{key[1]}x{key[2]}:tile{tn_tiles[key]}]")
         torch.cuda.empty_cache()
 

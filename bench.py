@@ -614,7 +614,8 @@ def main():
                "final_loss": round(final_loss, 5), "step_graph": graph_status, "optimizer": optim_info,
                "host_ms_per_step_by_rank": [round(h, 3) for h in host_ms_ranks],
                "exchange": ("none" if world == 1 and not alone else
-                            "one all-reduce (AVG) of the flat 165.5 MB gradient buffer between the two captured graphs"
+                            "three graphs: all-reduce (AVG) of the decoder + bottleneck gradients (106 MB) beside the captured "
+                            "encoder backward, all-reduce of the encoder's (59 MB) after it, then the captured optimizer section"
                             if graph_status == "captured" else "per-bucket all-reduce overlapped with the eager backward")}
         if not args.no_roofline:
             del step, loss

@@ -306,6 +306,13 @@ class CleanUMamba(nn.Module):
                 y1 = cs.ConvK4S2ReLU.apply(buf, enc[0].weight, enc[0].bias, gi, gm)
                 buf = cs.PointwiseGLU.apply(y1, enc[2].weight, enc[2].bias, gm, go, save)
                 outs.append(buf)
+        cut = self.__dict__.get("_encoder_cut")
+        if cut is not None and torch.is_grad_enabled():
+            # training/train_step.py, captured multi-rank step: the backward is cut at the encoder's outputs so that the
+            # decoder + bottleneck gradients can be exchanged while the encoder's backward runs (a second graph)
+            leaves = tuple(o.detach().requires_grad_(True) for o in outs)
+            cut.append((tuple(outs), leaves))
+            outs = leaves
         skips = [(b, g[2]) for b, g in zip(outs, enc_geos)][::-1]
         buf = outs[-1]
 

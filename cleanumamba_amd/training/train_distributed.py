@@ -132,6 +132,24 @@ class GradBuckets:
             dist.all_reduce(g, group=self.group)
             g /= self.world
 
+    def exchange_range(self, start, end):
+        """Average flat.grad[start:end] over the ranks, asynchronously: returns a wait() callable.  The collective is
+        ordered behind the work already enqueued on the current stream and runs beside what is enqueued after this
+        call (the process group's own stream on RCCL)."""
+        if not self.exchanging or end <= start:
+            return lambda: None
+        g = self.flat.grad[start:end]
+        if self.use_avg:
+            h = dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            return h.wait
+
+        h = dist.all_reduce(g, group=self.group, async_op=True)
+
+        def wait():
+            h.wait()
+            g.div_(self.world)
+        return wait
+
     def all_ranks_agree(self, ok):
         """True iff ``ok`` holds on every rank (an eager MIN all-reduce of one flag; call it outside any capture, at
         a point every rank reaches at the same step)."""

@@ -9,13 +9,15 @@ Host-side differences:
     with device-side loss scaling (training/flat_optim.py, csrc/optim.hip) instead of ~10 multi-tensor launches over
     103 tensors and GradScaler's device->host sync;
   * with static shapes the whole step (forward, loss, backward, optimizer section) is captured ONCE in a hipGraph and
-    replayed: ~430 launches per step leave the host's critical path (``use_graph``).  With several ranks the step is
-    TWO graphs around the exchange -- [zero_grad, forward, loss, backward] -> one all-reduce of the whole flat gradient
-    buffer, issued eagerly between the replays -> [clip + Adam] -- so that no collective is ever captured and every
-    rank's host issues three calls per step instead of ~430 launches.  The price is that the exchange (165.5 MB at E8)
-    is not overlapped with backward; ``use_graph=False`` is the eager step with per-bucket overlap
-    (training/train_distributed.py).
+    replayed: ~320 launches per step leave the host's critical path (``use_graph``).  With several ranks the default is
+    the eager step with per-bucket overlap (training/train_distributed.py); ``use_graph=True`` opts into the captured
+    form, in which no collective is ever captured: THREE graphs -- [zero_grad, forward, loss, backward of decoder +
+    bottleneck] -> all-reduce of their gradients (the head of the flat buffer: 106 of 165.5 MB at E8), issued eagerly and
+    running beside -> [backward of the encoder] -> all-reduce of the tail -> [clip + Adam] -- five host calls per step
+    instead of ~320 launches, with two thirds of the exchange under the encoder's backward.  (Gradient accumulation or a
+    model without the fused conv stack: two graphs around one whole-buffer all-reduce.)
 """
+import os
 import time
 import warnings
 
@@ -138,6 +140,40 @@ class TrainStep:
             scaled.backward()
         return loss.detach()
 
+    def _backward(self, scaled, tensors=None, grads=None):
+        """backward() with the kernels' gradient sinks armed (flat optimizer) / through the GradScaler."""
+        def run():
+            if tensors is not None:
+                torch.autograd.backward(tensors, grads)
+            else:
+                scaled.backward()
+        if self.flat:
+            fp = self.buckets.flat
+            fp.armed = True
+            try:
+                run()
+            finally:
+                fp.armed = False
+        else:
+            run()
+
+    def _encoder_cut_offset(self):
+        """Element offset in the flat buffers where the encoder's parameters start, if they form its tail (they do: the
+        flat order is the reverse of the registration order and the encoder registers first) and the model runs the
+        fused conv stack, which is where the cut lives; else None."""
+        enc = getattr(self.net, "encoder", None)
+        if enc is None or not self.flat or not getattr(self.net, "use_fused_convs", True):
+            return None
+        fp = self.buckets.flat
+        ids = {id(p) for p in enc.parameters()}
+        if not ids:
+            return None
+        inside = [o for p, o in zip(fp.params, fp.offsets) if id(p) in ids]
+        outside = [o for p, o in zip(fp.params, fp.offsets) if id(p) not in ids]
+        if len(inside) != len(ids) or not outside or max(outside) >= min(inside):
+            return None
+        return min(inside)
+
     def optimizer_step(self, write_lr=True):
         """unscale -> clip -> Adam -> scale update.  Returns the gradient norm (device scalar)."""
         if self.flat:
@@ -193,13 +229,46 @@ class TrainStep:
                 # the exchange runs eagerly between the replays, graph 2 is the optimizer section.
                 # (thread_local: the process group's watchdog thread may query events while this thread captures;
                 #  in the default "global" mode such a call from another thread invalidates the capture)
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    loss = self._micro_steps(g["clean"], g["noisy"], exchange=False)
+                cut = self._encoder_cut_offset()
+                if cut is not None and self.repeats == 1:
+                    # THREE graphs: [zero_grad, forward, loss, backward of decoder + bottleneck] -> all-reduce of their
+                    # gradients (the head of the flat buffer) issued eagerly, running beside -> [backward of the encoder]
+                    # -> all-reduce of the tail -> [clip + Adam].  The autograd graph is cut at the encoder's outputs
+                    # (network/CleanUMamba.py _forward_fused): graph A ends with their gradients in hand, graph B feeds
+                    # them to the encoder's backward.
+                    holder = []
+                    self.net.__dict__["_encoder_cut"] = holder
+                    try:
+                        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                            self.zero_grad()
+                            self.buckets.require_sync = False
+                            loss = self._loss(g["clean"], g["noisy"])
+                            if len(holder) != 1:
+                                raise RuntimeError("the forward did not pass the encoder cut exactly once")
+                            outs, leaves = holder[0]
+                            self._backward(self.optimizer.scale_loss(loss))
+                            dys = [t.grad for t in leaves]
+                    finally:
+                        self.net.__dict__.pop("_encoder_cut", None)
+                    enc_graph = torch.cuda.CUDAGraph()
+                    try:                       # (require_sync stays off: the encoder's backward announces its gradients too)
+                        with torch.cuda.graph(enc_graph, pool=graph.pool(), capture_error_mode="thread_local"):
+                            live = [(o, d) for o, d in zip(outs, dys) if d is not None]
+                            self._backward(None, tensors=[o for o, _ in live], grads=[d for _, d in live])
+                    finally:
+                        self.buckets.require_sync = True
+                    loss = loss.detach()
+                    g.update(enc_graph=enc_graph, cut=cut, keep=(outs, leaves, dys))
+                else:
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        loss = self._micro_steps(g["clean"], g["noisy"], exchange=False)
                 optim_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(optim_graph, pool=graph.pool(), capture_error_mode="thread_local"):
                     norm = self.optimizer_step(write_lr=False)
                 g.update(graph=graph, optim_graph=optim_graph, loss=loss, norm=norm)
         except Exception as exc:          # noqa: BLE001 - capture is an optimisation; stay eager
+            if os.environ.get("CUM_DEBUG_CAPTURE") == "1":        # debugging: surface the capture error instead of going eager
+                raise
             g = {"failed": repr(exc)}
             warnings.warn(f"TrainStep: hipGraph capture of the train step failed ({exc!r}); steps run eagerly")
         if self.buckets is not None and self.buckets.exchanging:
@@ -236,7 +305,14 @@ class TrainStep:
             g["noisy"].copy_(noisy_audio)
             self.optimizer.write_lr()
             g["graph"].replay()
-            if "optim_graph" in g:
+            if "enc_graph" in g:
+                wait_head = self.buckets.exchange_range(0, g["cut"])        # beside the encoder's backward
+                g["enc_graph"].replay()
+                wait_tail = self.buckets.exchange_range(g["cut"], self.buckets.flat.numel)
+                wait_head()
+                wait_tail()
+                g["optim_graph"].replay()
+            elif "optim_graph" in g:
                 self.buckets.exchange_all()
                 g["optim_graph"].replay()
             self.buckets.flat.bump_versions()             # the replay moved the parameters behind autograd's back

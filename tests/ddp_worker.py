@@ -74,13 +74,13 @@ def main():
                      autocast_dtype=ac, use_graph=use_graph)
     if os.environ.get("CUM_TEST_BREAK_CAPTURE") == str(rank):
         # this rank's capture fails (the others' succeed): every rank must end up on the eager step
-        real_micro = step._micro_steps
+        real_loss = step._loss
 
         def broken(*a, **k):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("capture broken on purpose (test)")
-            return real_micro(*a, **k)
-        step._micro_steps = broken
+            return real_loss(*a, **k)
+        step._loss = broken
     if world > 1:
         clean, noisy = batch(rank, per_rank, length, dev)
     else:                                            # the single-process run sees the concatenated batch

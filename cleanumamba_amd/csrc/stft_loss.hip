@@ -320,6 +320,12 @@ struct FusedFft {
   static constexpr bool LEAD2 = (LOGH & 1) != 0;
   static constexpr int PER = H / 64;                 // points per lane
   static constexpr int SLOTS = H + H / 16;
+  // Measured and not kept (tools/prof_stft.sh, same box; forward 76 / 80 / 108 us, backward 113 / 116 / 162 us as shipped):
+  //   next frame's samples prefetched into registers while the current frame is transformed (+ window in registers):
+  //     90 / 94 / 109 and 126 / 153 / 217 us -- the registers cost one to two waves per SIMD, and the waves ARE the
+  //     latency hiding here (an ablation puts the exposed load phase at a third of the kernel: more waves, not prefetch);
+  //   contiguous runs of frames per wave (L1 reuse of the overlapping windows) instead of round-robin: 86 / 86 / 114;
+  //   W^2j, W^3j by complex multiplication instead of two more table look-ups: within noise.
   // butterflies of one stage a lane keeps in flight: H = 1024 fits two waves per SIMD (LDS capacity), which need some
   // instruction-level overlap of their own; the smaller sizes run four or five waves per SIMD on <= 106 registers.
   // (Keeping each lane's stage twiddles in registers across its frames instead of looking them up in LDS was measured

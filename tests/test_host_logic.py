@@ -239,3 +239,26 @@ def test_pack_layouts_separate_into_row_and_column_tables():
     h[0, 0] = -1
     assert _separable(h) is None
     assert _separable(torch.full((4, 8), -1, dtype=torch.int64)) is None
+
+
+def test_loss_terms_combination_matches_the_chain_of_scalar_ops():
+    """util._Combine folds loss_fn's scalar chain (src/util/util.py:300-327: term * lambda, sums over the resolutions, / n,
+    the total, the three logged components) into one matrix-vector product; values and gradients equal the chain's."""
+    from cleanumamba_amd.util.util import _Combine
+    torch.manual_seed(3)
+    vals = [torch.rand((), dtype=torch.float32).requires_grad_(True) for _ in range(7)]      # ae, (sc, mag) x 3
+    lam, stft_lam, sc_l, mag_l, n = 1.0, 1.0, 0.5, 0.5, 3
+    cs_, cm_ = stft_lam * sc_l / n, stft_lam * mag_l / n
+    sc_w, mag_w = [cs_, 0.0] * n, [0.0, cm_] * n
+    rows = ((lam,) + tuple(a + b for a, b in zip(sc_w, mag_w)), (lam,) + (0.0,) * (2 * n), (0.0,) + tuple(sc_w), (0.0,) + tuple(mag_w))
+    out = _Combine.apply(rows, *vals)
+    ref_vals = [v.detach().clone().requires_grad_(True) for v in vals]
+    sc = (ref_vals[1] + ref_vals[3] + ref_vals[5]) * sc_l / n
+    mag = (ref_vals[2] + ref_vals[4] + ref_vals[6]) * mag_l / n
+    loss = ref_vals[0] * lam + (sc + mag) * stft_lam
+    assert torch.allclose(out[0], loss, rtol=1e-6) and torch.allclose(out[1], ref_vals[0] * lam, rtol=1e-6)
+    assert torch.allclose(out[2], sc * stft_lam, rtol=1e-6) and torch.allclose(out[3], mag * stft_lam, rtol=1e-6)
+    (3.0 * out[0]).backward()
+    (3.0 * loss).backward()
+    for a, b in zip(vals, ref_vals):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6)

@@ -18,6 +18,22 @@
 
 namespace cum {
 
+// -DCUM_SCAN_PROBE (tools/scan_phase_probe.py): wave 0 of every workgroup sums s_memtime deltas per phase of a chunk; the
+// totals leave through the delta-bias slab (the op's ddelta_bias output then holds, per channel group, the cycles of phase
+// i in channel i).  Not compiled into the shipped library.
+#ifdef CUM_SCAN_PROBE
+#define PROBE(i)                                                   \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const unsigned long long t__ = __builtin_amdgcn_s_memtime();   \
+    ph[i] += (float)(t__ - tprev);                                 \
+    tprev = t__;                                                   \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#endif
+
 constexpr int NA = 5;         // reverse steps per 8-step half that take their decay factors from LDS (80 KB at NW = 8)
 // BC = 0: B_t / C_t through scalar loads, generic strides; 1: scalar loads, unit stride, all NS states valid;
 // 2: the chunk's B / C tiles staged in LDS by the whole workgroup (one coalesced load per chunk, broadcast
@@ -121,6 +137,10 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     }
   };
   load_rows(nchunks - 1);
+#ifdef CUM_SCAN_PROBE
+  float ph[12] = {};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * TB;
@@ -164,7 +184,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       }
     }
     if (c > 0) load_rows(c - 1);
+    PROBE(0);
     __syncthreads();
+    PROBE(1);
 
     f2 xs[SUB][NP2];   // states before each step of the half being processed
     // Operands of one time step: B_t / C_t slices (SGPRs via s_load) and the per-(t, d) values from LDS.  They are
@@ -289,15 +311,20 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
           cur = nxt;
         }
       }
+      PROBE(2);
 #pragma unroll
       for (int s = SUB - 1; s >= 0; --s) {     // reverse 15..8 (cur holds step 15's operands)
         if (s > 0) fetch(SUB + s - 1, nxt, s - 1);
         rev_step(xs[s], SUB + s, s, cur);
         if (s > 0) cur = nxt;
       }
+      PROBE(3);
       __syncthreads();
+      PROBE(4);
       finish_half(1);
+      PROBE(5);
       __syncthreads();  // partial-sum buffers are reused by the first half
+      PROBE(6);
     }
     // ---- first half (local steps 0..7)
     {
@@ -315,14 +342,18 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
           cur = nxt;
         }
       }
+      PROBE(7);
 #pragma unroll
       for (int s = SUB - 1; s >= 0; --s) {
         if (s > 0) fetch(s - 1, nxt, s - 1);
         rev_step(xs[s], s, s, cur);
         if (s > 0) cur = nxt;
       }
+      PROBE(8);
       __syncthreads();
+      PROBE(9);
       finish_half(0);
+      PROBE(10);
     }
     // The next chunk's phase A writes only s_dt/s_du/s_dy (their readers finished before
     // the last barrier) and its first rev_step runs after that phase's barrier, which
@@ -348,6 +379,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     }
     p.ws_dD[(int64_t)b * Dm + d] = a;
     p.ws_dbias[(int64_t)b * Dm + d] = c2;
+#ifdef CUM_SCAN_PROBE
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v = lane == i ? ph[i] : v;
+    p.ws_dbias[(int64_t)b * Dm + d] = v;
+#endif
   }
 }
 

@@ -469,8 +469,9 @@ class _WgradArena:
         return torch.where(ids > 0, ids - 1 + self.offs[slot] + N * K, torch.full_like(ids, -1))
 
     def unpack_into(self, key, build_parts, shapes, dst, offs):
-        """The same gather with the flat gradient buffer ``dst`` as destination: parameter k lands at element offset
-        offs[k]; elements between parameters (alignment padding) are written as zeros.  One launch."""
+        """The arena's weight / bias gradients into the flat gradient buffer ``dst``: parameter k lands at element offset
+        offs[k]; the alignment padding between parameters is not written (FlatParams.zero_grad cleared it).  One
+        index-free launch (cum_pack2d) for everything whose layout separates."""
         lo = min(offs)
         hi = max(o + _numel(sh) for o, sh in zip(offs, shapes))
         if sum((_numel(sh) + 3) // 4 * 4 for sh in shapes) < hi - lo:
@@ -478,12 +479,49 @@ class _WgradArena:
         ck = (key, "into", tuple(o - lo for o in offs), self.buf.device)
         ent = _ARENA_INDEX.get(ck)
         if ent is None:
-            full = torch.full((hi - lo,), -1, dtype=torch.int64)
-            for part, o, sh in zip(build_parts(), offs, shapes):
-                full[o - lo:o - lo + _numel(sh)] = part.reshape(-1)
-            ent = full.to(torch.int32).to(self.buf.device)
+            # Every GEMM-layout -> parameter-layout map separates (source = rowoff[r] + coloff[c] over the parameter seen
+            # as a matrix: weights (a, b * c), vectors (1, n)), like the forward packs: the index-free cum_pack2d brings
+            # them over with two small tables per parameter instead of a 4-byte index per element.  What does not
+            # separate (or is narrower than 8 columns) keeps the per-element gather.
+            parts = build_parts()
+            jobs, tiles, tables, tab_pos, rest = [], [], [], 0, []
+            for k, (part, o, sh) in enumerate(zip(parts, offs, shapes)):
+                rows, cols = (sh[0], _numel(sh) // sh[0]) if len(sh) > 1 else (1, _numel(sh))
+                sep = _separable(part.reshape(rows, cols).to(torch.int64)) if (_PACK2D and cols % 8 == 0 and o % 4 == 0) else None
+                if sep is None or bool((part.reshape(-1) < 0).any()):
+                    rest.append(k)
+                    continue
+                ro, co, tr = sep
+                jobs.append((o, rows, cols, tab_pos, tab_pos + rows, int(tr)))
+                tables += [ro, co]
+                tab_pos += rows + cols
+                for tr_ in range((rows + 63) // 64):
+                    for tc_ in range((cols + 63) // 64):
+                        tiles.append((len(jobs) - 1, tr_, tc_))
+            pack2d = None
+            if jobs:
+                import numpy as np
+                jb = np.zeros(len(jobs), dtype=[("off", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("rt", "<i4"), ("ct", "<i4"),
+                                                ("tr", "<i4"), ("pad", "<i4")])
+                for i, (off, r, c, rt, ct, tr) in enumerate(jobs):
+                    jb[i] = (off, r, c, rt, ct, tr, 0)
+                dev = self.buf.device
+                pack2d = (torch.from_numpy(jb.view(np.uint8)).to(dev), torch.tensor(tiles, dtype=torch.int32).to(dev),
+                          torch.cat(tables).to(dev), len(tiles))
+            gidx = None
+            if rest:
+                # (the leftovers need not be contiguous: one small gather each)
+                gidx = [(offs[k], parts[k].reshape(-1).to(torch.int32).to(self.buf.device)) for k in rest]
+            ent = (pack2d, gidx)
             _ARENA_INDEX[ck] = ent
-        gather(self.buf, ent, torch.float32, out=dst[lo:hi])
+        pack2d, gidx = ent
+        if pack2d is not None:
+            jb, tl, tb, ntiles = pack2d
+            with torch.cuda.device(self.buf.device):
+                hip.check(hip.lib().cum_pack2d(hip.ptr(self.buf), hip.ptr(jb), hip.ptr(tl), ntiles, hip.ptr(tb),
+                                               hip.dtype_code(torch.float32), hip.ptr(dst), hip.stream_ptr()))
+        for o, gi in (gidx or ()):
+            gather(self.buf, gi, torch.float32, out=dst[o:o + gi.numel()])
 
     def unpack(self, key, build_parts, shapes):
         """One gather for all parameters; build_parts() -> [index tensor per parameter]; returns views per shape."""

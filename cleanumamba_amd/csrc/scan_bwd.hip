@@ -388,12 +388,16 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   }
 }
 
-// Deterministic slab reductions: dA, dD, dbias over batch; dB, dC over channel groups.
+// Deterministic slab reductions: dA, dD, dbias over batch; dB, dC over channel groups.  VEC: a thread owns four
+// consecutive dB / dC values (L * N a multiple of 4, 16-byte aligned buffers) and keeps eight 16-byte loads in flight --
+// the dB / dC slabs are the bulk of what this kernel reads (B * G * L * N * 8 bytes: 163 MB at the E8 bottleneck).
+template <bool VEC>
 __global__ void scan_bwd_finalize_kernel(const ScanParams p, float *dA, float *dD, float *dbias, float *dB,
                                          float *dC) {
+  constexpr int V = VEC ? 4 : 1;
   const int64_t N = p.s.dstate, L = p.s.len, Dm = p.s.dim, Bn = p.s.batch, G = p.ngroups;
-  const int64_t nA = Dm * N, nBC = Bn * L * N;
-  const int64_t total = nA + 2 * Dm + 2 * nBC;
+  const int64_t nA = Dm * N, nBC = Bn * L * N, LN = L * N;
+  const int64_t total = nA + 2 * Dm + 2 * nBC / V;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     if (i < nA) {
@@ -411,14 +415,31 @@ __global__ void scan_bwd_finalize_kernel(const ScanParams p, float *dA, float *d
       for (int64_t b = 0; b < Bn; ++b) s += p.ws_dbias[b * Dm + d];
       if (dbias) dbias[d] = s;
     } else {
-      int64_t r = i - nA - 2 * Dm;
+      int64_t r = (i - nA - 2 * Dm) * V;
       const bool isC = r >= nBC;
       if (isC) r -= nBC;
-      const int64_t b = r / (L * N), tn = r % (L * N);
-      const float *ws = (isC ? p.ws_dC : p.ws_dB) + b * G * L * N + tn;
-      float s = 0.f;
-      for (int64_t gg = 0; gg < G; ++gg) s += ws[gg * L * N];
-      (isC ? dC : dB)[r] = s;
+      const int64_t b = r / LN, tn = r % LN;
+      const float *ws = (isC ? p.ws_dC : p.ws_dB) + b * G * LN + tn;
+      if constexpr (VEC) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t gg = 0;
+        for (; gg + 8 <= G; gg += 8) {
+          float4 v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(ws + (gg + k) * LN);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }   // (same order as the scalar form)
+        }
+        for (; gg < G; ++gg) {
+          const float4 v = *reinterpret_cast<const float4 *>(ws + gg * LN);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>((isC ? dC : dB) + r) = s;
+      } else {
+        float s = 0.f;
+        for (int64_t gg = 0; gg < G; ++gg) s += ws[gg * LN];
+        (isC ? dC : dB)[r] = s;
+      }
     }
   }
 }
@@ -511,10 +532,15 @@ extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_gr
     default: rc = launch_bwd<8>(p, st); break;
   }
   if (rc) return rc;
-  const int64_t total = (int64_t)s->dim * s->dstate + 2 * s->dim + 2 * (int64_t)s->batch * s->len * s->dstate;
+  const int64_t LN = (int64_t)s->len * s->dstate;
+  const bool vec = LN % 4 == 0 && (((uintptr_t)dB | (uintptr_t)dC | (uintptr_t)p.ws_dB | (uintptr_t)p.ws_dC) & 15) == 0;
+  const int64_t total = (int64_t)s->dim * s->dstate + 2 * s->dim + 2 * (int64_t)s->batch * LN / (vec ? 4 : 1);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(scan_bwd_finalize_kernel, dim3(blocks), dim3(256), 0, st, p, dA, dD, ddelta_bias, dB, dC);
+  if (vec)
+    hipLaunchKernelGGL(scan_bwd_finalize_kernel<true>, dim3(blocks), dim3(256), 0, st, p, dA, dD, ddelta_bias, dB, dC);
+  else
+    hipLaunchKernelGGL(scan_bwd_finalize_kernel<false>, dim3(blocks), dim3(256), 0, st, p, dA, dD, ddelta_bias, dB, dC);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }

@@ -49,6 +49,10 @@ class AddLayerNormFn(torch.autograd.Function):
                 hip.ptr(y), hip.ptr(mean), hip.ptr(rstd), hip.stream_ptr()))
         ctx.save_for_backward(res_out, mean, rstd, weight)
         ctx.h_dtype, ctx.has_res, ctx.has_bias = hidden.dtype, residual is not None, bias is not None
+        # the parameters themselves (identity only: gradient-sink lookup), when they are f32 leaves
+        ctx.params = [q for q in (weight, bias) if q is not None]
+        if not all(q.is_leaf and q.dtype == torch.float32 for q in ctx.params):
+            ctx.params = None
         return y, res_out
 
     @staticmethod
@@ -70,8 +74,18 @@ class AddLayerNormFn(torch.autograd.Function):
         same = ctx.h_dtype == torch.float32
         dx32 = torch.empty(bsz, L, dim, dtype=torch.float32, device=dev) if (need_r or (need_h and same)) else None
         dxh = torch.empty(bsz, L, dim, dtype=ctx.h_dtype, device=dev) if (need_h and not same) else None
-        dw = torch.empty(dim, dtype=torch.float32, device=dev)
-        db = torch.empty(dim, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        # weight / bias gradients straight into the flat gradient buffer when it takes them (training/flat_optim.py): no
+        # AccumulateGrad add per vector
+        from ...network.convstack import grad_sink
+        sink = grad_sink(ctx.params) if (ctx.params and ctx.needs_input_grad[2]
+                                         and (not ctx.has_bias or ctx.needs_input_grad[3])) else None
+        if sink is not None:
+            flat, idx, offs = sink
+            dw = flat.grad[offs[0]:offs[0] + dim]
+            db = flat.grad[offs[1]:offs[1] + dim] if ctx.has_bias else None
+        else:
+            dw = torch.empty(dim, dtype=torch.float32, device=dev)
+            db = torch.empty(dim, dtype=torch.float32, device=dev) if ctx.has_bias else None
         ws = torch.empty(lib.cum_add_layernorm_bwd_workspace_elems(dim), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             hip.check(lib.cum_add_layernorm_bwd(
@@ -79,6 +93,9 @@ class AddLayerNormFn(torch.autograd.Function):
                 hip.ptr(res_out), hip.ptr(mean), hip.ptr(rstd), hip.ptr(weight), hip.ptr(dx32), hip.ptr(dxh),
                 hip.ptr(dw), hip.ptr(db), hip.ptr(ws), hip.stream_ptr()))
         dh = (dx32 if same else dxh) if need_h else None
+        if sink is not None:
+            flat.wrote(idx)
+            dw = db = None
         return dh, (dx32 if need_r else None), dw, db, None, None
 
 

@@ -1369,6 +1369,18 @@ class EncoderStack(torch.autograd.Function):
         return (dx0, None, None, *grads)
 
 
+def _convt_bias_grad(bt, dbp, Cp, C, dtype):
+    """Transposed-conv bias gradient = sum of the two halves of the paired-row bias gradient; one add straight into the
+    flat gradient buffer when it takes it (returns None then), else the tensor for autograd."""
+    sink = grad_sink([bt]) if (bt.is_leaf and bt.dtype == torch.float32) else None
+    if sink is not None:
+        flat, idx, offs = sink
+        torch.add(dbp[:C], dbp[Cp:Cp + C], out=flat.grad[offs[0]:offs[0] + C])
+        flat.wrote(idx)
+        return None
+    return (dbp[:Cp] + dbp[Cp:2 * Cp])[:C].to(dtype)
+
+
 class DecoderStack(torch.autograd.Function):
     """u_0 -> u_E: every decoder layer [Conv1d 1x1, GLU, ConvTranspose1d k4 s2, (ReLU)] with the encoder skip added
     to its output (src/network/CleanUMamba.py:121-130, 313-316).  geos[j] = (g_in, g_glu, g_out); skips[j] is added
@@ -1443,14 +1455,14 @@ class DecoderStack(torch.autograd.Function):
             if j == E - 1 and ctx.fused_last:
                 (ab, ao), nk = arena.out(2 * j + 1), 2 * go.Cp * 2 * gg.Cp
                 du, dpre = _dec7_bwd(dpre, us[j], acts[j - 1][gi.Cp // 4:], w1, b1, wt, gi, arena.out(2 * j), (ab, ao))
-                grads[4 * j + 3] = (ab[ao + nk:ao + nk + go.Cp] + ab[ao + nk + go.Cp:ao + nk + 2 * go.Cp])[:sht[1]].to(wt.dtype)
+                grads[4 * j + 3] = _convt_bias_grad(bt, ab[ao + nk:ao + nk + 2 * go.Cp], go.Cp, sht[1], wt.dtype)
                 if j - 1 < ctx.n_skips:
                     dskips[j - 1] = du
                 continue
             # transposed-conv weight gradient: pair rows of dpre against the 2*Cp contiguous inputs (rows m-1, m)
             dwp, dbp = wgrad(dpre, go.Cp, 2 * go.Cp, 2 * go.Cp, gs[j], 0, gg.Cp, 2 * gg.Cp, gg.M,
                              out=arena.out(2 * j + 1) if arena else None)
-            grads[4 * j + 3] = (dbp[:go.Cp] + dbp[go.Cp:])[:sht[1]].to(wt.dtype)
+            grads[4 * j + 3] = _convt_bias_grad(bt, dbp, go.Cp, sht[1], wt.dtype)
             if arena is None:
                 grads[4 * j + 2] = take(dwp, ("convt_unpack", sht, gg.Cp, go.Cp),
                                         lambda: _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)).to(wt.dtype)

@@ -253,18 +253,19 @@ __global__ __launch_bounds__(256) void dwconv_bwd_finalize_kernel(const float *w
   const int i = blockIdx.x * 64 + lane;
   const bool live = i < (MAXW + 1) * dim;
   const int k = live ? i / dim : 0, d = live ? i % dim : 0;
-  float a0 = 0.f, a1 = 0.f;
+  // eight loads in flight per thread (624 slabs at the E8 bottleneck: the two-deep form spent 25 us on load latency)
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (live && (k < W || k == MAXW)) {
     const float *base = ws + (int64_t)k * dim + d;
     const int64_t stride = (int64_t)(MAXW + 1) * dim;
     int j = sl;
-    for (; j + 4 < nslabs; j += 8) {
-      a0 += base[j * stride];
-      a1 += base[(j + 4) * stride];
+    for (; j + 28 < nslabs; j += 32) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] += base[(j + 4 * q) * stride];
     }
-    if (j < nslabs) a0 += base[j * stride];
+    for (int q = 0; j < nslabs; j += 4, ++q) a[q & 7] += base[j * stride];
   }
-  red[sl][lane] = a0 + a1;
+  red[sl][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   if (sl == 0 && live) {
     const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);

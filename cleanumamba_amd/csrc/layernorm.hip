@@ -224,16 +224,16 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_finalize_kernel(const f
   const int e = blockIdx.x * 64 + lane;
   const bool live = e < 2 * dim;
   const int k = live ? e / dim : 0, c = live ? e % dim : 0;
-  float a0 = 0.f, a1 = 0.f;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight loads in flight per thread
   if (live) {
     int s = sl;
-    for (; s + 4 < nslab; s += 8) {
-      a0 += slab[((int64_t)s * 2 + k) * dim + c];
-      a1 += slab[((int64_t)(s + 4) * 2 + k) * dim + c];
+    for (; s + 28 < nslab; s += 32) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] += slab[((int64_t)(s + 4 * q) * 2 + k) * dim + c];
     }
-    if (s < nslab) a0 += slab[((int64_t)s * 2 + k) * dim + c];
+    for (int q = 0; s < nslab; s += 4, ++q) a[q & 7] += slab[((int64_t)s * 2 + k) * dim + c];
   }
-  red[sl][lane] = a0 + a1;
+  red[sl][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   if (sl == 0 && live) {
     const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);

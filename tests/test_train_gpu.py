@@ -350,7 +350,8 @@ def test_gradient_accumulation_equals_one_big_batch(cuda):
 
 def test_gradient_sink_equals_autograd_accumulation(cuda, monkeypatch):
     """Kernels that write parameter gradients straight into the flat gradient buffer (convstack.grad_sink: the conv
-    stacks' batched un-pack, the 1x1 bottleneck convs, the Mamba projections) against the same backward with every
+    stacks' batched un-pack, the 1x1 bottleneck convs, the Mamba projections, the LayerNorm weights / biases, the transposed
+    convs' biases) against the same backward with every
     gradient routed through autograd's AccumulateGrad: bit-identical buffers; a second backward without zero_grad
     accumulates."""
     from cleanumamba_amd.network import convstack as cs

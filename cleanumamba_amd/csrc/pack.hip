@@ -70,7 +70,8 @@ struct PackJob {
   int32_t rows, cols;   // destination matrix (cols: multiple of 8)
   int32_t row_tab, col_tab;   // positions of the two tables in `tables`
   int32_t transpose;    // 1: source is fast along destination rows
-  int32_t pad_;
+  int32_t runs8;        // 1: every aligned group of 8 destination columns is 8 consecutive source elements (or all padding)
+                        // 2: ... and every such run starts on a 16-byte boundary of the source (two float4 loads)
 };
 
 template <typename TD>
@@ -110,10 +111,24 @@ __global__ __launch_bounds__(256) void pack2d_kernel(const float *__restrict__ s
     } else {
       const int ro = rt[r];
       float v[8];
+      if (j.runs8) {          // one table entry and a contiguous run instead of eight entries and eight gathers
+        const int co = ct[c];
+        const bool pad = ro == PACK_PAD || co == PACK_PAD;
+        const float *q = src + (pad ? 0 : (int64_t)ro + co);
+        if (j.runs8 == 2) {
+          const float4 a = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(q);
+          const float4 b = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(q + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int co = ct[c + i];
-        v[i] = (ro == PACK_PAD || co == PACK_PAD) ? 0.f : src[(int64_t)ro + co];
+          for (int i = 0; i < 8; ++i) v[i] = pad ? 0.f : q[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int co = ct[c + i];
+          v[i] = (ro == PACK_PAD || co == PACK_PAD) ? 0.f : src[(int64_t)ro + co];
+        }
       }
       *reinterpret_cast<V *>(out + (int64_t)r * j.cols + c) = Vec4<TD>::make(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<V *>(out + (int64_t)r * j.cols + c + 4) = Vec4<TD>::make(v[4], v[5], v[6], v[7]);
@@ -130,7 +145,8 @@ extern "C" int cum_pack2d(const float *src, const void *jobs, const int32_t *til
   CUM_REQUIRE(dtype_ok(dst_dtype), "pack2d: dst dtype must be CUM_F32 / CUM_BF16 / CUM_F16");
   CUM_REQUIRE(n_tiles >= 0, "pack2d: negative tile count");
   if (n_tiles == 0) return CUM_OK;
-  CUM_REQUIRE(src && jobs && tiles && tables && dst && ((uintptr_t)dst & 15) == 0, "pack2d: null or misaligned pointer");
+  CUM_REQUIRE(src && jobs && tiles && tables && dst && ((uintptr_t)dst & 15) == 0 && ((uintptr_t)src & 15) == 0,
+              "pack2d: null or misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
   const PackJob *pj = static_cast<const PackJob *>(jobs);
   if (dst_dtype == CUM_F16)

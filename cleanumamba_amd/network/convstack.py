@@ -195,6 +195,26 @@ def _separable(g2):
     return rowoff.to(torch.int32), coloff.to(torch.int32), bool(dr < dc)
 
 
+def _runs8(ro, co, base=0):
+    """cum_pack2d's fast path for a separable layout: 1 if every aligned group of 8 destination columns is either all
+    padding or 8 consecutive source elements, 2 if in addition every run starts on a 16-byte boundary of the f32 source
+    (``base``: element offset of the source inside its 16-byte aligned buffer), else 0."""
+    c = co.to(torch.int64).view(-1, 8)
+    pad = c == PACK_PAD
+    if bool((pad.any(1) & ~pad.all(1)).any()):
+        return 0
+    live = ~pad.all(1)
+    if not bool(live.any()):
+        return 0
+    cl = c[live]
+    if not torch.equal(cl, cl[:, :1] + torch.arange(8, dtype=torch.int64)):
+        return 0
+    rl = ro.to(torch.int64)
+    rl = rl[rl != PACK_PAD]
+    aligned = bool(((cl[:, 0] % 4) == 0).all()) and bool((((rl + base) % 4) == 0).all())
+    return 2 if aligned else 1
+
+
 class PackPlan:
     """Batches every weight / bias pack of one model into two gathers per forward.
 
@@ -287,7 +307,7 @@ class PackPlan:
                         rest.append((rk, g, shape))
                         continue
                     ro, co, tr = sep
-                    jobs.append((start, shape[0], shape[1], tab_pos, tab_pos + shape[0], int(tr)))
+                    jobs.append((start, shape[0], shape[1], tab_pos, tab_pos + shape[0], int(tr), 0 if tr else _runs8(ro, co)))
                     tables += [ro, co]
                     tab_pos += shape[0] + shape[1]
                     for tr_ in range((shape[0] + 63) // 64):
@@ -304,9 +324,9 @@ class PackPlan:
                 if jobs:
                     import numpy as np
                     jb = np.zeros(len(jobs), dtype=[("off", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("rt", "<i4"), ("ct", "<i4"),
-                                                    ("tr", "<i4"), ("pad", "<i4")])
-                    for i, (off, r, c, rt, ct, tr) in enumerate(jobs):
-                        jb[i] = (off, r, c, rt, ct, tr, 0)
+                                                    ("tr", "<i4"), ("runs8", "<i4")])
+                    for i, (off, r, c, rt, ct, tr, r8) in enumerate(jobs):
+                        jb[i] = (off, r, c, rt, ct, tr, r8)
                     pack2d = (torch.from_numpy(jb.view(np.uint8)).to(dev), torch.tensor(tiles, dtype=torch.int32).to(dev),
                               torch.cat(tables).to(dev), len(tiles))
                 gi = torch.cat(parts).to(dev) if parts else None
@@ -492,7 +512,7 @@ class _WgradArena:
                     rest.append(k)
                     continue
                 ro, co, tr = sep
-                jobs.append((o, rows, cols, tab_pos, tab_pos + rows, int(tr)))
+                jobs.append((o, rows, cols, tab_pos, tab_pos + rows, int(tr), 0 if tr else _runs8(ro, co)))
                 tables += [ro, co]
                 tab_pos += rows + cols
                 for tr_ in range((rows + 63) // 64):
@@ -502,9 +522,9 @@ class _WgradArena:
             if jobs:
                 import numpy as np
                 jb = np.zeros(len(jobs), dtype=[("off", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("rt", "<i4"), ("ct", "<i4"),
-                                                ("tr", "<i4"), ("pad", "<i4")])
-                for i, (off, r, c, rt, ct, tr) in enumerate(jobs):
-                    jb[i] = (off, r, c, rt, ct, tr, 0)
+                                                ("tr", "<i4"), ("runs8", "<i4")])
+                for i, (off, r, c, rt, ct, tr, r8) in enumerate(jobs):
+                    jb[i] = (off, r, c, rt, ct, tr, r8)
                 dev = self.buf.device
                 pack2d = (torch.from_numpy(jb.view(np.uint8)).to(dev), torch.tensor(tiles, dtype=torch.int32).to(dev),
                           torch.cat(tables).to(dev), len(tiles))

@@ -281,10 +281,13 @@ int cum_gather(int32_t src_dtype, const void *src, const int32_t *idx, int64_t n
 
 /* cum_pack2d: the same re-pack without a per-element index, for layouts that separate into dst[r][c] =
  * src[rowoff[r] + coloff[c]] (all weight layouts of the conv stack and the projections: network/convstack.py PackPlan).
- * jobs: device array of { int64 dst_off; int32 rows, cols (multiple of 8), row_tab, col_tab, transpose, pad } -- dst_off
+ * jobs: device array of { int64 dst_off; int32 rows, cols (multiple of 8), row_tab, col_tab, transpose, runs8 } -- dst_off
  * in elements (multiple of 8) from `dst`, row_tab / col_tab positions in `tables` (int32, INT32_MIN = zero padding),
- * transpose = 1 when the source is fast along destination rows (the 64 x 64 tile then goes through LDS).
- * tiles: device array of n_tiles x { job, tile row, tile column }.  src: f32. */
+ * transpose = 1 when the source is fast along destination rows (the 64 x 64 tile then goes through LDS); runs8 (only
+ * read when transpose = 0): 0 = no promise; 1 = every aligned group of 8 destination columns is all padding or 8
+ * consecutive source elements (one table entry and one run per group instead of eight gathers); 2 = and every run starts
+ * at a multiple of 4 elements from `src` (16-byte loads).
+ * tiles: device array of n_tiles x { job, tile row, tile column }.  src: f32, 16-byte aligned. */
 int cum_pack2d(const float *src, const void *jobs, const int32_t *tiles, int32_t n_tiles, const int32_t *tables,
                int32_t dst_dtype, void *dst, void *stream);
 

@@ -277,8 +277,9 @@ def test_fused_first_encoder_layer(cuda, tin, dtype, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_index_free_repack_equals_index_gather(cuda, dtype):
-    """cum_pack2d (row / column offset tables, LDS transpose) against cum_gather over the same layouts, bit for bit:
-    straight and transposed sources, padded rows and columns, ragged tile edges, several jobs in one launch."""
+    """cum_pack2d (row / column offset tables, LDS transpose, contiguous-run fast path) against cum_gather over the same
+    layouts, bit for bit: straight and transposed sources, padded rows and columns, ragged tile edges, runs of 8 on and off
+    16-byte boundaries, several jobs in one launch."""
     from cleanumamba_amd import hip
     from cleanumamba_amd.network import convstack as cs
     import numpy as np
@@ -297,20 +298,29 @@ def test_index_free_repack_equals_index_gather(cuda, dtype):
     wt = torch.full((96, 136), -1, dtype=torch.int64)
     wt[:, :130] = w.t()
     cases.append(wt)
+    # the contiguous-run fast path: the same weight padded to [136, 104] (runs of 8 on 16-byte boundaries: runs8 = 2),
+    # and at an odd offset (runs8 = 1: scalar loads of a run)
+    wp = torch.full((136, 104), -1, dtype=torch.int64)
+    wp[:130, :96] = w
+    cases.append(wp)
+    wo = torch.full((136, 104), -1, dtype=torch.int64)
+    wo[:130, :96] = w + 70001
+    cases.append(wo)
     jobs, tiles, tables, pos, off = [], [], [], 0, 0
     for g2 in cases:
         sep = cs._separable(g2)
         assert sep is not None
         ro, co, tr = sep
         R_, C_ = g2.shape
-        jobs.append((off, R_, C_, pos, pos + R_, int(tr), 0))
+        jobs.append((off, R_, C_, pos, pos + R_, int(tr), 0 if tr else cs._runs8(ro, co)))
         tables += [ro, co]
         pos += R_ + C_
         tiles += [(len(jobs) - 1, a, b) for a in range((R_ + 63) // 64) for b in range((C_ + 63) // 64)]
         off += (R_ * C_ + 7) // 8 * 8
-    assert [j[5] for j in jobs] == [0, 1, 0, 1]
+    assert [j[5] for j in jobs] == [0, 1, 0, 1, 0, 0]
+    assert [j[6] for j in jobs] == [0, 0, 2, 0, 2, 1]      # tap-major conv weight: no runs; plain weights: runs of 8
     jb = np.array(jobs, dtype=[("off", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("rt", "<i4"), ("ct", "<i4"), ("tr", "<i4"),
-                               ("pad", "<i4")])
+                               ("runs8", "<i4")])
     jbt = torch.from_numpy(jb.view(np.uint8).copy()).to(cuda)
     tl = torch.tensor(tiles, dtype=torch.int32, device=cuda)
     tb = torch.cat(tables).to(cuda)

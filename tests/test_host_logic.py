@@ -239,6 +239,19 @@ def test_pack_layouts_separate_into_row_and_column_tables():
     h[0, 0] = -1
     assert _separable(h) is None
     assert _separable(torch.full((4, 8), -1, dtype=torch.int64)) is None
+    # the contiguous-run promise of cum_pack2d (runs8): plain [N, K] weights yes, tap-major conv weights no
+    from cleanumamba_amd.network.convstack import _runs8
+    assert _runs8(ro, cl) == 0
+    w = torch.full((6, 24), -1, dtype=torch.int64)
+    w[:5, :16] = 2000 + torch.arange(5 * 16).view(5, 16)
+    r3, c3, _ = _separable(w)
+    assert _runs8(r3, c3) == 2                        # runs of 8 starting at multiples of 4 elements
+    r4, c4, _ = _separable(torch.where(w >= 0, w + 1, w))
+    assert _runs8(r4, c4) == 1                        # same runs, odd start: scalar loads
+    w5 = w.clone()
+    w5[:, 12:16] = -1                                 # a group of 8 that is half padding
+    r5, c5, _ = _separable(w5)
+    assert _runs8(r5, c5) == 0
 
 
 def test_loss_terms_combination_matches_the_chain_of_scalar_ops():

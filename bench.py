@@ -287,7 +287,7 @@ def other_kernels(dev, dt=torch.bfloat16):
 
 def layer_table(net, dev, dt):
     """SURVEY.md 8(d) rows a5 / a12 on the E8 B=16 training shapes: per encoder / decoder layer the forward launches the
-    model runs -- ONE for the first encoder / last decoder layer (csrc/enc0.hip, dec7.hip), else TWO (conv + ReLU,
+    model runs -- ONE for the first two encoder layers / the last decoder layer (csrc/enc0.hip, ench.hip, dec7.hip), else TWO (conv + ReLU,
     1x1 + GLU | 1x1 + GLU, transposed conv + ReLU + skip) -- summed, against the FUSED layer's algorithmic
     traffic s*B*(Cin*Tin + H*Tout) (+ weights; decoder: s*B*(2*H*T + Cout*(2T+2))) and flops 2*B*Tout*(4*Cin*H + 2*H^2).
     The H-channel intermediate and the saved gate pre-activation are real traffic of the two-launch form that the
@@ -309,10 +309,13 @@ def layer_table(net, dev, dt):
             x = (0.5 * torch.randn(gi.R, gi.Cp, device=dev)).to(dt)
 
             fused = i == 0 and cs._enc0_ok(enc[0].weight, enc[2].weight, gi, gm, go, dt)      # what the model runs
+            fused_h = not fused and cs._ench_ok(enc[0].weight, enc[2].weight, gi, gm, go, dt)  # csrc/ench.hip (width 128)
 
             def run():
                 if fused:
                     return cs._enc0_fwd(x, enc[0].weight, enc[0].bias, enc[2].weight, enc[2].bias, gm, go, True)
+                if fused_h:         # training form: hidden activation, sign nibbles and gate stored for the backward
+                    return cs._ench_fwd(x, enc[0].weight, enc[0].bias, enc[2].weight, enc[2].bias, gi, gm, go, True)
                 y1 = cs._conv_relu_fwd(x, enc[0].weight, enc[0].bias, gi, gm)
                 return cs._glu_fwd(y1, enc[2].weight, enc[2].bias, gm, go, True)
             run()
@@ -321,7 +324,7 @@ def layer_table(net, dev, dt):
             Cin, H = gi.C, gm.C
             byt = s * B * (Cin * gi.T + H * go.T) + s * (4 * Cin * H + 2 * H * H)
             fl = 2.0 * B * go.T * (4 * Cin * H + 2 * H * H)
-            rows.append(_layer_row(f"enc{i} {Cin}->{H} T {gi.T}->{go.T}", ms, byt, fl, 1 if fused else 2))
+            rows.append(_layer_row(f"enc{i} {Cin}->{H} T {gi.T}->{go.T}", ms, byt, fl, 1 if (fused or fused_h) else 2))
             del x
         E = len(net.decoder)
         gi = enc_geos[-1][2]

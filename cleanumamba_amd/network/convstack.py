@@ -1199,6 +1199,37 @@ def _enc0_fwd(xbuf, w1, b1, w2, b2, gm, go, save_z):
     return ybuf, z
 
 
+_ENCH_FUSED = os.environ.get("CUM_ENCH_FUSED", "1") != "0"      # "0": the two GEMM launches (A/B timing)
+
+
+def _ench_ok(w1, w2, gi, gm, go, dt):
+    """The width-128 encoder layer (64 -> 128 -> 128: the second layer of E6 / E8) takes the fused forward kernel."""
+    return (_ENCH_FUSED and dt in hip.HALF_TYPES and tuple(w1.shape) == (128, 64, 4) and tuple(w2.shape) == (256, 128, 1)
+            and gi.Cp == 64 and gm.Cp == 128 and go.Cp == 128 and gm.P >= 3)
+
+
+def _ench_fwd(xbuf, w1, b1, w2, b2, gi, gm, go, save_z):
+    """-> (y1 buffer, sign nibbles, output buffer, gate): what _conv_relu_fwd(want_bits) + _glu_fwd produce, in one launch
+    (csrc/ench.hip).  Without a backward to come neither the hidden activation nor the gate is stored."""
+    dt, dev = xbuf.dtype, xbuf.device
+    sh1, sh2 = tuple(w1.shape), tuple(w2.shape)
+    w1p = take(w1, ("conv_fwd", sh1, gi.Cp, 128, 256), lambda: lay_conv_fwd(sh1, gi.Cp, 128, 256), dt)
+    b1p = take(b1, ("vec", 128, 128), lambda: lay_vec(128, 128), torch.float32)
+    w2p = take(w2, ("glu_fwd", sh2, 256, 128), lambda: lay_glu_fwd(sh2, 256, 128), dt)
+    b2p = take(b2, ("glu_vec", 256), lambda: lay_glu_vec(256), torch.float32)
+    ybuf = go.new(dt, dev)
+    y1 = gm.new(dt, dev) if save_z else None
+    bits = torch.empty(gm.R * gm.Cp // 4, dtype=torch.uint8, device=dev) if (save_z and _ENC_BITS and _SIGN_MASK) else None
+    z = torch.empty(go.M, 128, dtype=dt, device=dev) if save_z else None
+    with torch.cuda.device(dev):
+        hip.check(hip.lib().cum_ench_fwd(
+            hip.dtype_code(dt), go.M, go.P, go.T, hip.ptr(xbuf[1:]), gi.R - 1, hip.ptr(w1p), hip.ptr(b1p), hip.ptr(w2p),
+            hip.ptr(b2p), hip.ptr(y1[1:]) if y1 is not None else None, gm.tail,
+            hip.ptr(bits[gm.Cp // 4:]) if bits is not None else None, hip.ptr(ybuf[1:]), go.tail, hip.ptr(z),
+            hip.stream_ptr()))
+    return y1, bits, ybuf, z
+
+
 def _enc0_bwd(dz, xbuf, w1, b1, w2, gm, go, slot_w1, slot_w2):
     """slot_* = (arena buffer, offset): weight / bias gradients of the conv and of the 1x1 in their arena layouts."""
     dt, dev = dz.dtype, dz.device
@@ -1266,6 +1297,8 @@ class EncoderStack(torch.autograd.Function):
             if i == 0 and _enc0_ok(w1, w2, gi, gm, go, xbuf.dtype):
                 y1 = None                      # rebuilt from the input where the backward needs it (csrc/enc0.hip)
                 y, z = _enc0_fwd(xbuf, w1, b1, w2, b2, gm, go, save_z)
+            elif _ench_ok(w1, w2, gi, gm, go, xbuf.dtype):
+                y1, sb, y, z = _ench_fwd(bufs[-1], w1, b1, w2, b2, gi, gm, go, save_z)    # one launch (csrc/ench.hip)
             else:
                 # with a backward to come, the ReLU's sign bits ride along: its gate then reads 1/8 of y1's bytes
                 y1, sb = _conv_relu_fwd(bufs[-1], w1, b1, gi, gm, want_bits=True) if (save_z and _ENC_BITS) else \

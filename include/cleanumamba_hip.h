@@ -423,6 +423,25 @@ int cum_enc0_bwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const v
                  const float *w1, const float *b1, const void *w2p, float *slot_w2, float *slot_w1, float *workspace,
                  void *stream);
 
+/* An encoder layer of width 128, forward, fused:  Conv1d(64 -> 128, k 4, s 2) + ReLU + Conv1d(128 -> 256, 1x1) + GLU of
+ * src/network/CleanUMamba.py:108-113 at channels_H = 64 (the second encoder layer of E6 / E8), 16-bit element types, one
+ * launch instead of cum_gemm_nt (EPI_RELU) + cum_gemm_nt (EPI_GLU); it writes what those two write, so the backward is
+ * theirs (csrc/ench.hip).
+ *   xin      row 1 of the input row buffer [..][64]: output row m reads input rows 2 m .. 2 m + 3; x_rows = rows readable
+ *            from xin (>= 2 M + 2)
+ *   w1p/b1p  conv weight packed [128][256] (column tap * 64 + channel: lay_conv_fwd) and bias [128] f32
+ *   w2p/b2p  1x1 weight packed [256][128] (rows 32 g + i: i < 16 value channel 16 g + i, else gate channel: lay_glu_fwd),
+ *            bias [256] f32 in the same row order
+ *   y1       row 1 of the hidden row buffer [..][128] (ReLU output; the 128 elements before it and y1_tail elements behind
+ *            row M are cleared) or NULL (inference: not stored); bits: its sign nibbles, one byte per four channels,
+ *            32 bytes per row (NULL: not kept)
+ *   out      row 1 of the output row buffer [..][128] (framing cleared as for y1); gate: [M][128] gate pre-activations for
+ *            the backward or NULL
+ *   M rows = clips x pitch; rows with (m mod pitch) >= valid are zero rows of y1 / out. */
+int cum_ench_fwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const void *xin, int64_t x_rows,
+                 const void *w1p, const float *b1p, const void *w2p, const float *b2p, void *y1, int64_t y1_tail,
+                 void *bits, void *out, int64_t out_tail, void *gate, void *stream);
+
 /* The last decoder layer, fused:  Conv1d(64 -> 128, 1x1) + GLU + ConvTranspose1d(64 -> 1, k 4, s 2) of
  * src/network/CleanUMamba.py:121-130 at channels_output = 1, channels_H = 64 (E6 / E8), 16-bit element types.  The GLU
  * output is rebuilt from the layer input wherever it is needed instead of being stored.

@@ -275,6 +275,79 @@ def test_fused_first_encoder_layer(cuda, tin, dtype, monkeypatch):
         assert rel_l2(g_f[k], g_g[k]) < btol, k
 
 
+@pytest.mark.parametrize("tin", [38, 270, 4100])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_width128_encoder_layer_forward(cuda, tin, dtype, monkeypatch):
+    """csrc/ench.hip -- an encoder layer 64 -> 128 -> 128 (Conv1d k4 s2, ReLU, Conv1d 1x1, GLU: the second layer of E6 /
+    E8, src/network/CleanUMamba.py:108-113) as one forward launch -- through EncoderStack: forward and all four parameter
+    gradients (the unchanged backward on what the fused forward saved) against the f64 oracle, against the two-launch
+    route on the same inputs (saved tensors included: hidden activation, sign nibbles, gate), framing rows zero,
+    bit-reproducible, really taken; and the no-backward form (nothing but the output stored)."""
+    from cleanumamba_amd.network import convstack as cs
+    tol, btol = LAYER_TOL[dtype]
+    B, cin, h = 3, 64, 128
+    sd = _layer_params(cin, h, h, seed=17)
+    x = torch.randn(B, cin, tin, generator=torch.Generator().manual_seed(21))
+    tout = (tin - 4) // 2 + 1
+    dout = torch.randn(B, h, tout, generator=torch.Generator().manual_seed(22))
+    ref = {k: (_rounded(v, dtype) if k.endswith("weight") else v.double()).requires_grad_(True)
+           for k, v in sd.items() if k.startswith("encoder")}
+    yr = R.encoder_layer(ref, 0, _rounded(x, dtype), store=_store(dtype))
+    (yr * dout.double()).sum().backward()
+    gi, gm, go = cs.Geo(B, tin, cin), cs.Geo(B, tout, h), cs.Geo(B, tout, h)
+    keys = ["encoder.0.0.weight", "encoder.0.0.bias", "encoder.0.2.weight", "encoder.0.2.bias"]
+    calls, saved = [], {}
+    real_fwd = cs._ench_fwd
+
+    def spy(*a, **k):
+        out = real_fwd(*a, **k)
+        calls.append("fwd")
+        saved["fused"] = out
+        return out
+    monkeypatch.setattr(cs, "_ench_fwd", spy)
+    real_conv, real_glu = cs._conv_relu_fwd, cs._glu_fwd
+    monkeypatch.setattr(cs, "_conv_relu_fwd", lambda *a, **k: saved.setdefault("conv", real_conv(*a, **k)))
+    monkeypatch.setattr(cs, "_glu_fwd", lambda *a, **k: saved.setdefault("glu", real_glu(*a, **k)))
+
+    def run(fused, save_z=True):
+        monkeypatch.setattr(cs, "_ENCH_FUSED", fused)
+        dev = {k: sd[k].to(cuda).requires_grad_(True) for k in keys}
+        buf = cs.to_rows(x.to(cuda), gi, dtype)
+        (ybuf,) = cs.EncoderStack.apply(buf, [(gi, gm, go)], save_z, *[dev[k] for k in keys])
+        y = cs.from_rows(ybuf, go).float()
+        rows = go.rows(ybuf)
+        assert float(rows[:, go.T:].abs().max()) == 0 and float(ybuf[0].abs().max()) == 0     # framing rows stay zero
+        assert float(ybuf[1 + go.M:].abs().max()) == 0
+        if not save_z:
+            return y.detach(), None
+        (y * dout.to(cuda)).sum().backward()
+        return y.detach(), {k: dev[k].grad.detach() for k in keys}
+    y_f, g_f = run(True)
+    assert calls == ["fwd"]
+    y_f2, g_f2 = run(True)
+    assert torch.equal(y_f, y_f2) and all(torch.equal(g_f[k], g_f2[k]) for k in keys)              # deterministic
+    y_g, g_g = run(False)
+    assert calls == ["fwd"] * 2                                                                   # two-launch route: not called
+    # what the fused forward saved for the backward is what the two launches save
+    y1_f, bits_f, _, z_f = saved["fused"]
+    (y1_g, bits_g), (_, z_g) = saved["conv"], saved["glu"]
+    assert float(y1_f[0].abs().max()) == 0 and float(y1_f[1 + gm.M:].abs().max()) == 0
+    assert rel_l2(y1_f.float(), y1_g.float()) < tol
+    live = slice(gm.Cp // 4, (1 + gm.M) * gm.Cp // 4)
+    same = (bits_f[live] == bits_g[live]).float().mean()
+    assert float(same) > 0.999                        # (a sign can differ where the two summation orders round across 0)
+    assert rel_l2(z_f.float(), z_g.float()) < tol
+    tag = f"ench_fused[{tin}-{dtype}]"
+    assert record(tag + ".fwd", rel_l2(y_f, yr)) < tol
+    assert record(tag + ".fwd_vs_generic", rel_l2(y_f, y_g)) < tol
+    for k in keys:
+        assert record(tag + ".d" + k, rel_l2(g_f[k], ref[k].grad)) < btol, k
+        assert rel_l2(g_f[k], g_g[k]) < btol, k
+    y_n, _ = run(True, save_z=False)                  # inference form: hidden activation / nibbles / gate not stored
+    assert saved["fused"][0] is None and saved["fused"][1] is None and saved["fused"][3] is None
+    assert torch.equal(y_n, y_f)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_index_free_repack_equals_index_gather(cuda, dtype):
     """cum_pack2d (row / column offset tables, LDS transpose, contiguous-run fast path) against cum_gather over the same

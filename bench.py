@@ -287,7 +287,7 @@ def other_kernels(dev, dt=torch.bfloat16):
 
 def layer_table(net, dev, dt):
     """SURVEY.md 8(d) rows a5 / a12 on the E8 B=16 training shapes: per encoder / decoder layer the forward launches the
-    model runs -- ONE for the first two encoder layers / the last decoder layer (csrc/enc0.hip, ench.hip, dec7.hip), else TWO (conv + ReLU,
+    model runs -- ONE for the first two encoder layers / the last two decoder layers (csrc/enc0.hip, ench.hip, dech.hip, dec7.hip), else TWO (conv + ReLU,
     1x1 + GLU | 1x1 + GLU, transposed conv + ReLU + skip) -- summed, against the FUSED layer's algorithmic
     traffic s*B*(Cin*Tin + H*Tout) (+ weights; decoder: s*B*(2*H*T + Cout*(2T+2))) and flops 2*B*Tout*(4*Cin*H + 2*H^2).
     The H-channel intermediate and the saved gate pre-activation are real traffic of the two-launch form that the
@@ -335,10 +335,13 @@ def layer_table(net, dev, dt):
             skip = (0.5 * torch.randn(go.R, go.Cp, device=dev)).to(dt) if j < E - 1 else None
 
             fused = j == E - 1 and cs._dec7_ok(dec[0].weight, dec[2].weight, gi, gg, go, dt)
+            fused_h = not fused and cs._dech_ok(dec[0].weight, dec[2].weight, skip, j < E - 1, gi, gg, go, dt)   # csrc/dech.hip
 
             def run():
                 if fused:
                     return cs._dec7_fwd(u, dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, gi, go)
+                if fused_h:         # training form: GLU output, gate and sign nibbles stored for the backward
+                    return cs._dech_fwd(u, dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, skip, gi, gg, go, True)
                 g, _ = cs._glu_fwd(u, dec[0].weight, dec[0].bias, gi, gg, True)
                 return cs._convt_fwd(g, dec[2].weight, dec[2].bias, skip, gg, go, j < E - 1)
             run()
@@ -347,7 +350,7 @@ def layer_table(net, dev, dt):
             H, Cout = gg.C, go.C
             byt = s * B * (H * gi.T + Cout * go.T * (2 if skip is not None else 1)) + s * (2 * H * H + 4 * H * Cout)
             fl = 2.0 * B * gi.T * (2 * H * H + 4 * H * Cout)
-            rows.append(_layer_row(f"dec{j} {H}->{Cout} T {gi.T}->{go.T}", ms, byt, fl, 1 if fused else 2))
+            rows.append(_layer_row(f"dec{j} {H}->{Cout} T {gi.T}->{go.T}", ms, byt, fl, 1 if (fused or fused_h) else 2))
             gi = go
             del u, skip
     return rows

@@ -109,6 +109,7 @@ SIGNATURES = {
     "cum_stft_loss_bwd_packed": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P, _P, _P, _P]),
     "cum_enc0_fwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P, _P]),
     "cum_ench_fwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P, _P, c_i64, _P, _P]),
+    "cum_dech_fwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, c_i64, _P, _P]),
     "cum_enc0_bwd_workgroups": (c_i32, [c_i64]),
     "cum_enc0_bwd_workspace_elems": (c_i64, [c_i64]),
     "cum_enc0_bwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -1230,6 +1230,43 @@ def _ench_fwd(xbuf, w1, b1, w2, b2, gi, gm, go, save_z):
     return y1, bits, ybuf, z
 
 
+_DECH_FUSED = os.environ.get("CUM_DECH_FUSED", "1") != "0"      # "0": the two GEMM launches (A/B timing)
+
+
+def _dech_ok(w1, wt, skip, relu, gi, gg, go, dt):
+    """The width-128 decoder layer (128 -> 128 -> 64, ReLU, skip: the second-to-last layer of E6 / E8) takes the fused
+    forward kernel."""
+    return (_DECH_FUSED and _SIGN_MASK and relu and skip is not None and dt in hip.HALF_TYPES
+            and tuple(w1.shape) == (256, 128, 1) and tuple(wt.shape) == (128, 64, 4)
+            and gi.Cp == 128 and gg.Cp == 128 and go.Cp == 64 and gg.P >= 3)
+
+
+def _dech_fwd(ubuf, w1, b1, wt, bt, skip, gi, gg, go, save_z):
+    """-> (g buffer, gate, output buffer, sign nibbles): what _glu_fwd + _convt_fwd produce, in one launch
+    (csrc/dech.hip).  Without a backward to come neither g nor the gate nor the nibbles are stored."""
+    dt, dev = ubuf.dtype, ubuf.device
+    sh1, sht = tuple(w1.shape), tuple(wt.shape)
+    w1p = take(w1, ("glu_fwd", sh1, 256, 128), lambda: lay_glu_fwd(sh1, 256, 128), dt)
+    b1p = take(b1, ("glu_vec", 256), lambda: lay_glu_vec(256), torch.float32)
+    wtp = take(wt, ("convt_fwd", sht, gg.Cp, go.Cp, 128, 256), lambda: lay_convt_fwd(sht, gg.Cp, go.Cp, 128, 256), dt)
+
+    def bias_layout():
+        out = torch.zeros(128, dtype=torch.int64)
+        out.view(2, 64)[:, :64] = _ids((64,))
+        return out
+    btp = take(bt, ("convt_vec", 64, go.Cp, 128), bias_layout, torch.float32)
+    ybuf = go.new(dt, dev)
+    g = gg.new(dt, dev) if save_z else None
+    z = torch.empty(gg.M, 128, dtype=dt, device=dev) if save_z else None
+    act = torch.empty(go.R * go.Cp // 4, dtype=torch.uint8, device=dev) if save_z else None
+    with torch.cuda.device(dev):
+        hip.check(hip.lib().cum_dech_fwd(
+            hip.dtype_code(dt), gg.M, gg.P, gg.T, hip.ptr(ubuf), gi.R, hip.ptr(w1p), hip.ptr(b1p), hip.ptr(wtp),
+            hip.ptr(btp), hip.ptr(skip[1:]), hip.ptr(g), gg.tail, hip.ptr(z), hip.ptr(ybuf[1:]), go.tail,
+            hip.ptr(act[go.Cp // 4:]) if act is not None else None, hip.stream_ptr()))
+    return g, z, ybuf, act
+
+
 def _enc0_bwd(dz, xbuf, w1, b1, w2, gm, go, slot_w1, slot_w2):
     """slot_* = (arena buffer, offset): weight / bias gradients of the conv and of the 1x1 in their arena layouts."""
     dt, dev = dz.dtype, dz.device
@@ -1459,8 +1496,11 @@ class DecoderStack(torch.autograd.Function):
                 acts.append(None)
                 fused_last = True
                 continue
-            g, z = _glu_fwd(us[-1], w1, b1, gi, gg, save_z)
-            y, act = _convt_fwd(g, wt, bt, skips[j], gg, go, relu)
+            if _dech_ok(w1, wt, skips[j], relu, gi, gg, go, ubuf.dtype):
+                g, z, y, act = _dech_fwd(us[-1], w1, b1, wt, bt, skips[j], gi, gg, go, save_z)   # one launch (csrc/dech.hip)
+            else:
+                g, z = _glu_fwd(us[-1], w1, b1, gi, gg, save_z)
+                y, act = _convt_fwd(g, wt, bt, skips[j], gg, go, relu)
             us.append(y)
             gs.append(g)
             zs.append(z)

@@ -442,6 +442,25 @@ int cum_ench_fwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const v
                  const void *w1p, const float *b1p, const void *w2p, const float *b2p, void *y1, int64_t y1_tail,
                  void *bits, void *out, int64_t out_tail, void *gate, void *stream);
 
+/* A decoder layer of width 128, forward, fused:  Conv1d(128 -> 256, 1x1) + GLU + ConvTranspose1d(128 -> 64, k 4, s 2) +
+ * ReLU (+ the next layer's skip connection) of src/network/CleanUMamba.py:121-130, 313-316 at channels_H = 64 (the
+ * second-to-last decoder layer of E6 / E8), 16-bit element types, one launch instead of cum_gemm_nt (EPI_GLU) +
+ * cum_gemm_nt (EPI_RELU with residual and sign nibbles); it writes what those two write (csrc/dech.hip).
+ *   u        row 0 (the leading zero row) of the input row buffer [..][128]; u_rows = rows readable from it
+ *   w1p/b1p  1x1 weight packed [256][128] (lay_glu_fwd) and bias [256] f32 in the same row order
+ *   wtp/btp  transposed-conv weight packed [128 = (output-row parity, 64 channels)][256 = (row m - 1 | row m, 128
+ *            channels)] (lay_convt_fwd) and bias [128] f32 (the 64 biases twice)
+ *   skip     row 1 of the skip row buffer [..][64] (added after the ReLU) or NULL
+ *   g        row 0 of the GLU-output row buffer [..][128] (row 0 and g_tail elements behind row M are cleared) with its gate
+ *            pre-activations gate [M][128], or both NULL (inference: not stored)
+ *   out      row 1 of the output row buffer [..][64] (GEMM row m = output rows 2 m, 2 m + 1; the 64 elements before it and
+ *            out_tail elements behind output row 2 M are cleared); bits: sign nibbles of the ReLU, 32 bytes per GEMM row
+ *            (NULL: not kept)
+ *   M input rows = clips x pitch; data row d is real iff (d mod pitch) < valid. */
+int cum_dech_fwd(int32_t dtype, int64_t M, int32_t pitch, int32_t valid, const void *u, int64_t u_rows,
+                 const void *w1p, const float *b1p, const void *wtp, const float *btp, const void *skip, void *g,
+                 int64_t g_tail, void *gate, void *out, int64_t out_tail, void *bits, void *stream);
+
 /* The last decoder layer, fused:  Conv1d(64 -> 128, 1x1) + GLU + ConvTranspose1d(64 -> 1, k 4, s 2) of
  * src/network/CleanUMamba.py:121-130 at channels_output = 1, channels_H = 64 (E6 / E8), 16-bit element types.  The GLU
  * output is rebuilt from the layer input wherever it is needed instead of being stored.

@@ -348,6 +348,87 @@ def test_fused_width128_encoder_layer_forward(cuda, tin, dtype, monkeypatch):
     assert torch.equal(y_n, y_f)
 
 
+@pytest.mark.parametrize("t", [15, 127, 1030])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_width128_decoder_layer_forward(cuda, t, dtype, monkeypatch):
+    """csrc/dech.hip -- a decoder layer 128 -> 128 -> 64 (Conv1d 1x1, GLU, ConvTranspose1d k4 s2, ReLU, + skip: the
+    second-to-last layer of E6 / E8, src/network/CleanUMamba.py:121-130, 313-316) as one forward launch -- as layer 0 of a
+    two-layer DecoderStack (layer 1: the fused last layer): the layer's output against the f64 oracle and against the
+    two-launch route, every tensor it saves for the backward (GLU output, gate, sign nibbles) against what the two
+    launches save, every gradient of the stack (the unchanged backward) against the two-launch route and the f64 chain,
+    framing rows zero, bit-reproducible, really taken; and the no-backward form."""
+    from cleanumamba_amd.network import convstack as cs
+    tol, btol = LAYER_TOL[dtype]
+    B, h0, h1 = 3, 128, 64
+    sd = {k: v for k, v in _layer_params(h0, h0, h1, seed=31).items() if k.startswith("decoder")}
+    sd.update({k.replace("decoder.0", "decoder.1"): v for k, v in _layer_params(h1, h1, 1, seed=32).items() if k.startswith("decoder")})
+    keys = [f"decoder.{j}.{i}.{n}" for j in range(2) for i in (0, 2) for n in ("weight", "bias")]
+    t1, t2 = 2 * t + 2, 2 * (2 * t + 2) + 2
+    gen = torch.Generator().manual_seed(33)
+    x, skip, dout = torch.randn(B, h0, t, generator=gen), torch.randn(B, h1, t1, generator=gen), torch.randn(B, 1, t2, generator=gen)
+    g0 = (cs.Geo(B, t, h0), cs.Geo(B, t, h0), cs.Geo(B, t1, h1))
+    g1 = (cs.Geo(B, t1, h1), cs.Geo(B, t1, h1), cs.Geo(B, t2, 1))
+    calls, saved = [], {}
+    real_fwd, real_glu, real_convt = cs._dech_fwd, cs._glu_fwd, cs._convt_fwd
+
+    def spy(*a, **k):
+        out = real_fwd(*a, **k)
+        calls.append("fwd")
+        saved["fused"] = out
+        return out
+    monkeypatch.setattr(cs, "_dech_fwd", spy)
+    monkeypatch.setattr(cs, "_glu_fwd", lambda *a, **k: saved.setdefault("glu", real_glu(*a, **k)))
+    monkeypatch.setattr(cs, "_convt_fwd", lambda *a, **k: saved.setdefault("convt", real_convt(*a, **k)))
+
+    def run(fused, save_z=True):
+        monkeypatch.setattr(cs, "_DECH_FUSED", fused)
+        dev = {k: sd[k].to(cuda).requires_grad_(True) for k in keys}
+        xd, sk = x.to(cuda).requires_grad_(True), skip.to(cuda).requires_grad_(True)
+        ybuf = cs.DecoderStack.apply(cs.to_rows(xd, g0[0], dtype), [g0, g1], save_z, 1, cs.to_rows(sk, g0[2], dtype),
+                                     *[dev[k] for k in keys])
+        y = cs.from_rows(ybuf, g1[2]).float()
+        if not save_z:
+            return y.detach(), None
+        (y * dout.to(cuda)).sum().backward()
+        return y.detach(), {**{k: dev[k].grad.detach() for k in keys}, "x": xd.grad.detach(), "skip": sk.grad.detach()}
+    y_f, g_f = run(True)
+    assert calls == ["fwd"]
+    y_f2, g_f2 = run(True)
+    assert torch.equal(y_f, y_f2) and all(torch.equal(g_f[k], g_f2[k]) for k in g_f)              # deterministic
+    y_g, g_g = run(False)
+    assert calls == ["fwd"] * 2                                                                   # two-launch route: not called
+    gg, go = g0[1], g0[2]
+    gb_f, z_f, u1_f, act_f = saved["fused"]
+    (gb_g, z_g), (u1_g, act_g) = saved["glu"], saved["convt"]
+    # framing of the two row buffers the fused kernel writes
+    assert float(gb_f[0].abs().max()) == 0 and float(gb_f[1 + gg.M:].abs().max()) == 0
+    assert float(u1_f[0].abs().max()) == 0 and float(u1_f[1 + go.M:].abs().max()) == 0
+    assert float(go.rows(u1_f)[:, go.T:].abs().max()) == 0 and float(gg.rows(gb_f)[:, gg.T:].abs().max()) == 0
+    assert rel_l2(gb_f.float(), gb_g.float()) < tol and rel_l2(z_f.float(), z_g.float()) < tol
+    assert rel_l2(u1_f.float(), u1_g.float()) < tol
+    live = slice(go.Cp // 4, (1 + go.M) * go.Cp // 4)
+    assert float((act_f[live] == act_g[live]).float().mean()) > 0.999     # (a sign can differ where summation orders round across 0)
+    tag = f"dech_fused[{t}-{dtype}]"
+    assert record(tag + ".fwd_vs_generic", rel_l2(y_f, y_g)) < tol
+    for k in g_f:
+        assert record(tag + ".vs_generic.d" + k, rel_l2(g_f[k], g_g[k])) < btol, k
+    # f64 oracle: the layer's own output, and the chain of both layers for the gradients
+    ref = {k: (_rounded(v, dtype) if k.endswith("weight") else v.double()).requires_grad_(True) for k, v in sd.items()}
+    xr, sr = _rounded(x, dtype).requires_grad_(True), _rounded(skip, dtype).requires_grad_(True)
+    u1r = R.decoder_layer(ref, 0, xr, last=False, store=_store(dtype)) + sr
+    assert record(tag + ".fwd", rel_l2(cs.from_rows(u1_f, go).float(), u1r)) < tol
+    yr = R.decoder_layer(ref, 1, u1r, last=True, store=_store(dtype))
+    (yr * dout.double()).sum().backward()
+    assert record(tag + ".chain_fwd", rel_l2(y_f, yr)) < 2 * tol
+    assert record(tag + ".dx", rel_l2(g_f["x"], xr.grad)) < 2 * btol
+    assert record(tag + ".dskip", rel_l2(g_f["skip"], sr.grad)) < 2 * btol
+    for k in keys[:4]:
+        assert record(tag + ".d" + k, rel_l2(g_f[k], ref[k].grad)) < 2 * btol, k
+    y_n, _ = run(True, save_z=False)                  # inference form: GLU output / gate / nibbles not stored
+    assert saved["fused"][0] is None and saved["fused"][1] is None and saved["fused"][3] is None
+    assert torch.equal(y_n, y_f)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_index_free_repack_equals_index_gather(cuda, dtype):
     """cum_pack2d (row / column offset tables, LDS transpose, contiguous-run fast path) against cum_gather over the same

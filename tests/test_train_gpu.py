@@ -166,6 +166,53 @@ def test_benched_configuration_graph_replay_equals_eager(cuda):
     assert max(abs(losses[0][i] - losses[1][i]) for i in fin) < 1e-4 * max(abs(l) for l in (losses[1][i] for i in fin))
 
 
+def test_benched_configuration_at_its_own_batch(cuda):
+    """BASELINE config 3 at ITS batch: E8, B = 16 clips of 10 s, fp16 autocast with device-side loss scaling -- the
+    dispatch map of this batch (256 x 256 ping-pong GEMMs on the deep layers, the fused width-128 layers, the 8-wave scan
+    kernels; per-call parity: test_dispatch_map_gpu.py) run as a whole step: five steps replayed from the hipGraph against
+    the same five steps run eagerly (same loss scale history, same skipped steps, parameters equal to 1e-5), losses
+    finite and falling into place, and the fused layers really taken."""
+    from cleanumamba_amd.network import Net
+    from cleanumamba_amd.network import convstack as cs
+    from cleanumamba_amd.training.train_step import TrainStep
+    taken = {"ench": 0, "dech": 0}
+    real_e, real_d = cs._ench_fwd, cs._dech_fwd
+
+    def spy_e(*a, **k):
+        taken["ench"] += 1
+        return real_e(*a, **k)
+
+    def spy_d(*a, **k):
+        taken["dech"] += 1
+        return real_d(*a, **k)
+    cs._ench_fwd, cs._dech_fwd = spy_e, spy_d
+    try:
+        nets, steps = [], []
+        for graph in (True, False):
+            torch.manual_seed(0)
+            nets.append(Net("CleanUMamba", E8).to(cuda).train())
+            steps.append(TrainStep(nets[-1], autocast_dtype=torch.float16, use_graph=graph))
+        losses, skipped = [[], []], [[], []]
+        for it in range(5):
+            clean, noisy = synth.waveform(16, 160000, seed=140 + it)
+            clean, noisy = clean.to(cuda), noisy.to(cuda)
+            for k in range(2):
+                loss, gn = steps[k](clean, noisy)
+                losses[k].append(float(loss))
+                skipped[k].append(float(steps[k].optimizer.state_vec[9]))
+    finally:
+        cs._ench_fwd, cs._dech_fwd = real_e, real_d
+    assert steps[0].graph_status == "captured", steps[0].graph_status
+    assert taken["ench"] >= 5 and taken["dech"] >= 5, taken          # eager steps + the capture call them
+    assert skipped[0] == skipped[1], skipped
+    assert float(steps[0].optimizer.state_vec[5]) >= 2                # real optimizer steps were taken
+    assert float(steps[0].optimizer.state_vec[3]) == float(steps[1].optimizer.state_vec[3])     # same loss scale
+    worst = max(rel_l2(pa, pb) for pa, pb in zip(nets[0].parameters(), nets[1].parameters()))
+    assert record("graph_vs_eager_e8_f16_b16", worst) < 1e-5
+    assert all(l == l for l in losses[0])
+    assert max(abs(a - b) for a, b in zip(losses[0], losses[1])) < 1e-4 * max(abs(l) for l in losses[1])
+
+
 @pytest.mark.parametrize("dtype", [None, torch.float16])
 def test_trained_weights_reach_every_inference_cache(cuda, dtype):
     """FlatAdam (eager and replayed) moves the parameters through raw pointers; every no-grad cache keyed on a

@@ -50,9 +50,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   constexpr int BCK = LDSBC ? (TB * NP + NT - 1) / NT : 1;
   __shared__ __attribute__((aligned(16))) float s_B[LDSBC ? TB : 1][LDSBC ? NP : 4];
   __shared__ __attribute__((aligned(16))) float s_C[LDSBC ? TB : 1][LDSBC ? NP : 4];
-  __shared__ float s_dt[TB][64];
-  __shared__ float s_du[TB][64];
-  __shared__ float s_dy[TB][64];
+  __shared__ __attribute__((aligned(16))) float4 s_op[TB][64];   // per (t, d): {delta', delta' u, dy, -}: one 16-byte read per step
   __shared__ float s_p1[NW][SUB][64];  // sum_n g * A'   (-> ddelta)
   __shared__ float s_p2[NW][SUB][64];  // sum_n dx * B   (-> ddelta, du)
   __shared__ float s_y[NW][SUB][64];   // sum_n C * x_t  (-> dz)
@@ -166,11 +164,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       dtv = ok ? dtv : 0.f;
       float dy = ok ? dov : 0.f;
       if (has_z) dy *= zv * sigmoidf_(zv);
-      if (tl < TB) {
-        s_dt[tl][lane] = dtv;
-        s_du[tl][lane] = ok ? dtv * uv : 0.f;
-        s_dy[tl][lane] = ok ? dy : 0.f;
-      }
+      if (tl < TB) s_op[tl][lane] = make_float4(dtv, ok ? dtv * uv : 0.f, ok ? dy : 0.f, 0.f);
       eu[k] = uv; ez[k] = zv; edo[k] = dov; edt[k] = dtv; esg[k] = sg;
     }
     if constexpr (LDSBC) {
@@ -217,9 +211,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
           o.cv[j] = f2{cs[2 * j], cs[2 * j + 1]};
         }
       }
-      o.dt = s_dt[tl][lane];
-      o.du = s_du[tl][lane];
-      o.dy = s_dy[tl][lane];
+      const float4 op = s_op[tl][lane];
+      o.dt = op.x; o.du = op.y; o.dy = op.z;
     };
     // one recomputed forward step (state only)
     auto fwd_step = [&](f2 (&x)[NP2], const StepOps &o, int aslot = -1) {
@@ -355,7 +348,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       finish_half(0);
       PROBE(10);
     }
-    // The next chunk's phase A writes only s_dt/s_du/s_dy (their readers finished before
+    // The next chunk's phase A writes only s_op / s_B / s_C (their readers finished before
     // the last barrier) and its first rev_step runs after that phase's barrier, which
     // every wave reaches only after this finish_half.
   }

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   __shared__ __attribute__((aligned(16))) float s_B[LDSBC ? TB : 1][LDSBC ? NP : 4];
   __shared__ __attribute__((aligned(16))) float s_C[LDSBC ? TB : 1][LDSBC ? NP : 4];
   __shared__ __attribute__((aligned(16))) float4 s_op[TB][64];   // per (t, d): {delta', delta' u, dy, -}: one 16-byte read per step
-  __shared__ float s_p1[NW][SUB][64];  // sum_n g * A'   (-> ddelta)
-  __shared__ float s_p2[NW][SUB][64];  // sum_n dx * B   (-> ddelta, du)
+  // per wave, step slot and channel: {sum_n g * A' (-> ddelta), sum_n dx * B (-> ddelta, du)}: one 8-byte store per step
+  __shared__ __attribute__((aligned(8))) float2 s_p12[NW][SUB][64];
   __shared__ float s_y[NW][SUB][64];   // sum_n C * x_t  (-> dz)
   // decay factors a_t = exp2(dt * A') of the first NA steps of the half being processed: written by the recomputed
   // forward steps, read back by the reverse steps instead of a second v_exp_f32 (each lane reads what it wrote)
@@ -248,8 +248,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         p1 = gg * Ap[j] + p1;
         p2 = dx * o.bv[j] + p2;
       }
-      s_p1[w][slot][lane] = p1.x + p1.y;
-      s_p2[w][slot][lane] = p2.x + p2.y;
+      s_p12[w][slot][lane] = make_float2(p1.x + p1.y, p2.x + p2.y);
       s_y[w][slot][lane] = yp.x + yp.y;
       const float tot = wave_reduce_scatter8x2q(dBp, dCp);
       if (tl <= tlast && st_on) cBC[tl * N + qoff] = tot;   // per-lane slab (dB or dC) + uniform row + per-lane column
@@ -266,8 +265,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
           float q1 = 0.f, q2 = 0.f, y = Dd * eu[k];
 #pragma unroll
           for (int ww = 0; ww < NW; ++ww) {
-            q1 += s_p1[ww][slot][lane];
-            q2 += s_p2[ww][slot][lane];
+            const float2 q = s_p12[ww][slot][lane];
+            q1 += q.x;
+            q2 += q.y;
             y += s_y[ww][slot][lane];
           }
           const float zv = ez[k], dov = edo[k];
@@ -360,15 +360,15 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       if (j < nvalid) wa[j] = dAacc[j / 2][j % 2];
   }
   __syncthreads();
-  s_p1[w][0][lane] = accD;
-  s_p2[w][0][lane] = accBias;
+  s_p12[w][0][lane] = make_float2(accD, accBias);
   __syncthreads();
   if (w == 0 && dok) {
     float a = 0.f, c2 = 0.f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) {
-      a += s_p1[ww][0][lane];
-      c2 += s_p2[ww][0][lane];
+      const float2 q = s_p12[ww][0][lane];
+      a += q.x;
+      c2 += q.y;
     }
     p.ws_dD[(int64_t)b * Dm + d] = a;
     p.ws_dbias[(int64_t)b * Dm + d] = c2;

@@ -40,7 +40,9 @@ constexpr int NA = 5;         // reverse steps per 8-step half that take their d
 // ds_read_b128 per step): no SGPR pressure -- the scalar variants keep 256 B/C values per chunk in flight and spend
 // ~20 % of their VALU instructions moving spilled SGPRs through VGPR lanes.
 // FULL: dstate == NW * NS known at compile time (every wave owns NS valid states, slab rows are 8-byte aligned pairs).
-template <int NW, int BC, typename TIO, bool FULL>
+// YIN: the forward kept y before the gate (ScanParams::ypre_in): the reverse step then neither rebuilds sum_n C x_t (one
+// packed fma per state pair, one add and one LDS store per step) nor does phase C sum it over the waves.
+template <int NW, int BC, typename TIO, bool FULL, bool YIN = false>
 __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   constexpr bool FAST = BC == 1;
   constexpr bool LDSBC = BC == 2;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   __shared__ __attribute__((aligned(16))) float4 s_op[TB][64];   // per (t, d): {delta', delta' u, dy, -}: one 16-byte read per step
   // per wave, step slot and channel: {sum_n g * A' (-> ddelta), sum_n dx * B (-> ddelta, du)}: one 8-byte store per step
   __shared__ __attribute__((aligned(8))) float2 s_p12[NW][SUB][64];
-  __shared__ float s_y[NW][SUB][64];   // sum_n C * x_t  (-> dz)
+  __shared__ float s_y[YIN ? 1 : NW][YIN ? 1 : SUB][64];   // sum_n C * x_t  (-> dz)
   // decay factors a_t = exp2(dt * A') of the first NA steps of the half being processed: written by the recomputed
   // forward steps, read back by the reverse steps instead of a second v_exp_f32 (each lane reads what it wrote)
   __shared__ __attribute__((aligned(16))) float4 s_a[NA][2][NT];
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   const bool has_z = p.z != nullptr;
   const TIO *zp = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb + dc * p.s.z_sd : up;
   const TIO *dop = static_cast<const TIO *>(p.dout) + b * p.s.o_sb + dc * p.s.o_sd;
+  const TIO *yip = YIN ? static_cast<const TIO *>(p.ypre_in) + b * p.s.o_sb + dc * p.s.o_sd : dop;
   TIO *dup = static_cast<TIO *>(p.du) + b * p.gs.du_sb + dc * p.gs.du_sd;
   TIO *ddtp = static_cast<TIO *>(p.ddelta) + b * p.gs.dd_sb + dc * p.gs.dd_sd;
   TIO *dzp = has_z ? static_cast<TIO *>(p.dz) + b * p.gs.dz_sb + dc * p.gs.dz_sd : nullptr;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   float accD = 0.f, accBias = 0.f;
 
   // raw (t, d) rows of the chunk about to be processed; fetched one chunk ahead
-  float ru[K], rdl[K], rz[K], rdo[K], rb[BCK], rc[BCK];
+  float ru[K], rdl[K], rz[K], rdo[K], ry[K], rb[BCK], rc[BCK];
   const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
   auto load_rows = [&](int c) {
     const int t0 = c * TB, tlast = L - 1 - t0;
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       rdl[k] = (float)dtp[tc * dt_sl];
       rz[k] = (float)zp[tc * z_sl];
       rdo[k] = (float)dop[tc * o_sl];
+      if constexpr (YIN) ry[k] = (float)yip[tc * o_sl];
     }
   };
   load_rows(nchunks - 1);
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     f2 x0[NP2], x8[NP2];   // x8: state entering the second half (local step 8), read only if the chunk reaches it
     ckpt_load(p.ckpt_in, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, dc), x0);
     ckpt_load(p.ckpt_in, ckpt_slot(b, nchunks, c, tlast >= SUB ? 1 : 0, NW, w, Dm, dc), x8);
-    float eu[K], ez[K], edo[K], edt[K], esg[K];
+    float eu[K], ez[K], edo[K], edt[K], esg[K], ey[K];
     // ---- phase A: per-(t, d) quantities, once, into LDS
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       if (has_z) dy *= zv * sigmoidf_(zv);
       if (tl < TB) s_op[tl][lane] = make_float4(dtv, ok ? dtv * uv : 0.f, ok ? dy : 0.f, 0.f);
       eu[k] = uv; ez[k] = zv; edo[k] = dov; edt[k] = dtv; esg[k] = sg;
+      if constexpr (YIN) ey[k] = ry[k];
     }
     if constexpr (LDSBC) {
 #pragma unroll
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         // the state after this step is the saved state before the next one (recomputed only for the half's last step)
         const f2 xt = slot + 1 < SUB ? xs[slot + 1][j] : a * xp[j] + du * o.bv[j];
         const f2 dx = o.cv[j] * dy + dxc[j];
-        yp = o.cv[j] * xt + yp;
+        if constexpr (!YIN) yp = o.cv[j] * xt + yp;
         dCp[j] = dy * xt;
         dBp[j] = dx * du;
         dxc[j] = a * dx;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         p2 = dx * o.bv[j] + p2;
       }
       s_p12[w][slot][lane] = make_float2(p1.x + p1.y, p2.x + p2.y);
-      s_y[w][slot][lane] = yp.x + yp.y;
+      if constexpr (!YIN) s_y[w][slot][lane] = yp.x + yp.y;
       const float tot = wave_reduce_scatter8x2q(dBp, dCp);
       if (tl <= tlast && st_on) cBC[tl * N + qoff] = tot;   // per-lane slab (dB or dC) + uniform row + per-lane column
       __builtin_amdgcn_sched_barrier(0);
@@ -262,13 +267,13 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         const int slot = tl - half * SUB;
         if (tl < TB && slot >= 0 && slot < SUB && tl <= tlast && dok) {
           const int t = t0 + tl;
-          float q1 = 0.f, q2 = 0.f, y = Dd * eu[k];
+          float q1 = 0.f, q2 = 0.f, y = YIN ? ey[k] : Dd * eu[k];
 #pragma unroll
           for (int ww = 0; ww < NW; ++ww) {
             const float2 q = s_p12[ww][slot][lane];
             q1 += q.x;
             q2 += q.y;
-            y += s_y[ww][slot][lane];
+            if constexpr (!YIN) y += s_y[ww][slot][lane];
           }
           const float zv = ez[k], dov = edo[k];
           float dy = dov;
@@ -451,7 +456,9 @@ static int launch_bwd_io(const ScanParams &p, hipStream_t st) {
     return CUM_OK;
   }
 #endif
-  if (p.s.dstate == NS * NW)
+  if (p.s.dstate == NS * NW && p.ypre_in && p.z)     // (y only enters dz; shapes with a ragged last wave rebuild it)
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO, true, true>), grid, block, 0, st, p);
+  else if (p.s.dstate == NS * NW)
     hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO, true>), grid, block, 0, st, p);
   else
     hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO, false>), grid, block, 0, st, p);
@@ -478,7 +485,7 @@ extern "C" int64_t cum_scan_bwd_workspace_elems(int32_t batch, int32_t dim, int3
 extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs, const void *u,
                                       const void *delta, const float *A,
                                       const float *Bm, const float *Cm, const float *D, const void *z,
-                                      const float *delta_bias, const void *dout, const float *ckpt, void *du,
+                                      const float *delta_bias, const void *dout, const void *y_pre, const float *ckpt, void *du,
                                       void *ddelta, float *dA, float *dB, float *dC, float *dD, void *dz,
                                       float *ddelta_bias, float *workspace, void *stream) {
   if (int rc = scan_check_shape(s)) return rc;
@@ -503,7 +510,7 @@ extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_gr
   p.s = *s;
   p.gs = *gs;
   p.u = u; p.delta = delta; p.A = A; p.Bm = Bm; p.Cm = Cm; p.D = D; p.z = z; p.bias = delta_bias;
-  p.dout = dout; p.ckpt_in = ckpt; p.du = du; p.ddelta = ddelta; p.dz = dz;
+  p.dout = dout; p.ypre_in = y_pre; p.ckpt_in = ckpt; p.du = du; p.ddelta = ddelta; p.dz = dz;
   p.nchunks = (s->len + TB - 1) / TB;
   p.ngroups = (s->dim + 63) / 64;
   const int64_t nA = (int64_t)s->batch * s->dim * s->dstate, nD = (int64_t)s->batch * s->dim;

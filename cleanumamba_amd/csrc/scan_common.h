@@ -31,6 +31,8 @@ struct ScanParams {
   const void *u, *delta, *z;
   const float *A, *Bm, *Cm, *D, *bias;
   void *out;
+  void *ypre;            // forward, optional: y before the gate (out's element type and strides), for the backward
+  const void *ypre_in;   // backward, optional: the forward's ypre (dout's strides); else y is rebuilt
   float *last_state, *ckpt;
   const void *dout;
   const float *ckpt_in;

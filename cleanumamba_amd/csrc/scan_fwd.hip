@@ -199,6 +199,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
   const bool has_z = p.z != nullptr;
   const TIO *zp = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb + dc * p.s.z_sd : up;
   TIO *op = static_cast<TIO *>(p.out) + b * p.s.o_sb + dc * p.s.o_sd;
+  TIO *yp = p.ypre ? static_cast<TIO *>(p.ypre) + b * p.s.o_sb + dc * p.s.o_sd : nullptr;   // y before the gate, kept for the backward
   const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
   const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
   const int o_sl = (int)p.s.o_sl;
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
         float y = Dd * eu[k];
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) y += s_y[ww][tl][lane];
+        if (yp) yp[t * o_sl] = (TIO)y;
         if (has_z) {
           const float zv = ez[k];
           y *= zv * sigmoidf_(zv);
@@ -959,12 +961,27 @@ extern "C" int cum_selective_scan_fwd(const cum_scan_shape *s, const void *u, co
                                       const float *Bm, const float *Cm, const float *D, const void *z,
                                       const float *delta_bias, void *out, float *last_state, float *ckpt,
                                       void *stream) {
-  return cum_selective_scan_fwd_ws(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last_state, ckpt, nullptr, stream);
+  return cum_selective_scan_fwd_ws(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, nullptr, last_state, ckpt, nullptr, stream);
+}
+
+// 1 if the forward this shape takes (with / without a workspace offered) can keep y before the gate for the backward:
+// the sequential kernel for d_state > 16 (the E6 / E8 bottleneck); the backward of the other shapes rebuilds it.
+extern "C" int32_t cum_scan_fwd_keeps_y(int32_t batch, int32_t dim, int32_t dstate, int32_t len, int32_t with_workspace) {
+  if (batch <= 0 || dim <= 0 || len <= 0 || dstate <= 2 * NS) return 0;
+#ifdef CUM_AB   // (the A/B forward variants do not write it)
+  if (cum_knob("CUM_SCAN_FWD_LDS", 1) == 0 || cum_knob("CUM_SCAN_FWD_WS3", 0) == 1) return 0;
+#endif
+  if (with_workspace) {
+    int nseg = 1, segc = 0;
+    scan_seg_plan(batch, dim, dstate, len, &nseg, &segc);
+    if (nseg > 1) return 0;
+  }
+  return 1;
 }
 
 extern "C" int cum_selective_scan_fwd_ws(const cum_scan_shape *s, const void *u, const void *delta, const float *A,
                                          const float *Bm, const float *Cm, const float *D, const void *z,
-                                         const float *delta_bias, void *out, float *last_state, float *ckpt,
+                                         const float *delta_bias, void *out, void *y_pre, float *last_state, float *ckpt,
                                          float *workspace, void *stream) {
   if (int rc = scan_check_shape(s)) return rc;
   if (s->batch == 0) return CUM_OK;
@@ -979,6 +996,9 @@ extern "C" int cum_selective_scan_fwd_ws(const cum_scan_shape *s, const void *u,
   p.s = *s;
   p.u = u; p.delta = delta; p.A = A; p.Bm = Bm; p.Cm = Cm; p.D = D; p.z = z; p.bias = delta_bias;
   p.out = out; p.last_state = last_state; p.ckpt = ckpt;
+  p.ypre = y_pre;
+  CUM_REQUIRE(!y_pre || cum_scan_fwd_keeps_y(s->batch, s->dim, s->dstate, s->len, workspace != nullptr),
+              "scan_fwd: y_pre is kept only where cum_scan_fwd_keeps_y says so");
   p.nchunks = (s->len + TB - 1) / TB;
   p.ngroups = (s->dim + 63) / 64;
   if (workspace) {          // the caller offers the segmented path its workspace: taken when the plan splits the sequence

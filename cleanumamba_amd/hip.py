@@ -61,9 +61,10 @@ SIGNATURES = {
     "cum_scan_ckpt_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "cum_selective_scan_fwd": (c_i32, [ctypes.POINTER(ScanShape)] + [_P] * 12),
     "cum_scan_fwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
-    "cum_selective_scan_fwd_ws": (c_i32, [ctypes.POINTER(ScanShape)] + [_P] * 13),
+    "cum_selective_scan_fwd_ws": (c_i32, [ctypes.POINTER(ScanShape)] + [_P] * 14),
+    "cum_scan_fwd_keeps_y": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "cum_scan_bwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
-    "cum_selective_scan_bwd": (c_i32, [ctypes.POINTER(ScanShape), ctypes.POINTER(ScanGradStrides)] + [_P] * 20),
+    "cum_selective_scan_bwd": (c_i32, [ctypes.POINTER(ScanShape), ctypes.POINTER(ScanGradStrides)] + [_P] * 21),
     "cum_selective_state_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, _P, c_i64, _P, c_i64,
                                            _P, _P, _P, c_i32, _P, _P]),
     "cum_causal_conv1d_fwd": (c_i32, [ctypes.POINTER(ConvShape)] + [_P] * 5),
@@ -148,7 +149,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 10:
+        if L.cum_abi_version() != 11:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -129,8 +129,12 @@ class _MambaInnerFn(torch.autograd.Function):
         if save:
             ckpt = torch.empty(max(lib.cum_scan_ckpt_elems(Bn, Dn, N, L), 1), dtype=torch.float32, device=dev)
         ss = ssi._shape(xcT, dtT, zv, yT, Bm, Cm, True)
-        ssi.scan_forward(ss, xcT, dtT, A, Bm, Cm, Df, zv, bias, yT, None, ckpt, ssi.TIME_PARALLEL)
-        ctx.save_for_backward(xz, w2, cb, xc, x_dbl, dt, bc, A, Df, bias, ckpt, xw, dtw)
+        # y before the gate, kept for the backward where the forward kernel can (the E6 / E8 bottleneck): the backward scan
+        # then reads it instead of rebuilding it
+        ypre = torch.empty_like(y) if (save and ssi.keeps_y(ss, ssi.TIME_PARALLEL)) else None
+        ssi.scan_forward(ss, xcT, dtT, A, Bm, Cm, Df, zv, bias, yT, None, ckpt, ssi.TIME_PARALLEL,
+                         y_pre=ypre.transpose(1, 2) if ypre is not None else None)
+        ctx.save_for_backward(xz, w2, cb, xc, x_dbl, dt, bc, A, Df, bias, ckpt, xw, dtw, ypre)
         ctx.params = (conv_w, conv_b, xw, dtw, dt_bias, A_log, Dp)
         ctx.cd, ctx.dims = cd, (Bn, L, Dn, N, R)
         return y
@@ -142,7 +146,7 @@ class _MambaInnerFn(torch.autograd.Function):
         from ...causal_conv1d import _shape as conv_shape
         from ...network import convstack as cs
         from ..ops import selective_scan_interface as ssi
-        xz, w2, cb, xc, x_dbl, dt, bc, A, Df, bias, ckpt, xw, dtw = ctx.saved_tensors
+        xz, w2, cb, xc, x_dbl, dt, bc, A, Df, bias, ckpt, xw, dtw, ypre = ctx.saved_tensors
         if ckpt is None:
             raise RuntimeError("Mamba inner backward called but the forward saved no scan checkpoints")
         conv_w, conv_b, xw_p, dtw_p, dt_bias_p, A_log_p, D_p = ctx.params
@@ -182,7 +186,8 @@ class _MambaInnerFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             hip.check(lib.cum_selective_scan_bwd(ctypes.byref(su), ctypes.byref(gs), hip.ptr(xcT), hip.ptr(dtT), hip.ptr(A),
                                                  hip.ptr(Bm), hip.ptr(Cm), hip.ptr(Df), hip.ptr(zv), hip.ptr(bias),
-                                                 hip.ptr(dyT), hip.ptr(ckpt), hip.ptr(duT), hip.ptr(ddT), hip.ptr(dA),
+                                                 hip.ptr(dyT), hip.ptr(ypre.transpose(1, 2) if ypre is not None else None),
+                                                 hip.ptr(ckpt), hip.ptr(duT), hip.ptr(ddT), hip.ptr(dA),
                                                  hip.ptr(dBC[0]), hip.ptr(dBC[1]), hip.ptr(dD), hip.ptr(dzT), hip.ptr(dbias),
                                                  hip.ptr(ws), hip.stream_ptr()))
         torch.mul(dA, A, out=dA_log)                                       # A = -exp(A_log): dA / dA_log = A

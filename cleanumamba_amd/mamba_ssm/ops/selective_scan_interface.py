@@ -13,6 +13,7 @@ read them and write out / du / ddelta / dz in that element type directly (cum_sc
 recurrence, A, B, C, D, the bias and their gradients are fp32.
 """
 import ctypes
+import os
 
 import torch
 
@@ -53,7 +54,7 @@ def _shape(u, delta, z, out, Bm, Cm, softplus):
     return s
 
 
-def scan_forward(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last, ckpt, time_parallel=True):
+def scan_forward(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last, ckpt, time_parallel=True, y_pre=None):
     """Launch the forward scan described by ``s`` (a hip.ScanShape).  Where the sequential grid -- batch * ceil(dim / 64)
     * ceil(d_state / 8) waves -- would leave most of the chip idle (batch-1 file denoising, the 442K model, the pruned
     checkpoints), the library asks for a workspace and runs its time-parallel form (csrc/scan_seg.hip: segments walked
@@ -65,7 +66,16 @@ def scan_forward(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last, ckpt, time
     with torch.cuda.device(u.device):
         hip.check(lib.cum_selective_scan_fwd_ws(ctypes.byref(s), hip.ptr(u), hip.ptr(delta), hip.ptr(A), hip.ptr(Bm),
                                                 hip.ptr(Cm), hip.ptr(D), hip.ptr(z), hip.ptr(delta_bias), hip.ptr(out),
-                                                hip.ptr(last), hip.ptr(ckpt), hip.ptr(ws), hip.stream_ptr()))
+                                                hip.ptr(y_pre), hip.ptr(last), hip.ptr(ckpt), hip.ptr(ws), hip.stream_ptr()))
+
+
+_KEEP_Y = os.environ.get("CUM_SCAN_KEEP_Y", "1") != "0"      # "0": the backward rebuilds y (A/B timing)
+
+
+def keeps_y(s, time_parallel=True):
+    """The forward of this shape can keep y before the gate for the backward (cum_scan_fwd_keeps_y): ask before
+    allocating ``y_pre`` (a tensor of out's dtype and strides)."""
+    return _KEEP_Y and bool(hip.lib().cum_scan_fwd_keeps_y(s.batch, s.dim, s.dstate, s.len, int(bool(time_parallel))))
 
 
 TIME_PARALLEL = True        # module switch for tests / A-B timing: False pins the sequential forward kernels
@@ -96,11 +106,16 @@ class SelectiveScanFn(torch.autograd.Function):
             ckpt = torch.empty(max(lib.cum_scan_ckpt_elems(bsz, dim, N, L), 1), dtype=torch.float32, device=u.device)
         last = torch.empty(bsz, dim, N, dtype=torch.float32, device=u.device) if return_last_state else None
         s = _shape(u, delta, z, out, Bm, Cm, delta_softplus)
-        scan_forward(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last, ckpt, TIME_PARALLEL)
+        # y before the gate, kept for the backward where the forward kernel can (d_state > 16, sequential form): the
+        # backward then does not rebuild it (csrc/scan_bwd.hip YIN)
+        y_pre = None
+        if need_grad and z is not None and keeps_y(s, TIME_PARALLEL):
+            y_pre = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device)
+        scan_forward(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last, ckpt, TIME_PARALLEL, y_pre=y_pre)
         ctx.delta_softplus = bool(delta_softplus)
         ctx.has_z = z is not None
         ctx.b4 = (B.dim() == 4, C.dim() == 4)
-        ctx.save_for_backward(u, delta, A, Bm, Cm, D, z, delta_bias, ckpt)
+        ctx.save_for_backward(u, delta, A, Bm, Cm, D, z, delta_bias, ckpt, y_pre)
         if return_last_state:
             ctx.mark_non_differentiable(last)
             return out, last
@@ -109,7 +124,7 @@ class SelectiveScanFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dout, *unused):
-        u, delta, A, Bm, Cm, D, z, delta_bias, ckpt = ctx.saved_tensors
+        u, delta, A, Bm, Cm, D, z, delta_bias, ckpt, y_pre = ctx.saved_tensors
         if ckpt is None:
             raise RuntimeError("selective_scan backward called but forward saved no checkpoints")
         bsz, dim, L = u.shape
@@ -119,6 +134,8 @@ class SelectiveScanFn(torch.autograd.Function):
         du, ddelta = _empty_like_layout(u), _empty_like_layout(delta)
         dz = _empty_like_layout(z) if z is not None else None
         su = _shape(u, delta, z, dout, Bm, Cm, ctx.delta_softplus)     # o_* strides := dout's
+        if y_pre is not None and y_pre.stride() != dout.stride():      # the kernel reads it with dout's strides
+            y_pre = None
         gs = hip.ScanGradStrides()
         gs.du_sb, gs.du_sd, gs.du_sl = du.stride()
         gs.dd_sb, gs.dd_sd, gs.dd_sl = ddelta.stride()
@@ -134,7 +151,7 @@ class SelectiveScanFn(torch.autograd.Function):
         with torch.cuda.device(u.device):
             hip.check(lib.cum_selective_scan_bwd(ctypes.byref(su), ctypes.byref(gs), hip.ptr(u), hip.ptr(delta), hip.ptr(A),
                                                  hip.ptr(Bm), hip.ptr(Cm), hip.ptr(D), hip.ptr(z),
-                                                 hip.ptr(delta_bias), hip.ptr(dout), hip.ptr(ckpt), hip.ptr(du),
+                                                 hip.ptr(delta_bias), hip.ptr(dout), hip.ptr(y_pre), hip.ptr(ckpt), hip.ptr(du),
                                                  hip.ptr(ddelta), hip.ptr(dA), hip.ptr(dB), hip.ptr(dC),
                                                  hip.ptr(dD), hip.ptr(dz), hip.ptr(dbias), hip.ptr(ws),
                                                  hip.stream_ptr()))

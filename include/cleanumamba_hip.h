@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 10
+#define CUM_ABI_VERSION 11
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -91,8 +91,12 @@ int cum_selective_scan_fwd(const cum_scan_shape *s, const void *u, const void *d
 int64_t cum_scan_fwd_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len);
 int cum_selective_scan_fwd_ws(const cum_scan_shape *s, const void *u, const void *delta,
                               const float *A, const float *Bm, const float *Cm, const float *D,
-                              const void *z, const float *delta_bias, void *out,
+                              const void *z, const float *delta_bias, void *out, void *y_pre,
                               float *last_state, float *ckpt, float *workspace, void *stream);
+/* y_pre: NULL, or a buffer of out's element type and strides that receives y before the gate (y_t = <C_t, x_t> + D u_t),
+ * which the backward then reads instead of rebuilding it (one packed fma per state pair and step saved there).  Only where
+ * cum_scan_fwd_keeps_y() returns 1 for the shape (the sequential kernel for d_state > 16: the E6 / E8 bottleneck). */
+int32_t cum_scan_fwd_keeps_y(int32_t batch, int32_t dim, int32_t dstate, int32_t len, int32_t with_workspace);
 
 /* Strides (batch, dim, len) of the three per-element gradient outputs. */
 typedef struct {
@@ -105,13 +109,14 @@ typedef struct {
  * dB, dC: (batch, len, dstate) CONTIGUOUS fp32 outputs.
  * dA: (dim, dstate), dD, ddelta_bias: (dim) -- fully overwritten (not accumulated).
  * workspace: fp32, cum_scan_bwd_workspace_elems() elements.
- * out_y: optional; if z != NULL the kernel needs y (pre-gate) and recomputes it. */
+ * y_pre: NULL, or the forward's y_pre (dout's strides): with z != NULL the kernel needs y before the gate and rebuilds it
+ * when it is not given. */
 int64_t cum_scan_bwd_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len);
 
 int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs,
                            const void *u, const void *delta,
                            const float *A, const float *Bm, const float *Cm, const float *D,
-                           const void *z, const float *delta_bias, const void *dout,
+                           const void *z, const float *delta_bias, const void *dout, const void *y_pre,
                            const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
                            float *dC, float *dD, void *dz, float *ddelta_bias,
                            float *workspace, void *stream);

@@ -181,6 +181,57 @@ def test_scan_small_state_optional_arguments(cuda, N, opts):
         assert rel_l2(dev[k].grad, ref[k].grad) < BWD_TOL, k
 
 
+@pytest.mark.parametrize("io", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 128, 64, 50), (1, 70, 64, 33), (2, 64, 32, 40)])
+def test_scan_backward_with_the_forwards_y_equals_the_rebuilding_one(cuda, shape, io, monkeypatch):
+    """d_state > 16, gated: the forward keeps y before the gate (cum_scan_fwd_keeps_y, y_pre) and the backward reads it
+    instead of rebuilding sum_n C x_t + D u (csrc/scan_bwd.hip YIN).  Every gradient against the f64 oracle and against
+    the backward that rebuilds y (keeps_y forced off); the kept y against the oracle's; really taken."""
+    from cleanumamba_amd.mamba_ssm.ops import selective_scan_interface as ssi
+    bsz, dim, N, L = shape
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *sh: torch.randn(*sh, generator=g)
+    cpu = dict(u=rn(bsz, L, dim).transpose(1, 2), delta=0.5 * rn(bsz, L, dim).transpose(1, 2), A=-torch.exp(0.5 * rn(dim, N)),
+               B=rn(bsz, L, N).transpose(1, 2), C=rn(bsz, L, N).transpose(1, 2), D=rn(dim), z=rn(bsz, L, dim).transpose(1, 2),
+               delta_bias=0.3 * rn(dim))
+    dout = rn(bsz, L, dim).transpose(1, 2)
+    lowp = ("u", "delta", "z")
+    rnd = lambda k, v: (v.to(io).double() if k in lowp else v.double())
+    ref = {k: rnd(k, v).detach().requires_grad_(True) for k, v in cpu.items()}
+    yr = M.selective_scan_ref(ref["u"], ref["delta"], ref["A"], ref["B"], ref["C"], ref["D"], z=ref["z"],
+                              delta_bias=ref["delta_bias"], delta_softplus=True)
+    (yr * dout.to(io).double()).sum().backward()
+    kept = []
+    real = ssi.scan_forward
+
+    def spy(*a, **k):
+        kept.append(k.get("y_pre"))
+        return real(*a, **k)
+    monkeypatch.setattr(ssi, "scan_forward", spy)
+
+    def run(keep):
+        if not keep:
+            monkeypatch.setattr(ssi, "keeps_y", lambda *a, **k: False)
+        dev = {k: (v.to(io) if k in lowp else v).to(cuda).detach().requires_grad_(True) for k, v in cpu.items()}
+        y = ssi.selective_scan_fn(dev["u"], dev["delta"], dev["A"], dev["B"], dev["C"], dev["D"], z=dev["z"],
+                                  delta_bias=dev["delta_bias"], delta_softplus=True)
+        (y.float() * dout.to(io).float().to(cuda)).sum().backward()
+        return y.detach().float(), {k: dev[k].grad.detach().float().cpu() for k in dev}
+    y1, g1 = run(True)
+    assert kept[-1] is not None and kept[-1].dtype == io                      # the forward was asked for y
+    yk = kept[-1].float().cpu()
+    ypre_ref = M.selective_scan_ref(ref["u"], ref["delta"], ref["A"], ref["B"], ref["C"], ref["D"], z=None,
+                                    delta_bias=ref["delta_bias"], delta_softplus=True).detach()
+    low = io != torch.float32
+    assert rel_l2(yk, ypre_ref) < (6e-3 if low else FWD_TOL)
+    y0, g0 = run(False)
+    assert kept[-1] is None
+    assert torch.equal(y1, y0)
+    for k in g1:
+        assert rel_l2(g1[k], g0[k]) < (6e-3 if low else 1e-5), k
+        assert rel_l2(g1[k], ref[k].grad) < (2e-2 if low else BWD_TOL), k
+
+
 def test_scan_softplus_threshold_and_empty(cuda):
     """delta + bias > 20 takes the identity branch; zero-length and zero-batch inputs are accepted."""
     from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import selective_scan_fn

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     auto rev_step = [&](const f2 (&xp)[NP2], int tl, int slot, const StepOps &o) {
       const float dt = o.dt, du = o.du, dy = o.dy;
       f2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, yp = {0.f, 0.f};   // even / odd states summed apart, joined below
-      f2 dBp[NP2], dCp[NP2];
+      float ra[8], rb[8];   // the dB / dC contributions of this step, as the reduction takes them (scan_reduce.h)
 #pragma unroll
       for (int j = 0; j < NP2; ++j) {
         const f2 a = slot < NA ? o.a[j] : exp2_2(dt * Ap[j]);
@@ -245,8 +245,13 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         const f2 xt = slot + 1 < SUB ? xs[slot + 1][j] : a * xp[j] + du * o.bv[j];
         const f2 dx = o.cv[j] * dy + dxc[j];
         if constexpr (!YIN) yp = o.cv[j] * xt + yp;
-        dCp[j] = dy * xt;
-        dBp[j] = dx * du;
+        // (scalar multiplies on purpose: sixteen free-standing registers for the exchanges instead of eight register
+        //  copies out of packed results)
+        float *const qB = j < 2 ? ra : rb, *const qC = j < 2 ? ra + 4 : rb + 4;
+        qB[2 * (j & 1)] = dx.x * du;
+        qB[2 * (j & 1) + 1] = dx.y * du;
+        qC[2 * (j & 1)] = dy * xt.x;
+        qC[2 * (j & 1) + 1] = dy * xt.y;
         dxc[j] = a * dx;
         const f2 gg = dxc[j] * xp[j];
         dAacc[j] = gg * dt + dAacc[j];
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       }
       s_p12[w][slot][lane] = make_float2(p1.x + p1.y, p2.x + p2.y);
       if constexpr (!YIN) s_y[w][slot][lane] = yp.x + yp.y;
-      const float tot = wave_reduce_scatter8x2q(dBp, dCp);
+      const float tot = wave_reduce_scatter8x2q_s(ra, rb);
       if (tl <= tlast && st_on) cBC[tl * N + qoff] = tot;   // per-lane slab (dB or dC) + uniform row + per-lane column
       __builtin_amdgcn_sched_barrier(0);
     };

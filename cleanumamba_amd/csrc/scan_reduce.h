@@ -85,9 +85,16 @@ __device__ __forceinline__ void wave_reduce_scatter8x2(const f2 (&b2)[NP2], cons
 // dC pair; row_half_mirror: even quads keep the first of the pair), then two quad steps -- 8 DPP adds instead of 16 and
 // no result copies.  On return lane l of row q holds, in every lane of its quad, the total of
 //   dB[2q] (l & 15 in 0-3), dB[2q + 1] (4-7), dC[2q] (8-11), dC[2q + 1] (12-15).
+__device__ __forceinline__ float wave_reduce_scatter8x2q_s(float (&a)[8], float (&b)[8]);
 __device__ __forceinline__ float wave_reduce_scatter8x2q(const f2 (&b2)[NP2], const f2 (&c2)[NP2]) {
   float a[8] = {b2[0].x, b2[0].y, b2[1].x, b2[1].y, c2[0].x, c2[0].y, c2[1].x, c2[1].y};
   float b[8] = {b2[2].x, b2[2].y, b2[3].x, b2[3].y, c2[2].x, c2[2].y, c2[3].x, c2[3].y};
+  return wave_reduce_scatter8x2q_s(a, b);
+}
+// The same on sixteen scalars: a[0..3] = dB values 0-3, a[4..7] = dC values 0-3, b[0..3] = dB values 4-7, b[4..7] = dC values
+// 4-7.  (Callers that form the values with scalar multiplies hand the exchanges sixteen free-standing registers; halves of
+// packed results cost a register copy each for eight of them.)
+__device__ __forceinline__ float wave_reduce_scatter8x2q_s(float (&a)[8], float (&b)[8]) {
   asm volatile(
       "s_nop 1\n\t"
       "v_permlane32_swap_b32 %0, %8\n\t"

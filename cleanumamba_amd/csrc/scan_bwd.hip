@@ -147,7 +147,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * TB;
     const int tlast = L - 1 - t0;  // last valid local step of this chunk (>= 0)
-    float *cBC = ((lane & 8) ? wsC : wsB) + (int64_t)t0 * N;
+    // per-lane slab (dB or dC) + this chunk's first row + per-lane column: the per-step row offset is then an immediate
+    float *const cBC = ((lane & 8) ? wsC : wsB) + (int64_t)t0 * N + qoff;
     // state entering the chunk: needed by both halves, requested now so that its latency hides behind phase A
     f2 x0[NP2], x8[NP2];   // x8: state entering the second half (local step 8), read only if the chunk reaches it
     ckpt_load(p.ckpt_in, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, dc), x0);
@@ -187,6 +188,11 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     __syncthreads();
     PROBE(1);
 
+    // this wave's slices of the B / C tiles: addresses kept in vector registers (left to itself the compiler re-creates the
+    // wave-uniform address from a scalar before every step's reads)
+    typedef const __attribute__((address_space(3))) float *lds_cfp;
+    lds_cfp lB = (lds_cfp)&s_B[0][LDSBC ? n0 : 0], lC = (lds_cfp)&s_C[0][LDSBC ? n0 : 0];
+    asm volatile("" : "+v"(lB), "+v"(lC));
     f2 xs[SUB][NP2];   // states before each step of the half being processed
     // Operands of one time step: B_t / C_t slices (SGPRs via s_load) and the per-(t, d) values from LDS.  They are
     // fetched one step ahead of their use so that neither the scalar-load nor the LDS latency is exposed.
@@ -202,8 +208,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         o.a[0] = f2{a0.x, a0.y}; o.a[1] = f2{a0.z, a0.w}; o.a[2] = f2{a1.x, a1.y}; o.a[3] = f2{a1.z, a1.w};
       }
       if constexpr (LDSBC) {
-        const float4 b0 = *reinterpret_cast<const float4 *>(&s_B[tc][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[tc][n0 + 4]);
-        const float4 c0 = *reinterpret_cast<const float4 *>(&s_C[tc][n0]), c1 = *reinterpret_cast<const float4 *>(&s_C[tc][n0 + 4]);
+        // (row tl itself, not the clamped tc: rows past the clip's end hold the last row's values and meet zero dt / du / dy,
+        //  and a compile-time tl makes these addresses immediates)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(3))) f4v *lds_c4p;
+        const f4v b0 = *(lds_c4p)(lB + tl * NP), b1 = *(lds_c4p)(lB + tl * NP + 4);
+        const f4v c0 = *(lds_c4p)(lC + tl * NP), c1 = *(lds_c4p)(lC + tl * NP + 4);
         o.bv[0] = f2{b0.x, b0.y}; o.bv[1] = f2{b0.z, b0.w}; o.bv[2] = f2{b1.x, b1.y}; o.bv[3] = f2{b1.z, b1.w};
         o.cv[0] = f2{c0.x, c0.y}; o.cv[1] = f2{c0.z, c0.w}; o.cv[2] = f2{c1.x, c1.y}; o.cv[3] = f2{c1.z, c1.w};
       } else {
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
     // one reverse step; xp = state before step tl; slot = tl % SUB
     auto rev_step = [&](const f2 (&xp)[NP2], int tl, int slot, const StepOps &o) {
       const float dt = o.dt, du = o.du, dy = o.dy;
-      f2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, yp = {0.f, 0.f};   // even / odd states summed apart, joined below
+      f2 p1, p2, yp = {0.f, 0.f};   // even / odd states summed apart, joined below
       float ra[8], rb[8];   // the dB / dC contributions of this step, as the reduction takes them (scan_reduce.h)
 #pragma unroll
       for (int j = 0; j < NP2; ++j) {
@@ -255,13 +265,22 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         dxc[j] = a * dx;
         const f2 gg = dxc[j] * xp[j];
         dAacc[j] = gg * dt + dAacc[j];
-        p1 = gg * Ap[j] + p1;
-        p2 = dx * o.bv[j] + p2;
+        if (j == 0) {            // (the first pair starts the sums: no zeroed accumulators to set up every step)
+          p1 = gg * Ap[j];
+          p2 = dx * o.bv[j];
+        } else {
+          p1 = gg * Ap[j] + p1;
+          p2 = dx * o.bv[j] + p2;
+        }
       }
-      s_p12[w][slot][lane] = make_float2(p1.x + p1.y, p2.x + p2.y);
+      {                       // (two scalar stores -> one ds_write2_b32 of two free-standing registers: no pair to assemble)
+        float *const q = reinterpret_cast<float *>(&s_p12[w][slot][lane]);
+        q[0] = p1.x + p1.y;
+        q[1] = p2.x + p2.y;
+      }
       if constexpr (!YIN) s_y[w][slot][lane] = yp.x + yp.y;
       const float tot = wave_reduce_scatter8x2q_s(ra, rb);
-      if (tl <= tlast && st_on) cBC[tl * N + qoff] = tot;   // per-lane slab (dB or dC) + uniform row + per-lane column
+      if (tl <= tlast && st_on) cBC[tl * N] = tot;
       __builtin_amdgcn_sched_barrier(0);
     };
     // phase C for one half: combine the per-wave partial sums, write du / ddelta / dz

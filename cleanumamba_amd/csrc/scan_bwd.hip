@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
           p2 = dx * o.bv[j] + p2;
         }
       }
-      {                       // (two scalar stores -> one ds_write2_b32 of two free-standing registers: no pair to assemble)
+      {
         float *const q = reinterpret_cast<float *>(&s_p12[w][slot][lane]);
         q[0] = p1.x + p1.y;
         q[1] = p2.x + p2.y;

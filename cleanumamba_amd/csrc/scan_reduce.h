@@ -95,6 +95,12 @@ __device__ __forceinline__ float wave_reduce_scatter8x2q(const f2 (&b2)[NP2], co
 // 4-7.  (Callers that form the values with scalar multiplies hand the exchanges sixteen free-standing registers; halves of
 // packed results cost a register copy each for eight of them.)
 __device__ __forceinline__ float wave_reduce_scatter8x2q_s(float (&a)[8], float (&b)[8]) {
+  // ONE asm block, instructions ordered so that every hazard distance (VALU write -> permlane swap / DPP read: two wait
+  // states) is covered by the neighbouring instructions: four s_nop per step instead of six, and no compiler-placed adds
+  // between blocks.  h_i = a_i + b_i after the half exchange; e = {h0, h1, h4, h5}, o = {h2, h3, h6, h7} meet in the row
+  // exchange; q0..q3 = a0, a1, a4, a5 enter the bank-masked DPP tail.
+  // (b0, b1, b2 are dead after the first adds and serve as the tail's two intermediates and its result: no register beyond
+  //  the sixteen operands)
   asm volatile(
       "s_nop 1\n\t"
       "v_permlane32_swap_b32 %0, %8\n\t"
@@ -104,39 +110,37 @@ __device__ __forceinline__ float wave_reduce_scatter8x2q_s(float (&a)[8], float 
       "v_permlane32_swap_b32 %4, %12\n\t"
       "v_permlane32_swap_b32 %5, %13\n\t"
       "v_permlane32_swap_b32 %6, %14\n\t"
-      "v_permlane32_swap_b32 %7, %15"
+      "v_permlane32_swap_b32 %7, %15\n\t"
+      "v_add_f32 %0, %0, %8\n\t"
+      "v_add_f32 %1, %1, %9\n\t"
+      "v_add_f32 %2, %2, %10\n\t"
+      "v_add_f32 %3, %3, %11\n\t"
+      "v_add_f32 %4, %4, %12\n\t"
+      "v_add_f32 %5, %5, %13\n\t"
+      "v_add_f32 %6, %6, %14\n\t"
+      "v_add_f32 %7, %7, %15\n\t"
+      "v_permlane16_swap_b32 %0, %2\n\t"
+      "v_permlane16_swap_b32 %1, %3\n\t"
+      "v_permlane16_swap_b32 %4, %6\n\t"
+      "v_permlane16_swap_b32 %5, %7\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      "v_add_f32 %1, %1, %3\n\t"
+      "v_add_f32 %4, %4, %6\n\t"
+      "v_add_f32 %5, %5, %7\n\t"
+      "v_add_f32_dpp %8, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %9, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %8, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %9, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %10, %8, %8 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %10, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %10, %10, %10 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %10, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
       : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]),
         "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
-  float h[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) h[i] = a[i] + b[i];
-  float e[4] = {h[0], h[1], h[4], h[5]}, o[4] = {h[2], h[3], h[6], h[7]};
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_permlane16_swap_b32 %0, %4\n\t"
-      "v_permlane16_swap_b32 %1, %5\n\t"
-      "v_permlane16_swap_b32 %2, %6\n\t"
-      "v_permlane16_swap_b32 %3, %7"
-      : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-  const float q0 = e[0] + o[0], q1 = e[1] + o[1], q2 = e[2] + o[2], q3 = e[3] + o[3];
-  float ra, rb, sv;
-  // (s_nop 1: two wait states between a VALU write of a register and a DPP read of it)
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-      "v_add_f32_dpp %1, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-      "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-      "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-      "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-      : "=&v"(ra), "=&v"(rb), "=&v"(sv)
-      : "v"(q0), "v"(q1), "v"(q2), "v"(q3));
-  return sv;
+  return b[2];
 }
 
 }  // namespace cum

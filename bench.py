@@ -395,8 +395,13 @@ def c2_e6_forward(dev, dt):
 def c5_streaming(dev, streams=256, seconds=30.0):
     """BASELINE.json configs[4]: the pruned CleanUMamba-E8 (492 K parameters, shipped checkpoint: tests/golden/
     ckpt_pruned500k.npz is its state dict as data) streaming 256 concurrent 30 s @ 16 kHz streams through feed_batch /
-    flush_batch (16 hops per call).  Real-time factor = audio seconds produced / wall seconds, aggregate over the streams
-    (the reference prints ms/frame and x real time for ONE stream, src/examples/streaming_demo.py:183-186)."""
+    flush_batch (16 hops = 256 ms of audio per call).  Real-time factor = audio seconds produced / wall seconds, aggregate
+    over the streams (the reference prints ms/frame and x real time for ONE stream, src/examples/streaming_demo.py:183-186).
+    Rows: "f32" = the default path, every hop of a call in ONE launch (csrc/hop.hip); "f32_per_layer" = the per-layer
+    hop it replaced (fused GEMM launches, hipGraph); "bf16_conv_activations" = that path with 16-bit activations.
+    `roofline`: the model's multiply-adds of a hop x 2 x streams / time against the f32 matrix peak (the kernel computes
+    in exact f32 on v_mfma_f32_16x16x4_f32).  The warm-up includes one flush: the first drain of a process loads the
+    BLAS library behind its einsums (0.26 s once, not per stream)."""
     import numpy as np
     from cleanumamba_amd.network import CleanUMamba
     with np.load(os.path.join(ROOT, "tests", "golden", "ckpt_pruned500k.npz")) as f:
@@ -407,26 +412,34 @@ def c5_streaming(dev, streams=256, seconds=30.0):
     n = int(seconds * 16000)
     g = torch.Generator(device=dev).manual_seed(99)
     x = 0.05 * torch.randn(streams, n, generator=g, device=dev)
-    for tag, bf16 in (("f32", False), ("bf16_conv_activations", True)):
+    for tag, kernel, bf16 in (("f32", True, False), ("f32_per_layer", False, False),
+                              ("bf16_conv_activations", False, True)):
         net = CleanUMamba(**cfg)
         net.load_pruned_state_dict(sd)
         net = net.to(dev).eval()
-        net.stream_bf16 = bf16
+        net.use_hop_kernel, net.stream_bf16 = kernel, bf16
         hop = net.total_stride
         with torch.no_grad():
-            net.feed_batch(x[:, :4 * hop + net.frame_length])       # warm-up: state buffers, hop graph
-            net.reset_stream()
+            net.feed_batch(x[:, :4 * hop + net.frame_length])       # warm-up: state buffers, hop plan / graph, drain
+            net.flush_batch()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(0, n, 16 * hop):                         # 256 ms of audio per call
                 net.feed_batch(x[:, i:i + 16 * hop])
-            status = net.hop_graph_status                           # (flush ends the streams; their graph goes with them)
-            net.flush_batch()
+            status = net.hop_kernel_status if kernel else net.hop_graph_status
+            plan = net.__dict__.get("_hop_plan")
+            net.flush_batch()                                       # (flush ends the streams; their state goes with them)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
-        out[tag] = {"wall_s": round(wall, 3), "ms_per_hop": round(1e3 * wall / (n // hop), 4),
-                    "hop_ms_audio": 1e3 * hop / 16000, "rtf_aggregate": round(streams * seconds / wall, 1),
-                    "rtf_per_stream": round(seconds / wall, 2), "hop_graph": status}
+        row = {"wall_s": round(wall, 3), "ms_per_hop": round(1e3 * wall / (n // hop), 4),
+               "hop_ms_audio": 1e3 * hop / 16000, "rtf_aggregate": round(streams * seconds / wall, 1),
+               "rtf_per_stream": round(seconds / wall, 2), "hop_path": ("one launch: " if kernel else "graph: ") + status}
+        if kernel and plan is not None:
+            flops = plan[1].flops_per_hop * streams * (n // hop)
+            row["launches_per_hop"] = round(1.0 / 16, 4)
+            row["roofline"] = {"bound": "mfma", "achieved": round(flops / wall / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                               "frac": round(flops / wall / 157.3e12, 4), "flops_per_hop_and_stream": plan[1].flops_per_hop}
+        out[tag] = row
         del net
     return out
 

@@ -98,6 +98,9 @@ SIGNATURES = {
     "cum_stream_window_update": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, c_i64, c_i64, c_i32, _P, _P, c_i64, _P]),
     "cum_stream_tail_rows": (c_i32, [c_i32, c_i32, c_i32, c_i32, _P, c_i64, c_i32, _P, c_i64, _P]),
     "cum_stream_overlap_add": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i64, _P, c_i64, c_i32, _P]),
+    "cum_stream_hop_plan_ints": (c_i32, []),
+    "cum_stream_hop_max_lds_bytes": (c_i32, []),
+    "cum_stream_hop": (c_i32, [_P, _P, _P, c_i64, c_i32, _P, c_i64, _P, c_i64, c_i32, c_i32, _P]),
     "cum_fft_plan_create": (c_i32, [c_i32, c_i32, c_i64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_i64)]),
     "cum_fft_plan_destroy": (c_i32, [_P]),
     "cum_fft_exec": (c_i32, [_P, _P, _P, c_i32, _P, _P]),
@@ -149,7 +152,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 11:
+        if L.cum_abi_version() != 12:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -33,6 +33,7 @@ from ..mamba_ssm.utils.generation import InferenceParams
 from ..util.util import weight_scaling_init
 from .. import hip
 from . import convstack as cs
+from . import hopplan
 from .layers import Activation
 
 
@@ -148,6 +149,8 @@ class CleanUMamba(nn.Module):
         state.pop("_plist", None)
         state.pop("_wv_call", None)
         state.pop("_hop_graph", None)       # captured hipGraph of the streaming hop
+        state.pop("_hop_plan", None)        # packed weights / plan of the one-launch hop
+        state.pop("_hop_kernel_why", None)
         return state
 
     # ------------------------------------------------------------------ geometry
@@ -378,6 +381,8 @@ class CleanUMamba(nn.Module):
         """Drop the cached GEMM-layout copies of the conv weights (rebuilt on the next forward)."""
         self.__dict__.pop("_pack_plans", None)
         self.__dict__.pop("_hop_graph", None)
+        self.__dict__.pop("_hop_plan", None)
+        self.__dict__.pop("_hop_kernel_why", None)      # (shapes may have changed: ask again)
         self.__dict__.pop("_plist", None)
 
     # ----------------------------------------------------------------- streaming
@@ -405,6 +410,7 @@ class CleanUMamba(nn.Module):
         self.input_std = 0
         self._std_frames = 0
         self.__dict__.pop("_hop_graph", None)    # it captured the addresses of the dropped state buffers
+        self.__dict__.pop("_hop_state", None)    # state blocks of the one-launch hop (csrc/hop.hip)
 
     @torch.no_grad()
     def flush(self):
@@ -450,6 +456,9 @@ class CleanUMamba(nn.Module):
         Decoder layer j still holds 2 overhang rows of its transposed conv (``dec{j}``, bias excluded) and encoder
         layer i holds ``2^(E-i) - 2`` output rows no hop has consumed as skips yet; layer j maps its
         ``2^(j+1) - 2`` trailing input rows to ``2^(j+2) - 2`` trailing output rows."""
+        hs = self.__dict__.get("_hop_state")
+        if hs is not None:                                      # the one-launch hop owns the state: bring it back
+            self.encoder_decoder_state = hs["plan"].export_state(self, hs["state"])
         state, E = self.encoder_decoder_state, self.encoder_n_layers
         S, dev = self.pending.shape[0], self.pending.device
 
@@ -524,6 +533,19 @@ class CleanUMamba(nn.Module):
         denoised_frames = []
         self.__dict__["_wv_call"] = None            # weights cannot change inside one call: checked on its first hop only
         while self.pending.shape[1] >= self.frame_length:
+            hs = self._hop_kernel_state()
+            if hs is not None:
+                # every remaining hop of this call in ONE launch (csrc/hop.hip): a workgroup per stream walks them
+                n_hops = (self.pending.shape[1] - self.frame_length) // total_stride + 1
+                out = torch.empty(S, n_hops * total_stride, dtype=torch.float32, device=self.pending.device)
+                hs["plan"].run(hs["state"], self.pending, out, n_hops)
+                self.frames += n_hops
+                self._std_frames += n_hops
+                if self.normalize_input:
+                    self.input_std = hs["state"][:, 0:1]         # the kernel keeps the running std in the state block
+                denoised_frames.append(out)
+                self.pending = self.pending[:, n_hops * total_stride:]
+                break
             self.frames += 1
             self._std_frames = getattr(self, "_std_frames", 0) + 1
             frame = self.pending[:, :self.frame_length]
@@ -543,6 +565,55 @@ class CleanUMamba(nn.Module):
         if denoised_frames:
             return torch.cat(denoised_frames, 1)
         return torch.zeros(S, 0, device=noisy_input.device)
+
+    def _hop_kernel_state(self):
+        """{"plan", "state"} once the one-launch hop (csrc/hop.hip) can take this stream's hops, else None: it needs a
+        model the plan supports (hopplan.unsupported_reason), f32 streams on the GPU, and the state the per-layer path
+        leaves after the FIRST frame of the streams (whole windows, no history), which is converted here once."""
+        hs = self.__dict__.get("_hop_state")
+        if hs is not None:
+            wv = self.__dict__.get("_wv_call")
+            if wv is None:
+                wv = self.__dict__["_wv_call"] = self._weights_version()
+            if hs["plan_weights"] != wv:                    # weights changed under a live stream: re-pack them
+                hs["plan"], hs["plan_weights"] = hopplan.HopPlan(self), wv
+            return hs
+        if not getattr(self, "use_hop_kernel", True) or getattr(self, "stream_bf16", False) \
+                or not getattr(self, "stream_incremental", True):
+            return None
+        state = self.encoder_decoder_state
+        if not state or "enc0" not in state or state["enc0"].dim() != 2 or not self.pending.is_cuda \
+                or self.pending.dtype != torch.float32 or self.pending.stride(1) != 1:
+            return None
+        why = self.__dict__.get("_hop_kernel_why")
+        if why is None:
+            why = self.__dict__["_hop_kernel_why"] = hopplan.unsupported_reason(self) or ""
+        if why:
+            return None
+        wv = self._weights_version()
+        self.__dict__["_wv_call"] = wv
+        cached = self.__dict__.get("_hop_plan")
+        if cached is None or cached[0] != wv:
+            try:
+                cached = (wv, hopplan.HopPlan(self))
+            except ValueError as exc:                       # e.g. LDS budget: stay on the per-layer path
+                self.__dict__["_hop_kernel_why"] = str(exc)
+                return None
+            self.__dict__["_hop_plan"] = cached
+        plan = cached[1]
+        hs = {"plan": plan, "plan_weights": wv, "state": plan.import_state(self, self.pending.shape[0])}
+        self.__dict__["_hop_state"] = hs
+        self.__dict__.pop("_hop_graph", None)
+        return hs
+
+    @property
+    def hop_kernel_status(self):
+        """"active" while the one-launch hop owns the stream state, else why not ("off", "first frame pending", reason)."""
+        if self.__dict__.get("_hop_state") is not None:
+            return "active"
+        if not getattr(self, "use_hop_kernel", True):
+            return "off"
+        return self.__dict__.get("_hop_kernel_why") or "first frame pending"
 
     @property
     def hop_graph_status(self):

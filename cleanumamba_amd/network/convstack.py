@@ -496,7 +496,9 @@ class _WgradArena:
         hi = max(o + _numel(sh) for o, sh in zip(offs, shapes))
         if sum((_numel(sh) + 3) // 4 * 4 for sh in shapes) < hi - lo:
             raise RuntimeError("unpack_into: the parameters are not one contiguous run of the flat buffer")
-        ck = (key, "into", tuple(o - lo for o in offs), self.buf.device)
+        # the cached jobs hold offsets RELATIVE to lo (the same stack in another flat layout -- other bottleneck, other
+        # frozen set -- must not reuse absolute positions); lo's 16-byte phase decides which parameters pack2d may take
+        ck = (key, "into", tuple(o - lo for o in offs), lo % 4, self.buf.device)
         ent = _ARENA_INDEX.get(ck)
         if ent is None:
             # Every GEMM-layout -> parameter-layout map separates (source = rowoff[r] + coloff[c] over the parameter seen
@@ -512,7 +514,7 @@ class _WgradArena:
                     rest.append(k)
                     continue
                 ro, co, tr = sep
-                jobs.append((o, rows, cols, tab_pos, tab_pos + rows, int(tr), 0 if tr else _runs8(ro, co)))
+                jobs.append((o - lo, rows, cols, tab_pos, tab_pos + rows, int(tr), 0 if tr else _runs8(ro, co)))
                 tables += [ro, co]
                 tab_pos += rows + cols
                 for tr_ in range((rows + 63) // 64):
@@ -531,10 +533,11 @@ class _WgradArena:
             gidx = None
             if rest:
                 # (the leftovers need not be contiguous: one small gather each)
-                gidx = [(offs[k], parts[k].reshape(-1).to(torch.int32).to(self.buf.device)) for k in rest]
+                gidx = [(offs[k] - lo, parts[k].reshape(-1).to(torch.int32).to(self.buf.device)) for k in rest]
             ent = (pack2d, gidx)
             _ARENA_INDEX[ck] = ent
         pack2d, gidx = ent
+        dst = dst[lo:hi]
         if pack2d is not None:
             jb, tl, tb, ntiles = pack2d
             with torch.cuda.device(self.buf.device):

@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 11
+#define CUM_ABI_VERSION 12
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -403,6 +403,25 @@ int cum_stream_tail_rows(int32_t dtype, int32_t streams, int32_t rows, int32_t C
 int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t Cp, int32_t C, const void *y,
                            int64_t y_pitch, void *tail, const float *bias, const void *skip, int64_t skip_pitch,
                            void *out, int64_t out_pitch, int32_t relu, void *stream);
+
+/* ---- the whole streaming hop in ONE launch (csrc/hop.hip): CleanUMamba.feed / _denoise_frame of
+ * src/network/CleanUMamba.py:370-490 (running input std :399-401, encoder caches :425-447, Mamba.step :451-454, decoder
+ * overlap-add :476-488, with the skip order fixed as SURVEY fact 9 describes) for `n_hops` consecutive hops of `streams`
+ * concurrent streams; a workgroup owns one stream, activations stay in LDS, f32 throughout (exact-f32 matrix cores).
+ *   plan     device int32[cum_stream_hop_plan_ints()]: sizes, LDS regions, offsets into `weights` and into a stream's
+ *            state block, in the field order of csrc/hop.hip::HopPlan (built by cleanumamba_amd/network/hopplan.py)
+ *   weights  device f32 blob: every matrix zero-padded and in MFMA fragment order ([tile][16-deep k chunk][lane][4]),
+ *            biases / LayerNorm parameters / -exp(A_log) / D padded to the pitches the plan names
+ *   state    device f32 [streams][state_stride]: encoder rings, decoder tails, conv / SSM states, running std, ring phase
+ *   in       stream s, hop h reads the frame in[s * in_stride + h * hop_len ...+ frame_len) (raw samples)
+ *   out      stream s, hop h writes out[s * out_stride + h * hop_len ...+ hop_len)
+ *   lds_bytes dynamic LDS the plan needs (<= cum_stream_hop_max_lds_bytes(), multiple of 16)
+ * The first frame of a stream (whole windows, no history) is the per-layer path's; its state is converted once. */
+int cum_stream_hop_plan_ints(void);
+int cum_stream_hop_max_lds_bytes(void);
+int cum_stream_hop(const void *plan, const float *weights, float *state, int64_t state_stride, int32_t streams,
+                   const float *in, int64_t in_stride, float *out, int64_t out_stride, int32_t n_hops,
+                   int32_t lds_bytes, void *stream);
 
 /* ---- first encoder layer, fused (csrc/enc0.hip): Conv1d(1 -> 64, k 4, s 2) + ReLU + Conv1d(64 -> 128, 1x1) + GLU of
  * src/network/CleanUMamba.py:108-113 at channels_input = 1, channels_H = 64 (E6 / E8), 16-bit element types.  The ReLU

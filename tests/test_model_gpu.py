@@ -329,6 +329,44 @@ def test_every_shipped_checkpoint_forward_and_stream(cuda, name):
                 assert net.hop_graph_status == "pending"       # flush() ended the stream; its graph went with it
 
 
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("name", ["pruned500k", "442k", "e8_pruned2m", "e6_pruned2m", "e6_pruned200k"])
+def test_one_launch_hop_equals_per_layer_hop(cuda, name, normalize):
+    """the streaming hop as ONE launch (csrc/hop.hip: a workgroup per stream, activations in LDS, encoder
+    windows as rings) against the per-layer hop (fused GEMM launches + window shifts) on the same streams, fed in
+    ragged chunks (single hops, many hops per call, less than a hop), with and without the running input std; then
+    flush() drains the decoder from the kernel's state.  Also against the parallel forward (normalisation off)."""
+    net = _net(name, cuda, pruned=name != "442k")
+    net.normalize_input = normalize
+    hop, S = net.total_stride, 3
+    L = 40 * hop + 123
+    x = (0.1 * torch.randn(S, L, generator=torch.Generator().manual_seed(21))).to(cuda)
+    x[1] *= 7.0                                             # streams with different running stds
+    sizes = [net.frame_length, hop, hop, 3 * hop + 5, 17, 9 * hop, hop - 17]
+    sizes.append(L - sum(sizes))
+    outs = {}
+    with torch.no_grad():
+        for kernel in (True, False):
+            net.reset_stream()
+            net.use_hop_kernel = kernel
+            chunks, i = [], 0
+            for n in sizes:
+                chunks.append(net.feed_batch(x[:, i:i + n]))
+                i += n
+            assert i == L
+            assert net.hop_kernel_status == ("active" if kernel else "off")
+            chunks.append(net.flush_batch())
+            outs[kernel] = torch.cat(chunks, 1)
+        net.use_hop_kernel = True
+        par = net(x.unsqueeze(1))[:, 0, :L]
+    assert outs[True].shape == (S, L)
+    assert record(f"hop_kernel[{name}-norm{int(normalize)}]", rel_l2(outs[True], outs[False])) < 5e-5
+    for s in range(S):                                     # (f32 rounding of two summation orders: 1.5e-5 measured)
+        assert rel_l2(outs[True][s], outs[False][s]) < 5e-5
+    if not normalize:
+        assert rel_l2(outs[True], par) < 1e-4
+
+
 def test_stream_after_flush_starts_a_fresh_running_std(cuda):
     """normalize_input=True: the running mean of the per-frame std (src/network/CleanUMamba.py:399-401) belongs to a
     stream.  A second clip fed after flush() must come out exactly as from a freshly constructed model."""

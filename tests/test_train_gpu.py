@@ -422,6 +422,38 @@ def test_gradient_sink_equals_autograd_accumulation(cuda, monkeypatch):
     assert float(grads[True].abs().sum()) > 0
 
 
+def test_gradient_sink_with_two_flat_layouts_in_one_process(cuda, monkeypatch):
+    """Two models with the SAME encoder / decoder configuration and different bottlenecks live in one process: the
+    conv stacks' cached un-pack jobs (convstack._ARENA_INDEX) are keyed by the stack, so they must hold positions
+    relative to the stack's run of the flat gradient buffer -- the second model's run starts elsewhere.
+    Every gradient of either model equals the AccumulateGrad route bit for bit."""
+    from cleanumamba_amd.network import CleanUMamba, convstack as cs
+    from cleanumamba_amd.training.train_step import TrainStep
+    clean, noisy = synth.waveform(2, 6000, seed=6)
+    clean, noisy = clean.to(cuda), noisy.to(cuda)
+    base = dict(channels_input=1, channels_output=1, channels_H=16, max_H=32, encoder_n_layers=4, kernel_size=4,
+                stride=2, tsfm_n_layers=1, tsfm_n_head=8, tsfm_d_inner=64)
+    cs._ARENA_INDEX.clear()
+    starts = []
+    for d_model in (64, 24, 64):
+        grads = {}
+        for sink in (True, False):
+            monkeypatch.setattr(cs, "_GRAD_SINK", sink)
+            torch.manual_seed(d_model)
+            net = CleanUMamba(**base, tsfm_d_model=d_model).to(cuda).train()
+            step = TrainStep(net, optimization={"n_iters": 100}, use_graph=False)
+            step.zero_grad()
+            step.micro_step(clean, noisy)
+            flat = step.buckets.flat
+            grads[sink] = {n: p.grad.clone() for n, p in net.named_parameters()}
+            if sink:
+                starts.append(flat.offsets[flat.by_ptr[net.encoder[0][0].weight.data_ptr()]])
+        for n in grads[True]:
+            assert torch.equal(grads[True][n], grads[False][n]), (d_model, n)
+        assert all(float(g.abs().sum()) > 0 for n, g in grads[True].items() if n.startswith(("encoder", "decoder")))
+    assert starts[0] != starts[1], "the two flat layouts were meant to place the encoder at different offsets"
+
+
 def test_foreign_backward_sees_plain_autograd(cuda):
     """The gradient sinks are armed only inside TrainStep's own backward: torch.autograd.grad on a flat-managed model
     returns every gradient (none swallowed into the flat buffer) and leaves the flat gradient buffer untouched; a plain

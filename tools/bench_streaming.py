@@ -23,6 +23,7 @@ if len(sys.argv) > 3:
     net.use_fused_stream = sys.argv[3] != "cached"      # third argument "cached": torch-module hop with encoder caches
     net.stream_bf16 = sys.argv[3] == "bf16"              # "bf16": fused hop with bf16 activations / GEMMs
     net.fused_min_streams = 1                            # an explicit variant also applies to a single stream
+    net.use_hop_kernel = sys.argv[3] == "kernel"          # "kernel" (default without the argument): one launch per hop
 n = int(SECONDS * 16000)
 x = 0.05 * torch.randn(S, n, device=dev)
 hop = net.total_stride
@@ -34,10 +35,11 @@ with torch.no_grad():
     chunk = 16 * hop                                      # 256 ms of audio per call
     for i in range(0, n, chunk):
         net.feed_batch(x[:, i:i + chunk])
+    status = net.hop_kernel_status
     net.flush_batch()
     torch.cuda.synchronize()
     dt = time.time() - t0
 frames = n // hop
 print(json.dumps({"streams": S, "seconds_per_stream": SECONDS, "wall_s": round(dt, 3),
                   "rtf_aggregate": round(S * SECONDS / dt, 1), "rtf_per_stream": round(SECONDS / dt, 2),
-                  "ms_per_hop": round(1e3 * dt / frames, 3), "hop_ms_audio": 1e3 * hop / 16000}))
+                  "ms_per_hop": round(1e3 * dt / frames, 3), "hop_ms_audio": 1e3 * hop / 16000, "hop_kernel": status}))

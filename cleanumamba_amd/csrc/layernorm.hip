@@ -244,6 +244,105 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_finalize_kernel(const f
   }
 }
 
+// ---- any d_model (pruned checkpoints: 55, 114, 477 ...): rows are not 16-byte aligned, so the same arithmetic with
+// element accesses, lane l owning elements l, l + 64, ... (<= 32 per lane).  Same launch geometry and slab layout.
+constexpr int LN_MAXE = 32;
+
+template <typename T>
+__device__ __forceinline__ float ln_ld(const void *p, int64_t i) { return (float)static_cast<const T *>(p)[i]; }
+template <typename T>
+__device__ __forceinline__ void ln_st(void *p, int64_t i, float v) { static_cast<T *>(p)[i] = (T)v; }
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_any_kernel(const LnParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int64_t xo = (row / p.len) * p.x_sb + (row % p.len) * p.x_sl;
+  float v[LN_MAXE];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXE; ++i) {
+    const int e = lane + 64 * i;
+    v[i] = 0.f;
+    if (e < p.dim) {
+      v[i] = ln_ld<TX>(p.x, xo + e) + (p.res ? p.res[row * p.dim + e] : 0.f);
+      p.res_out[row * p.dim + e] = v[i];
+      s += v[i];
+    }
+  }
+  const float mean = wave_sum(s) / p.dim;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXE; ++i)
+    if (lane + 64 * i < p.dim) {
+      const float d = v[i] - mean;
+      q += d * d;
+    }
+  const float rstd = rsqrtf(wave_sum(q) / p.dim + p.eps);
+  if (lane == 0) {
+    p.mean[row] = mean;
+    p.rstd[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXE; ++i) {
+    const int e = lane + 64 * i;
+    if (e < p.dim) ln_st<TY>(p.y, row * p.dim + e, (v[i] - mean) * rstd * p.w[e] + (p.b ? p.b[e] : 0.f));
+  }
+}
+
+template <typename TY, typename TH>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_any_kernel(const LnBwdParams p) {
+  __shared__ float red[4][2][LN_MAXE * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float aw[LN_MAXE], ab[LN_MAXE];
+#pragma unroll
+  for (int i = 0; i < LN_MAXE; ++i) aw[i] = ab[i] = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < p.rows; row += (int64_t)gridDim.x * 4) {
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float g[LN_MAXE], xh[LN_MAXE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXE; ++i) {
+      const int e = lane + 64 * i;
+      g[i] = xh[i] = 0.f;
+      if (e < p.dim) {
+        const float d = ln_ld<TY>(p.dy, row * p.dim + e);
+        xh[i] = (p.xr[row * p.dim + e] - mean) * rstd;
+        g[i] = d * p.w[e];
+        s1 += g[i];
+        s2 += g[i] * xh[i];
+        aw[i] += d * xh[i];
+        ab[i] += d;
+      }
+    }
+    const float c1 = wave_sum(s1) / p.dim, c2 = wave_sum(s2) / p.dim;
+#pragma unroll
+    for (int i = 0; i < LN_MAXE; ++i) {
+      const int e = lane + 64 * i;
+      if (e < p.dim) {
+        float o = rstd * (g[i] - c1 - xh[i] * c2);
+        if (p.dres) o += p.dres[row * p.dim + e];
+        if (p.dx32) p.dx32[row * p.dim + e] = o;
+        if (p.dxh) ln_st<TH>(p.dxh, row * p.dim + e, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXE; ++i) {
+    const int e = lane + 64 * i;
+    if (e < p.dim) {
+      red[wv][0][e] = aw[i];
+      red[wv][1][e] = ab[i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * p.dim; e += 256) {
+    const int k = e / p.dim, c = e % p.dim;
+    p.slab[((int64_t)blockIdx.x * 2 + k) * p.dim + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
+  }
+}
+
 constexpr int kLnBwdGroups = 256;
 
 }  // namespace cum
@@ -251,8 +350,7 @@ constexpr int kLnBwdGroups = 256;
 using namespace cum;
 
 static int ln_check(int64_t batch, int32_t len, int32_t dim) {
-  CUM_REQUIRE(batch >= 0 && len >= 0 && dim >= 8 && dim % 8 == 0 && dim <= 64 * 8 * LN_MAXCH,
-              "add_layernorm: d_model must be a multiple of 8 and <= 2048");
+  CUM_REQUIRE(batch >= 0 && len >= 0 && dim >= 1 && dim <= 64 * 8 * LN_MAXCH, "add_layernorm: d_model must be 1 ... 2048");
   return CUM_OK;
 }
 
@@ -266,12 +364,31 @@ extern "C" int cum_add_layernorm_fwd(int32_t x_dtype, int32_t y_dtype, int64_t b
   const int64_t rows = batch * len;
   if (rows == 0) return CUM_OK;
   CUM_REQUIRE(x && weight && residual_out && y && mean && rstd, "add_layernorm_fwd: null pointer");
-  CUM_REQUIRE(x_sb % 8 == 0 && x_sl % 8 == 0, "add_layernorm_fwd: hidden strides must keep 16-byte alignment");
+  // vector path: 16-byte aligned rows everywhere; else the element-access kernels (any d_model, any strides)
+  const bool vec = dim % 8 == 0 && x_sb % 8 == 0 && x_sl % 8 == 0 && ((uintptr_t)x & 15) == 0;
   LnParams p{};
   p.x = x; p.res = residual; p.w = weight; p.b = bias; p.res_out = residual_out; p.y = y; p.mean = mean; p.rstd = rstd;
   p.x_sb = x_sb; p.x_sl = x_sl; p.rows = rows; p.len = len; p.dim = dim; p.nch = dim / 8; p.eps = eps;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (!vec) {
+    if (x_dtype == CUM_F16 && y_dtype == CUM_F16)
+      hipLaunchKernelGGL((add_layernorm_fwd_any_kernel<f16, f16>), grid, block, 0, st, p);
+    else if (x_dtype == CUM_F16)
+      hipLaunchKernelGGL((add_layernorm_fwd_any_kernel<f16, float>), grid, block, 0, st, p);
+    else if (y_dtype == CUM_F16)
+      hipLaunchKernelGGL((add_layernorm_fwd_any_kernel<float, f16>), grid, block, 0, st, p);
+    else if (x_dtype == CUM_BF16 && y_dtype == CUM_BF16)
+      hipLaunchKernelGGL((add_layernorm_fwd_any_kernel<__bf16, __bf16>), grid, block, 0, st, p);
+    else if (x_dtype == CUM_BF16)
+      hipLaunchKernelGGL((add_layernorm_fwd_any_kernel<__bf16, float>), grid, block, 0, st, p);
+    else if (y_dtype == CUM_BF16)
+      hipLaunchKernelGGL((add_layernorm_fwd_any_kernel<float, __bf16>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((add_layernorm_fwd_any_kernel<float, float>), grid, block, 0, st, p);
+    CUM_CHECK_LAUNCH();
+    return CUM_OK;
+  }
   if (x_dtype == CUM_F16 && y_dtype == CUM_F16)
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<f16, f16>), grid, block, 0, st, p);
   else if (x_dtype == CUM_F16)
@@ -312,6 +429,22 @@ extern "C" int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t r
   p.dx32 = dx32; p.dxh = dxh; p.slab = workspace; p.rows = rows; p.dim = dim; p.nch = dim / 8;
   const int groups = (int)((rows + 3) / 4 < kLnBwdGroups ? (rows + 3) / 4 : kLnBwdGroups);
   dim3 grid(groups), block(256);
+  if (dim % 8 != 0) {
+    if (y_dtype == CUM_F16 && h_dtype == CUM_F16)
+      hipLaunchKernelGGL((add_layernorm_bwd_any_kernel<f16, f16>), grid, block, 0, st, p);
+    else if (y_dtype == CUM_F16)
+      hipLaunchKernelGGL((add_layernorm_bwd_any_kernel<f16, float>), grid, block, 0, st, p);
+    else if (h_dtype == CUM_F16)
+      hipLaunchKernelGGL((add_layernorm_bwd_any_kernel<float, f16>), grid, block, 0, st, p);
+    else if (y_dtype == CUM_BF16 && h_dtype == CUM_BF16)
+      hipLaunchKernelGGL((add_layernorm_bwd_any_kernel<__bf16, __bf16>), grid, block, 0, st, p);
+    else if (y_dtype == CUM_BF16)
+      hipLaunchKernelGGL((add_layernorm_bwd_any_kernel<__bf16, float>), grid, block, 0, st, p);
+    else if (h_dtype == CUM_BF16)
+      hipLaunchKernelGGL((add_layernorm_bwd_any_kernel<float, __bf16>), grid, block, 0, st, p);
+    else
+      hipLaunchKernelGGL((add_layernorm_bwd_any_kernel<float, float>), grid, block, 0, st, p);
+  } else
   if (y_dtype == CUM_F16 && h_dtype == CUM_F16)
     hipLaunchKernelGGL((add_layernorm_bwd_kernel<f16, f16>), grid, block, 0, st, p);
   else if (y_dtype == CUM_F16)

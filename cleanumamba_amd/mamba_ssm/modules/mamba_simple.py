@@ -45,7 +45,10 @@ class _ProjFn(torch.autograd.Function):
         N, K = w.shape
         xc = x if x.dtype == cd else x.to(cd)
         x2 = xc.reshape(-1, K)
-        y = cs.proj_fwd(x2, w, cd)
+        if N % 8:        # odd widths (pruned checkpoints): rows of the result keep 16-byte alignment in a padded buffer
+            y = cs.proj_fwd(x2, w, cd, out=torch.empty(x2.shape[0], cs.rup(N, 8), dtype=cd, device=x2.device)[:, :N])
+        else:
+            y = cs.proj_fwd(x2, w, cd)
         ctx.save_for_backward(x2, w)
         ctx.x_dtype, ctx.w_dtype, ctx.cd, ctx.x_shape = x.dtype, w.dtype, cd, x.shape
         # the parameter itself (identity only: gradient-sink lookup), when the weight is an f32 leaf
@@ -62,8 +65,18 @@ class _ProjFn(torch.autograd.Function):
         d2 = (dy if dy.dtype == cd else dy.to(cd)).reshape(-1, N)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = cs.proj_dgrad(d2, w, cd).view(ctx.x_shape).to(ctx.x_dtype)
-        if ctx.needs_input_grad[1]:
+            if K % 8:
+                dx = cs.proj_dgrad(d2, w, cd, out=torch.empty(d2.shape[0], cs.rup(K, 8), dtype=cd, device=d2.device)[:, :K])
+                dx = dx.reshape(ctx.x_shape).to(ctx.x_dtype)
+            else:
+                dx = cs.proj_dgrad(d2, w, cd).view(ctx.x_shape).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1] and (N % 8 or K % 8):
+            # cum_gemm_tn takes widths that are multiples of 8: zero columns add nothing to the real entries
+            N8, K8 = cs.rup(N, 8), cs.rup(K, 8)
+            dw, _ = cs.wgrad(F.pad(d2, (0, N8 - N)), 0, N8, N8, F.pad(x2, (0, K8 - K)), 0, K8, K8, x2.shape[0],
+                             want_bias=False)
+            dw = dw[:N, :K].to(ctx.w_dtype)
+        elif ctx.needs_input_grad[1]:
             if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
                 x2 = x2.contiguous()
             if d2.stride(1) != 1 or d2.stride(0) % 8 or d2.data_ptr() % 16:
@@ -251,12 +264,13 @@ _FUSED_STEP = os.environ.get("CUM_FUSED_STEP", "1") != "0"  # "0": Block + Mamba
 
 def _proj(x, w, bias=None):
     """F.linear(x, w) of a bias-free projection on the library's GEMM kernels (see _ProjFn): training and inference,
-    f32 and autocast.  Shapes the kernels do not take (a bias, channel counts that are not multiples of 8: pruned
-    checkpoints) stay on F.linear; the per-token streaming step has its own kernels (cum_mamba_step / cum_small_linear).
+    f32 and autocast, any channel counts (the pruned checkpoints' d_model 55, 114, 477 ...: operands and results are padded
+    to 16-byte rows).  Only a projection WITH a bias (never built by the reference's configs) stays on F.linear; the
+    per-token streaming step has its own kernels (csrc/hop.hip, cum_mamba_step).
     The choice must not depend on the number of rows: two f32 implementations of one GEMM differ in the last bit, which
     flips enough ReLU gates downstream to move end-to-end gradients by 1e-3 -- a 2-rank run and its single-process
     twin would no longer agree (tools/debug_batch_invariance.py)."""
-    if bias is None and x.is_cuda and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+    if bias is None and x.is_cuda:
         cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
         if cd in hip.IO_TYPES and (cd in hip.HALF_TYPES or w.dtype == torch.float32) and x.dtype in hip.IO_TYPES:
             return _ProjFn.apply(x, w, cd)
@@ -373,17 +387,17 @@ class Mamba(nn.Module):
         assert hidden_states.shape[1] == 1, "step() decodes one token at a time"
         dt_rank = self.dt_proj.weight.shape[1]
         d_state = (self.x_proj.weight.shape[0] - dt_rank) // 2
-        xz = F.linear(hidden_states.squeeze(1), self.in_proj.weight, self.in_proj.bias)
+        xz = _proj(hidden_states.squeeze(1), self.in_proj.weight, self.in_proj.bias)
         x, z = xz.chunk(2, dim=-1)
         x = causal_conv1d_update(x.float(), conv_state, self.conv1d.weight.squeeze(1).float(),
                                  None if self.conv1d.bias is None else self.conv1d.bias.float(), self.activation)
-        x_db = F.linear(x, self.x_proj.weight)
+        x_db = _proj(x, self.x_proj.weight)
         dt, Bv, Cv = torch.split(x_db, [dt_rank, d_state, d_state], dim=-1)
-        dt = F.linear(dt, self.dt_proj.weight)
+        dt = _proj(dt, self.dt_proj.weight)
         A = self._neg_exp_A_log()
         y = selective_state_update(ssm_state, x, dt.float(), A, Bv, Cv, self.D.float(), z=z.float(),
                                    dt_bias=self.dt_proj.bias.float(), dt_softplus=True)
-        out = F.linear(y.to(hidden_states.dtype), self.out_proj.weight, self.out_proj.bias)
+        out = _proj(y.to(hidden_states.dtype), self.out_proj.weight, self.out_proj.bias)
         return out.unsqueeze(1), conv_state, ssm_state
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):

@@ -3,8 +3,8 @@
 Arithmetic of mamba-ssm's ``Block.forward`` with ``fused_add_norm=False`` as the reference runs it
 (src/network/CleanUMamba.py:156-189, 288-294):  ``residual = hidden + residual`` (fp32),
 ``hidden = LayerNorm(residual)``.  Upstream offers the same fusion as a Triton kernel (``fused_add_norm=True``,
-never enabled by the reference); this is the MI355X counterpart and it is used whenever the shapes allow
-(d_model a multiple of 8, <= 2048), otherwise the caller falls back to the separate torch ops.
+never enabled by the reference); this is the MI355X counterpart: d_model <= 2048 (16-byte vector kernels when d_model
+and the strides are multiples of 8, element-access kernels for the pruned checkpoints' odd widths).
 """
 import os
 
@@ -18,9 +18,8 @@ _ENABLED = os.environ.get("CUM_FUSED_LN", "1") != "0"      # "0": the separate t
 def supported(hidden, norm):
     dim = hidden.shape[-1]
     return (_ENABLED and hidden.is_cuda and isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine
-            and norm.weight.dtype == torch.float32 and dim % 8 == 0 and dim <= 2048 and hidden.dim() == 3
-            and hidden.stride(2) == 1 and hidden.stride(0) % 8 == 0 and hidden.stride(1) % 8 == 0
-            and hidden.data_ptr() % 16 == 0 and hidden.dtype in hip.IO_TYPES)
+            and norm.weight.dtype == torch.float32 and 1 <= dim <= 2048 and hidden.dim() == 3
+            and hidden.stride(2) == 1 and hidden.dtype in hip.IO_TYPES)       # (any d_model / strides: element kernels)
 
 
 class AddLayerNormFn(torch.autograd.Function):

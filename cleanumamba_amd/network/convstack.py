@@ -937,8 +937,12 @@ def proj_fwd(x2, w, dt, out=None):
     a = _gemm_rows(x2, Kp)
     M = a.shape[0]
     if out is None:
-        out = torch.empty(M, N, dtype=dt, device=a.device)
-    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, out.stride(0), M, 1 << 30, 1 << 30, hip.EPI_BIAS, N,
+        out = torch.empty(M, rup(N, 8), dtype=dt, device=a.device)[:, :N]
+    # odd widths (pruned checkpoints): whole 16-byte groups are stored, the columns past N are the packed operand's
+    # zero rows and land in the padding of the row
+    ns = N if N % 8 == 0 else rup(N, 8)
+    assert out.stride(0) >= ns
+    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, out.stride(0), M, 1 << 30, 1 << 30, hip.EPI_BIAS, ns,
          split_k=N <= 256)
     return out
 
@@ -952,8 +956,10 @@ def proj_dgrad(dy2, w, dt, out=None, res=None, tail_ok=False):
     a = _gemm_rows(dy2, Kp, tail_ok)
     M = a.shape[0]
     if out is None:
-        out = torch.empty(M, K, dtype=dt, device=a.device)
-    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, out.stride(0), M, 1 << 30, 1 << 30, hip.EPI_BIAS, K,
+        out = torch.empty(M, rup(K, 8), dtype=dt, device=a.device)[:, :K]
+    ks = K if K % 8 == 0 else rup(K, 8)
+    assert out.stride(0) >= ks and (res is None or K % 8 == 0)
+    gemm(a, 0, a.stride(0), wp, _zero_bias(Np, a.device), out, 0, out.stride(0), M, 1 << 30, 1 << 30, hip.EPI_BIAS, ks,
          res=res, r_off=0, ldr=res.stride(0) if res is not None else 0, split_k=K <= 256 and res is None)
     return out
 

@@ -345,7 +345,9 @@ int cum_stft_fused_bwd(const float *x, const float *y, int64_t batch, int64_t le
  * runs it, src/network/CleanUMamba.py:156-189, 288-294, and the final add + norm_f, :292-294):
  *   residual_out = x + residual (fp32);   y = (residual_out - mean) * rstd * weight + bias
  * x: (batch, len, dim) of x_dtype with element strides (x_sb, x_sl, 1); residual: contiguous fp32 or NULL;
- * y: contiguous, y_dtype; mean, rstd: fp32 [batch*len] (saved for the backward).  dim multiple of 8, <= 2048.
+ * y: contiguous, y_dtype; mean, rstd: fp32 [batch*len] (saved for the backward).  1 <= dim <= 2048: 16-byte vector
+ * kernels when dim and the hidden strides are multiples of 8, element-access kernels otherwise (pruned checkpoints'
+ * d_model 55, 114, 477 ...).
  * Backward: dy (y_dtype) and dres_out (fp32 or NULL, the gradient arriving at residual_out) ->
  *   dx = d(x) = d(residual) written as fp32 (dx32, may be NULL) and/or in h_dtype (dxh, may be NULL);
  *   dweight, dbias (dbias may be NULL): fully overwritten.  workspace: cum_add_layernorm_bwd_workspace_elems(dim) fp32. */

@@ -286,3 +286,85 @@ def test_ping_pong_kernel_ragged_rows_every_epilogue(cuda, dtype, epi):
         key = (epi, M, N, K, K, ldc, 5003, 5001, n_store, has_res, ldr, has_aux, ldz, has_aux2, ldy, gate_only, mask_bits,
                False, epi != hip.EPI_GLU_BWD, None, 0, 0)
         _check_nt(cuda, dtype, key, f"nt9.ragged[{dtype}:epi{epi}:{ci}]")
+
+
+def _e6_net(cuda):
+    from conftest import golden_json, load_golden
+    from oracle import synth
+    from cleanumamba_amd.network import CleanUMamba
+    g = load_golden("e2e_e6_synth")
+    meta = golden_json(g["meta"])
+    sd = synth.fill_state_dict(dict(zip(meta["keys"], meta["shapes"])), seed=meta["seed"])
+    net = CleanUMamba(**meta["cfg"])
+    net.load_state_dict(sd, strict=True)
+    return net.to(cuda).eval(), sd
+
+
+def test_every_gemm_of_the_e6_b32_forward(cuda):
+    """BASELINE config 2 at its OWN batch: the E6 (27.2 M) no-grad forward on 32 clips of 10 s under f16 autocast (M =
+    32 x 80 032 ... 32 x 2 501 rows, other tile choices than the B = 16 E8 step): every distinct cum_gemm_nt call is
+    recorded, re-issued through the C ABI on seeded operands and compared with an f64 product; the library reports
+    which launches run on the 256 x 256 ping-pong kernel."""
+    from cleanumamba_amd import hip
+    from cleanumamba_amd.network import convstack as cs
+    dtype = torch.float16
+    net, _ = _e6_net(cuda)
+    g = torch.Generator(device=cuda).manual_seed(4321)
+    noisy = 0.1 * torch.randn(32, 1, CLIP, generator=g, device=cuda)
+    nt = {}
+    real_gemm = cs.gemm
+
+    def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_store, res=None, r_off=0, ldr=0,
+             aux=None, x_off=0, ldz=0, geo=None, aux2=None, y_off=0, ldy=0, gate_only=False, mask_bits=False,
+             split_k=False):
+        key = (epilogue, M, Wp.shape[0], Wp.shape[1], lda, ldc, min(pitch, 1 << 30), min(valid, 1 << 30), n_store,
+               res is not None, ldr if res is not None else 0, aux is not None, ldz if aux is not None else 0,
+               aux2 is not None, ldy if aux2 is not None else 0, bool(gate_only), bool(mask_bits), bool(split_k),
+               bias is not None, (geo.head, geo.tail) if geo is not None else None, a_off, o_off)
+        nt[key] = nt.get(key, 0) + 1
+        return real_gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_store, res=res,
+                         r_off=r_off, ldr=ldr, aux=aux, x_off=x_off, ldz=ldz, geo=geo, aux2=aux2, y_off=y_off, ldy=ldy,
+                         gate_only=gate_only, mask_bits=mask_bits, split_k=split_k)
+
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        net(noisy)                                # first call: packs, caches
+        cs.gemm = gemm
+        try:
+            y = net(noisy)
+        finally:
+            cs.gemm = real_gemm
+    torch.cuda.synchronize()
+    assert y.shape == (32, 1, CLIP) and bool(torch.isfinite(y).all())
+    del net, y, noisy
+    torch.cuda.empty_cache()
+    lib, dc = hip.lib(), hip.dtype_code(dtype)
+
+    def nt_tile(key):
+        d = hip.GemmDesc()
+        d.dtype, d.M, d.N, d.K, d.allow_split_k = dc, key[1], key[2], key[3], 2 if key[17] else 0
+        return lib.cum_gemm_nt_tile(ctypes.byref(d))
+    tiles = {k: nt_tile(k) for k in nt}
+    # 4 unfused encoder layers x 2 + 5 unfused decoder layers x 2 + the 1x1 convs + 3 blocks x 4 projections
+    assert sum(nt.values()) >= 30, sum(nt.values())
+    on9 = {(k[0], k[1]) for k, t in tiles.items() if t == 512}
+    for T in (10002, 5000, 2499):                 # enc3 / enc4 / enc5 (and their decoder mirrors): 768-wide layers
+        assert any(m == 32 * (T + 2) for _, m in on9), (T, sorted(on9))
+    for i, key in enumerate(nt):
+        _check_nt(cuda, dtype, key, f"e6b32.nt[{i}:epi{key[0]}:{key[1]}x{key[2]}x{key[3]}:tile{tiles[key]}]")
+        torch.cuda.empty_cache()
+
+
+def test_e6_b32_f32_forward_against_the_oracle_on_two_clips(cuda):
+    """The same configuration in f32 against oracle.cleanumamba_ref.forward_ref (CPU) on the first and the last clip of
+    the batch: north_star's 1e-4 at BASELINE config 2's own batch and length."""
+    from oracle import cleanumamba_ref as R
+    net, sd = _e6_net(cuda)
+    g = torch.Generator().manual_seed(77)
+    noisy = 0.1 * torch.randn(32, 1, CLIP, generator=g)
+    with torch.no_grad():
+        y = net(noisy.to(cuda)).cpu()
+        pick = [0, 31]
+        ref = R.forward_ref(sd, noisy[pick])
+    err = record("e6b32.f32_forward_vs_oracle", rel_l2(y[pick], ref))
+    assert err < 1e-4
+    assert rel_l2(y[31:32], ref[1:2]) < 1e-4

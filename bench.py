@@ -49,10 +49,14 @@ def parse():
                          "optimizer state are f32 in every mode")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph", action="store_true",
-                    help="N > 1 only: the captured step ([graph] -> one whole-buffer all-reduce -> [graph]) instead of the "
-                         "default eager backward with per-bucket all-reduce overlap (the captured form is opt-in until it "
-                         "has run on several real GPUs over RCCL; one GPU always replays one graph unless --no-graph)")
+                    help="N > 1 only: time ONLY the captured three-graph step (default for N > 1: both forms are timed, "
+                         "the eager backward with per-bucket all-reduce overlap and the three-graph form, and the faster "
+                         "one is the headline; --no-graph: only the eager form; one GPU always replays one graph unless "
+                         "--no-graph)")
     ap.add_argument("--rank-timeout", type=float, default=1500.0, help="seconds the launcher waits for its ranks")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the ranks to their GPUs' NUMA nodes")
+    ap.add_argument("--no-baseline-mode", action="store_true",
+                    help="N > 1: skip the third timed loop (the same GPUs without gradient exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-clip", type=int, default=CLIP, help="samples in the CPU-baseline clip")
@@ -476,6 +480,46 @@ def _free_port():
     return port
 
 
+def _cpus_of_rank(local_rank, local_world, sys_root="/sys", allowed=None):
+    """CPU set for one rank of a node: the cores of the NUMA node its GPU hangs off (AMD display-class PCI devices in bus
+    order = HIP's device order), shared evenly with the other ranks of that node; an even contiguous split of the
+    allowed cores when sysfs does not tell.  Pure host logic (no GPU call): runs in the rank before anything else."""
+    allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+
+    def cpulist(text):
+        out = []
+        for part in text.strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                out += range(int(a), int(b or a) + 1)
+        return out
+    try:
+        gpus = []
+        pci = os.path.join(sys_root, "bus", "pci", "devices")
+        for bdf in sorted(os.listdir(pci)):
+            d = os.path.join(pci, bdf)
+            with open(os.path.join(d, "vendor")) as f:
+                vendor = f.read().strip()
+            with open(os.path.join(d, "class")) as f:
+                cls = f.read().strip()
+            if vendor == "0x1002" and cls.startswith(("0x0302", "0x0380", "0x0300", "0x1200")):
+                with open(os.path.join(d, "numa_node")) as f:
+                    gpus.append(int(f.read().strip()))
+        if len(gpus) >= local_world and gpus[local_rank] >= 0:
+            node = gpus[local_rank]
+            with open(os.path.join(sys_root, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+                cores = [c for c in cpulist(f.read()) if c in set(allowed)]
+            peers = [r for r in range(local_world) if gpus[r] == node]
+            share = len(cores) // len(peers)
+            if share >= 1:
+                i = peers.index(local_rank)
+                return cores[i * share:(i + 1) * share]
+    except (OSError, ValueError, IndexError):
+        pass
+    share = max(1, len(allowed) // max(local_world, 1))
+    return allowed[local_rank * share:(local_rank + 1) * share] or allowed
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with no rank environment: start N FRESH rank processes (the reference starts its own
     ranks the same way, src/training/train_distributed.py:172-178) -- before this process has made any GPU call; it
@@ -486,7 +530,7 @@ def launch_ranks(args):
     n = args.gpus
     env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))     # cores this process may use
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     outs, logs, procs = [], [], []
     for r in range(n):
@@ -533,6 +577,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        # a rank that hangs (a collective one peer never joined) says where: all thread stacks go to stderr shortly
+        # before the launcher's deadline, and the launcher relays every rank's stderr when it gives up
+        import faulthandler
+        faulthandler.dump_traceback_later(max(30.0, 0.8 * args.rank_timeout), exit=False)
+    cpus = None
+    if world > 1 and not args.no_pin:
+        # every rank on the cores of its GPU's NUMA node, before any GPU call: the eager multi-rank step spends ~16 ms of
+        # Python per 20 ms step, a rank that migrates between sockets is the scaling curve's jitter
+        try:
+            cpus = _cpus_of_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            os.sched_setaffinity(0, cpus)
+            torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))      # no more threads than cores
+        except (OSError, ValueError):
+            cpus = None
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = torch.cuda.device_count()
@@ -561,14 +620,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    torch.manual_seed(0)                                 # reference seeds 0 (src/training/train.py:51-53)
-    net = Net("CleanUMamba", E8).to(dev).train()
-    if world > 1 or alone:
-        net = apply_gradient_allreduce(net)
     ac = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": None}[args.dtype]
-    # use_graph=None: TrainStep's default -- one graph for one process, the eager overlapped exchange for several ranks
-    step = TrainStep(net, autocast_dtype=ac, use_graph=False if args.no_graph else (True if args.graph else None))
-
     B = args.batch_per_gpu
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     clean = 0.05 * torch.randn(B, 1, CLIP, generator=g, device=dev)
@@ -580,44 +632,88 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    settle = 0
-    if ac == torch.float16:
-        # Dynamic loss scaling starts at 65536 (GradScaler's default, as in the reference) and backs off while the
-        # first scaled gradients overflow; those optimizer steps are skipped.  Let the scale settle before the W
-        # warm-up steps so that the timed region holds real steps only (untimed, at most 24 extra steps).
-        clean_run, skipped = 0, 0.0
-        while clean_run < 2 and settle < 24:
-            step(clean, noisy)
-            settle += 1
-            now = float(step.optimizer.state_vec[9])
-            clean_run = clean_run + 1 if now == skipped else 0
-            skipped = now
-    for _ in range(args.warmup):
-        loss, _ = step(clean, noisy)
-    skipped_before = float(step.optimizer.state_vec[9]) if step.flat else 0.0
-    barrier()
-    host0 = step.host_seconds
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step(clean, noisy)
-    host_ms = 1e3 * (step.host_seconds - host0) / max(args.steps, 1)      # enqueue time only: nothing inside synchronises
-    barrier()
-    elapsed = time.perf_counter() - t0
-    host_ms_ranks = [host_ms]
-    if world > 1:
+    def run_mode(exchange, use_graph):
+        """A fresh model + train step in one form, settled, warmed up, then EXACTLY args.steps steps between two
+        barriers; -> dict(ms, elapsed (max over ranks), host ms by rank, loss, graph status, optimizer info, net)."""
+        torch.manual_seed(0)                             # reference seeds 0 (src/training/train.py:51-53)
+        net = Net("CleanUMamba", E8).to(dev).train()
+        if exchange:
+            net = apply_gradient_allreduce(net)
+        # use_graph=None: TrainStep's default -- one graph for one process, the eager overlapped exchange for several ranks
+        step = TrainStep(net, autocast_dtype=ac, use_graph=use_graph)
+        settle = 0
+        if ac == torch.float16:
+            # Dynamic loss scaling starts at 65536 (GradScaler's default, as in the reference) and backs off while the
+            # first scaled gradients overflow; those optimizer steps are skipped.  Let the scale settle before the W
+            # warm-up steps so that the timed region holds real steps only (untimed, at most 24 extra steps).
+            clean_run, skipped = 0, 0.0
+            while clean_run < 2 and settle < 24:
+                step(clean, noisy)
+                settle += 1
+                now = float(step.optimizer.state_vec[9])
+                clean_run = clean_run + 1 if now == skipped else 0
+                skipped = now
+        for _ in range(args.warmup):
+            loss, _ = step(clean, noisy)
+        skipped_before = float(step.optimizer.state_vec[9]) if step.flat else 0.0
+        barrier()
+        host0 = step.host_seconds
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = step(clean, noisy)
+        host_ms = 1e3 * (step.host_seconds - host0) / max(args.steps, 1)  # enqueue time only: nothing inside synchronises
+        barrier()
+        elapsed = time.perf_counter() - t0
+        host_ms_ranks = [host_ms]
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed, host_ms], device=dev, dtype=torch.float64)
+            gathered = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            elapsed = max(float(x[0]) for x in gathered)                  # MAX over ranks
+            host_ms_ranks = [float(x[1]) for x in gathered]
+        info = {"optimizer": "flat clip + Adam (csrc/optim.hip)" if step.flat else "torch.optim.Adam"}
+        if step.flat:
+            sv = step.optimizer.state_vec.cpu()
+            info.update(loss_scale=float(sv[3]) if ac == torch.float16 else None, settle_steps=settle,
+                        skipped_steps_in_timed_region=float(sv[9]) - skipped_before, adam_steps_total=float(sv[5]))
+        return {"ms": 1e3 * elapsed / args.steps, "elapsed": elapsed, "host": host_ms_ranks, "loss": float(loss),
+                "graph": step.graph_status, "optim": info, "net": net}
+
+    exchanging = world > 1 or alone
+    modes = {}
+    if not exchanging:
+        best = run_mode(False, False if args.no_graph else None)
+    elif args.no_graph or args.graph:
+        best = run_mode(True, not args.no_graph)
+    else:
+        # several ranks: BOTH step forms in one invocation (the first multi-GPU run must not measure half of what
+        # matters): the eager step with the per-bucket exchange overlapped, then the three-graph form; the headline is the
+        # faster one.  Then the same GPUs without any exchange: what the data-parallel step adds on this node.
+        eager = run_mode(True, False)
+        eager.pop("net")
+        torch.cuda.empty_cache()
+        graph = run_mode(True, True)
+        modes = {"eager_overlapped": round(eager["ms"], 3), "three_graphs": round(graph["ms"], 3),
+                 "three_graphs_status": graph["graph"]}
+        best = graph if graph["ms"] < eager["ms"] and graph["graph"] == "captured" else dict(eager, net=graph["net"])
+        if best is not graph:
+            graph.pop("net", None)
+        torch.cuda.empty_cache()
+        if not args.no_baseline_mode:
+            solo = run_mode(False, None)
+            solo.pop("net")
+            torch.cuda.empty_cache()
+            modes["no_exchange"] = round(solo["ms"], 3)
+            modes["exchange_exposed_ms"] = round(min(eager["ms"], graph["ms"]) - solo["ms"], 3)
+    elapsed, host_ms_ranks, final_loss, graph_status, optim_info, net = (best["elapsed"], best["host"], best["loss"],
+                                                                         best["graph"], best["optim"], best["net"])
+    rccl_ranks = None
+    if exchanging:
         import torch.distributed as dist
-        t = torch.tensor([elapsed, host_ms], device=dev, dtype=torch.float64)
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        elapsed = max(float(x[0]) for x in gathered)                      # MAX over ranks
-        host_ms_ranks = [float(x[1]) for x in gathered]
-    final_loss = float(loss)
-    graph_status = step.graph_status
-    optim_info = {"optimizer": "flat clip + Adam (csrc/optim.hip)" if step.flat else "torch.optim.Adam"}
-    if step.flat:
-        sv = step.optimizer.state_vec.cpu()
-        optim_info.update(loss_scale=float(sv[3]) if ac == torch.float16 else None, settle_steps=settle,
-                          skipped_steps_in_timed_region=float(sv[9]) - skipped_before, adam_steps_total=float(sv[5]))
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                              # the rank count the collective itself observes
+        rccl_ranks = int(one.item())
 
     if rank == 0:
         gb = B * world
@@ -632,12 +728,14 @@ def main():
                           "parallelism": f"dp{world}", "weights": "random init (reference init, seed 0)"},
                "final_loss": round(final_loss, 5), "step_graph": graph_status, "optimizer": optim_info,
                "host_ms_per_step_by_rank": [round(h, 3) for h in host_ms_ranks],
+               "modes": modes or None, "collective_ranks_observed": rccl_ranks,
+               "backend": (os.environ.get("CUM_DIST_BACKEND", "nccl") if exchanging else None),
+               "cpu_affinity_rank0": (f"{len(cpus)} cores: {cpus[0]}-{cpus[-1]}" if cpus else None),
                "exchange": ("none" if world == 1 and not alone else
                             "three graphs: all-reduce (AVG) of the decoder + bottleneck gradients (106 MB) beside the captured "
                             "encoder backward, all-reduce of the encoder's (59 MB) after it, then the captured optimizer section"
                             if graph_status == "captured" else "per-bucket all-reduce overlapped with the eager backward")}
         if not args.no_roofline:
-            del step, loss
             torch.cuda.empty_cache()
             kdt = ac if ac is not None else torch.bfloat16
             out["roofline"] = tn_roofline(dev, kdt)

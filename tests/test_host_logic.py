@@ -166,6 +166,41 @@ def test_bench_launcher_starts_ranks_and_fails_fast_without_a_gpu():
     assert time.time() - t0 < 100
 
 
+def test_bench_pins_ranks_to_the_numa_node_of_their_gpu(tmp_path):
+    """bench.py --gpus N: every rank's CPU set comes from the NUMA node of its GPU (AMD display-class PCI devices in bus
+    order), shared with the other ranks of that node; an even split when sysfs does not tell."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sysr = tmp_path / "sys"
+    nodes = [0, 0, 1, 1]
+    for i, node in enumerate(nodes):
+        d = sysr / "bus" / "pci" / "devices" / f"0000:{0x10 + i:02x}:00.0"
+        d.mkdir(parents=True)
+        (d / "vendor").write_text("0x1002\n")
+        (d / "class").write_text("0x038000\n")
+        (d / "numa_node").write_text(f"{node}\n")
+    d = sysr / "bus" / "pci" / "devices" / "0000:01:00.0"          # an unrelated device in front of them
+    d.mkdir(parents=True)
+    (d / "vendor").write_text("0x8086\n")
+    (d / "class").write_text("0x020000\n")
+    (d / "numa_node").write_text("0\n")
+    for node, cl in ((0, "0-7,16-23"), (1, "8-15,24-31")):
+        nd = sysr / "devices" / "system" / "node" / f"node{node}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cl + "\n")
+    allowed = set(range(32))
+    got = [bench._cpus_of_rank(r, 4, str(sysr), allowed) for r in range(4)]
+    assert got[0] == [0, 1, 2, 3, 4, 5, 6, 7] and got[1] == [16, 17, 18, 19, 20, 21, 22, 23]
+    assert got[2] == [8, 9, 10, 11, 12, 13, 14, 15] and got[3] == [24, 25, 26, 27, 28, 29, 30, 31]
+    # no sysfs: contiguous even split of what the process may use
+    got = [bench._cpus_of_rank(r, 4, str(tmp_path / "nothing"), set(range(8))) for r in range(4)]
+    assert got == [[0, 1], [2, 3], [4, 5], [6, 7]]
+
+
 def test_flat_adam_checkpoint_rules_and_sink_registry():
     """FlatAdam.load_state_dict: a checkpoint written by a run WITHOUT loss scaling must not overwrite the live loss
     scale of an fp16 run (scale 1.0 would underflow the gradients for thousands of steps), one written with scaling

@@ -643,18 +643,19 @@ def test_one_rank_rccl_group_runs_every_collective(cuda, tmp_path, graph):
     assert max(abs(x - y) for x, y in zip(a["losses"], b["losses"])) < 1e-5 * max(b["losses"])
 
 
-@pytest.mark.parametrize("captured", [False, True])
-def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path, captured):
+@pytest.mark.parametrize("mode", ["both", "graph", "eager"])
+def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path, mode):
     """`python bench.py --gpus 2 ...` with no rank environment must start its own two ranks (fresh processes, here both on
     the one GPU with gradients over gloo), and print ONE JSON line for n_gpus = 2 -- the shape of the driver's command.
-    Default for several ranks: the eager step with the per-bucket exchange overlapped with backward; `--graph` opts into
-    [graph] -> one all-reduce -> [graph]."""
+    Default for several ranks: BOTH step forms are timed in the one invocation (the eager step with the per-bucket
+    exchange overlapped with backward, then the three-graph form, then the same GPUs without exchange) and the faster
+    form is the headline; `--graph` / `--no-graph` time one form only."""
     import json
     torch.cuda.empty_cache()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(CUM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline",
-           "--batch-per-gpu", "2", "--rank-timeout", "600"] + (["--graph"] if captured else [])
+           "--batch-per-gpu", "2", "--rank-timeout", "600"] + {"both": [], "graph": ["--graph"], "eager": ["--no-graph"]}[mode]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=700)
     assert res.returncode == 0, res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -662,5 +663,15 @@ def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path, captured):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 4
     assert out["value"] > 0 and out["scaling"] == "weak" and len(out["host_ms_per_step_by_rank"]) == 2
-    assert out["step_graph"] == ("captured" if captured else "off"), out["step_graph"]
-    assert ("per-bucket" in out["exchange"]) == (not captured), out["exchange"]
+    assert out["collective_ranks_observed"] == 2 and out["backend"] == "gloo"
+    if mode == "both":
+        m = out["modes"]
+        assert m["eager_overlapped"] > 0 and m["three_graphs"] > 0 and m["no_exchange"] > 0
+        assert m["three_graphs_status"] == "captured"
+        assert abs(m["exchange_exposed_ms"] - (min(m["eager_overlapped"], m["three_graphs"]) - m["no_exchange"])) < 2e-3
+        assert abs(out["ms_per_step"] - min(m["eager_overlapped"], m["three_graphs"])) < 2e-3
+        assert out["step_graph"] == ("captured" if m["three_graphs"] < m["eager_overlapped"] else "off")
+    else:
+        assert out["modes"] is None
+        assert out["step_graph"] == ("captured" if mode == "graph" else "off"), out["step_graph"]
+        assert ("per-bucket" in out["exchange"]) == (mode == "eager"), out["exchange"]

@@ -734,8 +734,12 @@ __device__ __forceinline__ void nt_epilogue_any(const GemmParams &p, const f32x4
 // 85 flop/B; 256x256: 128 flop/B), so the largest tile that still fills the chip wins.
 template <typename T, int EPI, int BM, int BN>
 // 16-bit element types: four waves per SIMD (128 VGPRs).  f32 (the parity path) carries 16-byte operand registers
-// through the epilogues and needs up to ~170: it is allowed down to two waves per SIMD instead of spilling.
-__global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 4, 4))) void gemm_nt_kernel(const GemmParams p) {
+// through the epilogues and needs up to ~170: it is allowed down to two waves per SIMD instead of spilling.  So is the
+// GLU-backward epilogue (three operand streams): held to 128 it parked 84 values in AGPRs (v_accvgpr moves in the loop,
+// "desired occupancy 4, final 2"); allowed to choose, it takes 119 VGPRs and no AGPR -- three waves per SIMD (its LDS
+// staging caps it there anyway): 1.06 -> 0.90 ms per step over its five launches, same box.  (The MASK epilogue at 128
+// VGPRs spills 9 dwords; given 140 registers at three waves it ran 6 % slower: it stays at four.)
+__global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 || EPI == EPI_GLU_BWD) ? 2 : 4, 4))) void gemm_nt_kernel(const GemmParams p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;  // 64 bf16 / 32 f32: LDS rows are 128 B either way
   constexpr int NT = BM * BN / 64;   // threads: one wave per 64x64 sub-tile

@@ -519,7 +519,7 @@ __device__ __forceinline__ void fused_load_tables(const FusedStftParams &p, floa
 constexpr int kFusedWaves = 4;
 
 template <int H>
-__global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_eu(H == 256 ? 8 : (H == 512 ? 4 : 2)))) void stft_fused_fwd_kernel(const FusedStftParams p) {
+__global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_eu(H == 256 ? 6 : (H == 512 ? 4 : 2)))) void stft_fused_fwd_kernel(const FusedStftParams p) {
   typedef FusedFft<H> F;
   __shared__ __attribute__((aligned(16))) float4 s_buf[kFusedWaves][F::SLOTS];
   __shared__ float2 s_tw[H + 1];
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
 }
 
 template <int H>
-__global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_eu(H == 256 ? 8 : (H == 512 ? 4 : 2)))) void stft_fused_bwd_kernel(const FusedStftParams p) {
+__global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_eu(H == 256 ? 6 : (H == 512 ? 4 : 2)))) void stft_fused_bwd_kernel(const FusedStftParams p) {
   typedef FusedFft<H> F;
   __shared__ __attribute__((aligned(16))) float4 s_buf[kFusedWaves][F::SLOTS];
   __shared__ float2 s_tw[H + 1];

@@ -65,10 +65,10 @@ def parse():
 
 MFMA_PEAK_TFS = 2500.0      # MI355X_MICROARCH.md: bf16 / f16 dense
 # HBM bytes per gemm_tn launch (kernel + slab reduce), mean over the 10 MFMA-bound encoder weight-gradient shapes the
-# roofline object is quoted on.  NOT measured in this run: a constant from separate `rocprofv3 --pmc FETCH_SIZE` /
-# `--pmc WRITE_SIZE` passes over tools/bench_gemm.py tn, corrected as MI355X_MICROARCH.md prescribes
-# (profiles/r03_gemm_tn_pmc.md: 337.7 MB fetched + 71.1 MB written against 218.1 MB algorithmic).
-TN_TRAFFIC_BYTES = 408.8e6
+# roofline object is quoted on.  NOT measured inside this run (counters need their own rocprofv3 passes): the figure of this
+# round's `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over tools/bench_gemm.py tn, corrected as
+# MI355X_MICROARCH.md prescribes (profiles/r05_gemm_tn_pmc.md: 338.5 MB fetched + 71.1 MB written against 218.1 MB algorithmic).
+TN_TRAFFIC_BYTES = 409.6e6
 # selective-scan issue roof, MEASURED: the bare inner-loop instruction mix of the forward kernel (per state pair v_pk_mul,
 # 2 x v_exp_f32, v_pk_mul, 2 x v_pk_fma) on registers only, every SIMD of the chip busy (tools/clock_probe.hip)
 SCAN_ISSUE_ROOF = 8.6e12     # state updates / s: tools/clock_probe.hip on MI355X (profiles/r02_clock_probe.txt: 8.56-8.89 T/s
@@ -164,7 +164,7 @@ def tn_roofline(dev, dt=torch.bfloat16):
                                        f"launches of one E8 B=16 step ({n_mf} encoder shapes, enc3-enc7; mirrored by the decoder)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFS, 4),
             "traffic": TN_TRAFFIC_BYTES, "traffic_source": "constant: mean HBM bytes per launch over these 10 shapes from separate "
-                                                             "PMC passes (profiles/r03_gemm_tn_pmc.md: 1.87 x algorithmic), not "
+                                                             "PMC passes (profiles/r05_gemm_tn_pmc.md: 1.88 x algorithmic), not "
                                                              "measured in this run",
             "launch_ms": round(ms / n_mf, 4), "algorithmic_flops": fl / n_mf, "launches": n_mf,
             "hbm_bound_shapes": {"shapes": len(rows) - n_mf, "achieved_GBps": round(hb[1] / hb[2] / 1e6, 1),

@@ -481,15 +481,20 @@ class CleanUMamba(nn.Module):
                 return t.transpose(1, 2)[:, :self.decoder[j][2].weight.shape[1]].float()
             return t.float()                                   # cached path: (S, C, 2)
 
+        from ..mamba_ssm.modules.mamba_simple import _proj       # cum_gemm_nt on padded operands: any channel count
+
+        def linear_ct(w2d, x):
+            """(O, C) x (S, C, T) -> (S, O, T) on the library's GEMM (a handful of columns per stream: rows = S * T)."""
+            return _proj(x.transpose(1, 2).contiguous(), w2d.contiguous()).transpose(1, 2)
+
         def conv_t(g, conv):
-            """ConvTranspose1d on a handful of columns as one matmul + K strided adds (the few-column shapes of the
+            """ConvTranspose1d on a handful of columns as one GEMM per tap + K strided adds (the few-column shapes of the
             drain are not worth a MIOpen solver search, and small transposed convs abort in MIOpen on some boxes)."""
             w, K, S = conv.weight.float(), self.kernel_size, self.stride           # (Cin, Cout, K)
             T = g.shape[-1]
-            taps = torch.einsum("bct,cok->bokt", g, w)
             out = conv.bias.float().view(1, -1, 1).repeat(g.shape[0], 1, (T - 1) * S + K)
             for k in range(K):
-                out[..., k:k + (T - 1) * S + 1:S] += taps[:, :, k]
+                out[..., k:k + (T - 1) * S + 1:S] += linear_ct(w[:, :, k].t(), g)
             return out
 
         x = None
@@ -498,7 +503,7 @@ class CleanUMamba(nn.Module):
                 y = tail(0) + dec[2].bias.float().view(1, -1, 1)
             else:
                 x = x + trailing_skip(E - 1 - j)[..., :x.shape[-1]]
-                pre = torch.einsum("oc,bct->bot", dec[0].weight.float().squeeze(-1), x) + dec[0].bias.float().view(1, -1, 1)
+                pre = linear_ct(dec[0].weight.float().squeeze(-1), x) + dec[0].bias.float().view(1, -1, 1)
                 y = conv_t(dec[1](pre), dec[2])
                 y[..., :self.stride] += tail(j)
             if j != E - 1:

@@ -216,9 +216,26 @@ def _scan_case(dev, bsz, dim, Ns, L, io, backward):
         finally:
             ssi.TIME_PARALLEL = True
     t_b = None
+    _scan_case.sequential_bwd_ms = None
     if backward:
         out = fwd()                      # checkpoints saved once; the op's backward node alone is replayed
-        t_b = _time(lambda: torch.autograd.grad(out, leaves, dout, retain_graph=True))
+        bwd = lambda: torch.autograd.grad(out, leaves, dout, retain_graph=True)
+        if small:
+            # graph-replay timing cannot capture the autograd engine (its worker thread is outside the capture): call the
+            # op's backward node itself on this thread -- the same kernels, none of the engine
+            node = out.grad_fn
+            while node is not None and "SelectiveScan" not in type(node).__name__:
+                node = node.next_functions[0][0]
+            if node is not None:
+                bwd = lambda: type(node)._forward_cls.backward(node, dout)      # (a Function's grad_fn IS its ctx)
+        t_b = timer(bwd)
+        if hip.lib().cum_scan_bwd_tp_workspace_elems(bsz, dim, Ns, L) > 0:
+            # this shape takes the time-parallel backward (csrc/scan_bwd_small.hip): the sequential kernels beside it
+            ssi.TIME_PARALLEL = False
+            try:
+                _scan_case.sequential_bwd_ms = timer(bwd)
+            finally:
+                ssi.TIME_PARALLEL = True
     return t_i, t_b
 
 
@@ -257,6 +274,10 @@ def scan_rows(dev, dt):
                          "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "state_updates_T_per_s": round(ups / 1e12, 3),
                          "issue_roof_frac": round(ups / issue_roof, 4) if kind == "fwd" else None,
                          "binding_roof": "hbm" if byt / (HBM_PEAK_GBS * 1e9) > upd / issue_roof else "v_exp_f32 issue"})
+            if kind == "bwd" and _scan_case.sequential_bwd_ms is not None:
+                sb = _scan_case.sequential_bwd_ms
+                rows[-1].update(path="time-parallel (segments + carry, csrc/scan_bwd_small.hip PASS 1 / 0)",
+                                sequential_kernel_ms=round(sb, 4), speedup_vs_sequential=round(sb / ms, 2))
             if kind == "fwd" and seq_ms is not None:
                 rows[-1].update(path="time-parallel (segments + carry, csrc/scan_seg.hip)",
                                 sequential_kernel_ms=round(seq_ms, 4), speedup_vs_sequential=round(seq_ms / ms, 2))

@@ -413,28 +413,67 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
 // Deterministic slab reductions: dA, dD, dbias over batch; dB, dC over channel groups.  VEC: a thread owns four
 // consecutive dB / dC values (L * N a multiple of 4, 16-byte aligned buffers) and keeps eight 16-byte loads in flight --
 // the dB / dC slabs are the bulk of what this kernel reads (B * G * L * N * 8 bytes: 163 MB at the E8 bottleneck).
+// dA, dD, dbias over MANY slab rows (time-parallel form: batch x segments rows, 3 840 at the pruned block with 256 clips):
+// one wave per output element, lanes over the rows (four loads in flight each), fixed-order lane sums + xor tree ->
+// bit-reproducible.  (One thread per output walking the rows one dependent load at a time, as the kernel below does for
+// the <= 64 rows of the sequential form, took 3.8 ms there.)
+__global__ __launch_bounds__(256) void scan_bwd_finalize_rows_kernel(const ScanParams p, float *dA, float *dD,
+                                                                     float *dbias) {
+  const int64_t N = p.s.dstate, Dm = p.s.dim, nA = Dm * N, n_out = nA + 2 * Dm;
+  const int64_t Bs = (int64_t)p.s.batch * (p.nseg > 1 ? p.nseg : 1);
+  const int lane = threadIdx.x & 63;
+  for (int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); o < n_out; o += (int64_t)gridDim.x * 4) {
+    const float *src;
+    int64_t stride;
+    float *dst;
+    if (o < nA) {
+      src = p.ws_dA + o, stride = nA, dst = dA + o;
+    } else if (o < nA + Dm) {
+      src = p.ws_dD + (o - nA), stride = Dm, dst = dD ? dD + (o - nA) : nullptr;
+    } else {
+      src = p.ws_dbias + (o - nA - Dm), stride = Dm, dst = dbias ? dbias + (o - nA - Dm) : nullptr;
+    }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int64_t b = lane;
+    for (; b + 192 < Bs; b += 256) {
+      a0 += src[b * stride];
+      a1 += src[(b + 64) * stride];
+      a2 += src[(b + 128) * stride];
+      a3 += src[(b + 192) * stride];
+    }
+    for (; b < Bs; b += 64) a0 += src[b * stride];
+    float v = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0 && dst) *dst = v;
+  }
+}
+
 template <bool VEC>
 __global__ void scan_bwd_finalize_kernel(const ScanParams p, float *dA, float *dD, float *dbias, float *dB,
-                                         float *dC) {
+                                         float *dC, int rows_done) {
   constexpr int V = VEC ? 4 : 1;
   const int64_t N = p.s.dstate, L = p.s.len, Dm = p.s.dim, Bn = p.s.batch, G = p.ngroups;
+  const int64_t Bs = Bn * (p.nseg > 1 ? p.nseg : 1);     // rows of the dA / dD / dbias slabs: (batch, segment)
   const int64_t nA = Dm * N, nBC = Bn * L * N, LN = L * N;
   const int64_t total = nA + 2 * Dm + 2 * nBC / V;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < nA) {
+    if (i < nA + 2 * Dm && rows_done) {
+      // (summed by scan_bwd_finalize_rows_kernel)
+    } else if (i < nA) {
       float s = 0.f;
-      for (int64_t b = 0; b < Bn; ++b) s += p.ws_dA[b * nA + i];
+      for (int64_t b = 0; b < Bs; ++b) s += p.ws_dA[b * nA + i];
       dA[i] = s;
     } else if (i < nA + Dm) {
       const int64_t d = i - nA;
       float s = 0.f;
-      for (int64_t b = 0; b < Bn; ++b) s += p.ws_dD[b * Dm + d];
+      for (int64_t b = 0; b < Bs; ++b) s += p.ws_dD[b * Dm + d];
       if (dD) dD[d] = s;
     } else if (i < nA + 2 * Dm) {
       const int64_t d = i - nA - Dm;
       float s = 0.f;
-      for (int64_t b = 0; b < Bn; ++b) s += p.ws_dbias[b * Dm + d];
+      for (int64_t b = 0; b < Bs; ++b) s += p.ws_dbias[b * Dm + d];
       if (dbias) dbias[d] = s;
     } else {
       int64_t r = (i - nA - 2 * Dm) * V;
@@ -506,12 +545,22 @@ extern "C" int64_t cum_scan_bwd_workspace_elems(int32_t batch, int32_t dim, int3
   return (int64_t)batch * dim * dstate + 2 * (int64_t)batch * dim + 2 * (int64_t)batch * G * len * dstate;
 }
 
-extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs, const void *u,
-                                      const void *delta, const float *A,
-                                      const float *Bm, const float *Cm, const float *D, const void *z,
-                                      const float *delta_bias, const void *dout, const void *y_pre, const float *ckpt, void *du,
-                                      void *ddelta, float *dA, float *dB, float *dC, float *dD, void *dz,
-                                      float *ddelta_bias, float *workspace, void *stream) {
+// time-parallel backward (cum_selective_scan_bwd_tp): 0 = "the plan keeps this shape on the sequential kernels"
+extern "C" int64_t cum_scan_bwd_tp_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len) {
+  if (batch <= 0 || dim <= 0 || dstate <= 0 || len <= 0) return 0;
+  int nseg = 1, sc = 0;
+  scan_seg_plan_bwd(batch, dim, dstate, len, &nseg, &sc);
+  if (nseg <= 1) return 0;
+  const int64_t G = (dim + 63) / 64;
+  return (int64_t)nseg * ((int64_t)batch * dim * dstate + 2 * (int64_t)batch * dim) + 2 * (int64_t)batch * G * len * dstate +
+         scan_seg_carry_elems(batch, dim, dstate, nseg);
+}
+
+static int scan_bwd_impl(const cum_scan_shape *s, const cum_scan_grad_strides *gs, const void *u, const void *delta,
+                         const float *A, const float *Bm, const float *Cm, const float *D, const void *z,
+                         const float *delta_bias, const void *dout, const void *y_pre, const float *ckpt, void *du,
+                         void *ddelta, float *dA, float *dB, float *dC, float *dD, void *dz, float *ddelta_bias,
+                         float *workspace, void *stream, bool time_parallel) {
   if (int rc = scan_check_shape(s)) return rc;
   CUM_REQUIRE(gs && dA, "scan_bwd: null tensor");
   {
@@ -537,13 +586,16 @@ extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_gr
   p.dout = dout; p.ypre_in = y_pre; p.ckpt_in = ckpt; p.du = du; p.ddelta = ddelta; p.dz = dz;
   p.nchunks = (s->len + TB - 1) / TB;
   p.ngroups = (s->dim + 63) / 64;
-  const int64_t nA = (int64_t)s->batch * s->dim * s->dstate, nD = (int64_t)s->batch * s->dim;
+  p.nseg = 1;
+  if (time_parallel) scan_seg_plan_bwd(s->batch, s->dim, s->dstate, s->len, &p.nseg, &p.seg_chunks);
+  const int64_t nA = (int64_t)p.nseg * s->batch * s->dim * s->dstate, nD = (int64_t)p.nseg * s->batch * s->dim;
   const int64_t nBC = (int64_t)s->batch * p.ngroups * s->len * s->dstate;
   p.ws_dA = workspace;
   p.ws_dD = workspace + nA;
   p.ws_dbias = p.ws_dD + nD;
   p.ws_dB = p.ws_dbias + nD;
   p.ws_dC = p.ws_dB + nBC;
+  p.carry = p.ws_dC + nBC;            // (time-parallel form: leaving dx carries and sums of delta' of the segments)
   int rc;
   switch ((s->dstate + NS - 1) / NS) {
     case 1:
@@ -561,10 +613,38 @@ extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_gr
   const int64_t total = (int64_t)s->dim * s->dstate + 2 * s->dim + 2 * (int64_t)s->batch * LN / (vec ? 4 : 1);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
+  const int rows_done = (int64_t)s->batch * p.nseg > 64;
+  if (rows_done) {
+    const int64_t n_out = (int64_t)s->dim * s->dstate + 2 * s->dim;
+    hipLaunchKernelGGL(scan_bwd_finalize_rows_kernel, dim3((unsigned)((n_out + 3) / 4 < 4096 ? (n_out + 3) / 4 : 4096)),
+                       dim3(256), 0, st, p, dA, dD, ddelta_bias);
+    CUM_CHECK_LAUNCH();
+  }
   if (vec)
-    hipLaunchKernelGGL(scan_bwd_finalize_kernel<true>, dim3(blocks), dim3(256), 0, st, p, dA, dD, ddelta_bias, dB, dC);
+    hipLaunchKernelGGL(scan_bwd_finalize_kernel<true>, dim3(blocks), dim3(256), 0, st, p, dA, dD, ddelta_bias, dB, dC,
+                       rows_done);
   else
-    hipLaunchKernelGGL(scan_bwd_finalize_kernel<false>, dim3(blocks), dim3(256), 0, st, p, dA, dD, ddelta_bias, dB, dC);
+    hipLaunchKernelGGL(scan_bwd_finalize_kernel<false>, dim3(blocks), dim3(256), 0, st, p, dA, dD, ddelta_bias, dB, dC,
+                       rows_done);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
+}
+
+extern "C" int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides *gs, const void *u,
+                                      const void *delta, const float *A, const float *Bm, const float *Cm, const float *D,
+                                      const void *z, const float *delta_bias, const void *dout, const void *y_pre,
+                                      const float *ckpt, void *du, void *ddelta, float *dA, float *dB, float *dC, float *dD,
+                                      void *dz, float *ddelta_bias, float *workspace, void *stream) {
+  return scan_bwd_impl(s, gs, u, delta, A, Bm, Cm, D, z, delta_bias, dout, y_pre, ckpt, du, ddelta, dA, dB, dC, dD, dz,
+                       ddelta_bias, workspace, stream, false);
+}
+
+extern "C" int cum_selective_scan_bwd_tp(const cum_scan_shape *s, const cum_scan_grad_strides *gs, const void *u,
+                                         const void *delta, const float *A, const float *Bm, const float *Cm,
+                                         const float *D, const void *z, const float *delta_bias, const void *dout,
+                                         const void *y_pre, const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
+                                         float *dC, float *dD, void *dz, float *ddelta_bias, float *workspace,
+                                         void *stream) {
+  return scan_bwd_impl(s, gs, u, delta, A, Bm, Cm, D, z, delta_bias, dout, y_pre, ckpt, du, ddelta, dA, dB, dC, dD, dz,
+                       ddelta_bias, workspace, stream, true);
 }

@@ -30,7 +30,12 @@
 
 namespace cum {
 
-template <int NW, typename TIO>
+// PASS 0: the whole backward over the workgroup's range of halves -- all of them (sequential form), or one SEGMENT of
+// whole chunks (time-parallel form, blockIdx.z = segment) entered with the dx carry composed from the later segments.
+// PASS 1 (time-parallel form only, segments 1 .. nseg - 1): nothing but the reverse recurrence g <- a_t (C_t dy_t + g)
+// from a zero carry and the segment's sum of delta' -> p.carry, as scan_seg.hip's pass 1 does for the forward: the
+// reverse recurrence is the same linear operator run backwards, a segment's decay is exp2(A' sum delta') again.
+template <int NW, typename TIO, int PASS>
 __global__ __launch_bounds__((NW + 2) * 64) void scan_bwd_ws_kernel(const ScanParams p) {
   constexpr int NPD = NW * NS;               // padded state count: 8 or 16
   constexpr int BCE = SUB * 2 * NPD / 64;    // B / C tile elements per loader lane and half
@@ -54,8 +59,14 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_bwd_ws_kernel(const ScanPa
   const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
   const bool dok = d < Dm;
   const int dc = dok ? d : Dm - 1;           // lanes past the last channel walk a valid one; their values are zeroed
-  const int nh = (L + SUB - 1) / SUB;        // halves, walked nh - 1 ... 0: interval i handles half nh - 1 - i
-  const int nchunks = p.nchunks;
+  const int nchunks = p.nchunks, nseg = p.nseg;
+  const int seg = nseg > 1 ? (int)blockIdx.z + (PASS == 1 ? 1 : 0) : 0;
+  const int nh_all = (L + SUB - 1) / SUB;
+  const int h_lo = nseg > 1 ? 2 * seg * p.seg_chunks : 0;
+  const int hb = nseg > 1 ? (h_lo + 2 * p.seg_chunks < nh_all ? h_lo + 2 * p.seg_chunks : nh_all) : nh_all;
+  const int nh = hb - h_lo;                  // halves of this workgroup, walked hb - 1 ... h_lo: interval i handles hb - 1 - i
+  const int64_t slab = (int64_t)b * nseg + seg;                      // row of the dA / dD / dbias slabs
+  float *xsum = p.carry + (int64_t)p.s.batch * nseg * NW * Dm * NS;   // [(b, seg, d)] sums of delta' (time-parallel form)
   const bool has_z = p.z != nullptr;
 
   if (w == NW) {
@@ -128,14 +139,14 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_bwd_ws_kernel(const ScanPa
 #pragma unroll
       for (int k = 0; k < BCE; ++k) (&s_bc[i & 1][0][0])[lane + 64 * k] = rbc[k];
     };
-    load_rows(nh - 1);
-    prepare(nh - 1, 0);
-    if (nh > 1) load_rows(nh - 2);
+    load_rows(hb - 1);
+    prepare(hb - 1, 0);
+    if (nh > 1) load_rows(hb - 2);
     for (int i = 0; i < nh; ++i) {
-      __syncthreads();                       // interval i: the consumers walk half nh - 1 - i
+      __syncthreads();                       // interval i: the consumers walk half hb - 1 - i
       if (i + 1 < nh) {
-        prepare(nh - 2 - i, i + 1);
-        if (i + 2 < nh) load_rows(nh - 3 - i);
+        prepare(hb - 2 - i, i + 1);
+        if (i + 2 < nh) load_rows(hb - 3 - i);
       }
     }
     __syncthreads();
@@ -182,13 +193,15 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_bwd_ws_kernel(const ScanPa
     };
     for (int i = 0; i < nh; ++i) {
       __syncthreads();
-      if (i > 0) epilogue(nh - i, i - 1);
+      if (PASS == 0 && i > 0) epilogue(hb - i, i - 1);
     }
     __syncthreads();
-    epilogue(0, nh - 1);
-    if (dok) {
-      p.ws_dD[(int64_t)b * Dm + d] = accD;
-      p.ws_dbias[(int64_t)b * Dm + d] = accBias;
+    if constexpr (PASS == 0) {
+      epilogue(h_lo, nh - 1);
+      if (dok) {
+        p.ws_dD[slab * Dm + d] = accD;
+        p.ws_dbias[slab * Dm + d] = accBias;
+      }
     }
     return;
   }
@@ -214,16 +227,53 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_bwd_ws_kernel(const ScanPa
   float *wsBC = ((lane & 8) ? wsC : wsB) + qoff;
 
   auto ck = [&](int h) { return ckpt_slot(b, nchunks, h >> 1, h & 1, NW, w, Dm, dc); };
+  if constexpr (PASS == 1) {
+    // ---- time-parallel pass 1: the dx recurrence of this segment from a zero carry, and its sum of delta'
+    float dsum = 0.f;
+    for (int i = 0; i < nh; ++i) {
+      const int slot = i % 3, ps = i & 1;
+      __syncthreads();
+      const float (*tile)[2 * NPD] = s_bc[ps];
+#pragma unroll
+      for (int k = SUB - 1; k >= 0; --k) {
+        const float4 o4 = s_op[slot][k][lane];
+        const float dt = o4.x, dy = o4.z;
+        const float4 c0 = *reinterpret_cast<const float4 *>(&tile[k][NPD + n0]), c1 = *reinterpret_cast<const float4 *>(&tile[k][NPD + n0 + 4]);
+        const f2 cv[NP2] = {f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, f2{c1.z, c1.w}};
+#pragma unroll
+        for (int j = 0; j < NP2; ++j) dxc[j] = exp2_2(dt * Ap[j]) * (cv[j] * dy + dxc[j]);
+        dsum += dt;
+      }
+    }
+    __syncthreads();
+    if (dok) {
+      ckpt_store(p.carry, carry_slot(b, nseg, seg, NW, w, Dm, d), dxc);
+      if (w == 0) xsum[slab * Dm + d] = dsum;
+    }
+    return;
+  }
+  if (nseg > 1) {
+    // the carry entering this segment from the future: compose the (decay, g leaving from zero) pairs of all later
+    // segments, last first -- dependent fma chains on loads that do not depend on each other
+#pragma unroll 4
+    for (int sp = nseg - 1; sp > seg; --sp) {
+      f2 e[NP2];
+      ckpt_load(p.carry, carry_slot(b, nseg, sp, NW, w, Dm, dc), e);
+      const float ds = xsum[((int64_t)b * nseg + sp) * Dm + dc];
+#pragma unroll
+      for (int j = 0; j < NP2; ++j) dxc[j] = exp2_2(ds * Ap[j]) * dxc[j] + e[j];
+    }
+  }
   f2 xn[NP2];                                // state entering the next half to be processed, requested one half ahead
-  ckpt_load(p.ckpt_in, ck(nh - 1), xn);
+  ckpt_load(p.ckpt_in, ck(hb - 1), xn);
 
   for (int i = 0; i < nh; ++i) {
-    const int h = nh - 1 - i, slot = i % 3, ps = i & 1, t0 = h * SUB;
+    const int h = hb - 1 - i, slot = i % 3, ps = i & 1, t0 = h * SUB;
     f2 x[NP2];
 #pragma unroll
     for (int j = 0; j < NP2; ++j) x[j] = xn[j];
     __syncthreads();                         // the producer has finished this half's slot
-    if (h > 0) ckpt_load(p.ckpt_in, ck(h - 1), xn);
+    if (h > h_lo) ckpt_load(p.ckpt_in, ck(h - 1), xn);
     const float (*tile)[2 * NPD] = s_bc[ps];
     f2 xs[SUB][NP2];                         // state before each step
     f2 as[SUB - 1][NP2];                     // decay factors of steps 0 .. 6 (step 7's is formed in the reverse walk)
@@ -279,24 +329,31 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_bwd_ws_kernel(const ScanPa
   }
   __syncthreads();                           // lets the finisher close the last half
   if (dok) {
-    float *wa = p.ws_dA + ((int64_t)b * Dm + d) * N + n0;
+    float *wa = p.ws_dA + (slab * Dm + d) * N + n0;
 #pragma unroll
     for (int j = 0; j < NS; ++j)
       if (j < nvalid) wa[j] = dAacc[j / 2][j % 2];
   }
 }
 
-template <int NW>
-static int launch_small(const ScanParams &p, hipStream_t st) {
-  dim3 grid((p.s.dim + 63) / 64, p.s.batch), block((NW + 2) * 64);
-  if (p.s.io_dtype == CUM_BF16)
-    hipLaunchKernelGGL((scan_bwd_ws_kernel<NW, __bf16>), grid, block, 0, st, p);
-  else if (p.s.io_dtype == CUM_F16)
-    hipLaunchKernelGGL((scan_bwd_ws_kernel<NW, f16>), grid, block, 0, st, p);
-  else
-    hipLaunchKernelGGL((scan_bwd_ws_kernel<NW, float>), grid, block, 0, st, p);
+template <int NW, typename TIO>
+static int launch_small_io(const ScanParams &p, hipStream_t st) {
+  const dim3 block((NW + 2) * 64);
+  if (p.nseg > 1) {       // time-parallel: pass 1 over segments 1 .. nseg - 1, then every segment with its composed carry
+    hipLaunchKernelGGL((scan_bwd_ws_kernel<NW, TIO, 1>), dim3((p.s.dim + 63) / 64, p.s.batch, p.nseg - 1), block, 0, st, p);
+    CUM_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL((scan_bwd_ws_kernel<NW, TIO, 0>), dim3((p.s.dim + 63) / 64, p.s.batch, p.nseg > 1 ? p.nseg : 1), block,
+                     0, st, p);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
+}
+
+template <int NW>
+static int launch_small(const ScanParams &p, hipStream_t st) {
+  if (p.s.io_dtype == CUM_BF16) return launch_small_io<NW, __bf16>(p, st);
+  if (p.s.io_dtype == CUM_F16) return launch_small_io<NW, f16>(p, st);
+  return launch_small_io<NW, float>(p, st);
 }
 
 int launch_bwd_small(const ScanParams &p, hipStream_t st) {

@@ -65,6 +65,12 @@ __device__ __forceinline__ void ckpt_load(const float *ck, int64_t slot, f2 (&x)
   x[0] = f2{a.x, a.y}; x[1] = f2{a.z, a.w}; x[2] = f2{c.x, c.y}; x[3] = f2{c.z, c.w};
 }
 
+// carry buffer of the time-parallel forms (scan_seg.hip forward, scan_bwd_small.hip backward): [(b, seg, w, d)][NS] f32
+// (a segment's end state / leaving dx carry from a zero start), then the per-segment sums of delta' [(b, seg, d)]
+__device__ __forceinline__ int64_t carry_slot(int b, int nseg, int seg, int NW, int w, int Dm, int d) {
+  return ((((int64_t)b * nseg + seg) * NW + w) * Dm + d) * NS;
+}
+
 typedef const float __attribute__((address_space(4))) *cfp;
 
 // B_t or C_t slice of this wave (wave-uniform address -> s_load_dwordx8).
@@ -85,6 +91,8 @@ __device__ __forceinline__ void load_bc(const float *base, int sn, int nvalid, f
 }
 
 int scan_check_shape(const cum_scan_shape *s);
+// segment plan of the time-parallel backward (d_state <= 16 only: scan_bwd_small.hip)
+void scan_seg_plan_bwd(int batch, int dim, int dstate, int len, int *nseg, int *seg_chunks);
 // time-parallel forward for grids that do not fill the chip (scan_seg.hip): plan (nseg == 1: sequential kernels),
 // workspace size in f32 elements, launcher
 void scan_seg_plan(int batch, int dim, int dstate, int len, int *nseg, int *seg_chunks);

@@ -24,12 +24,6 @@
 
 namespace cum {
 
-// carry buffer: [(b, seg, w, d)][NS] f32 (x_end^0 of every segment but the last, written by pass 1), then the
-// per-segment sums of delta' [(b, seg, d)]
-__device__ __forceinline__ int64_t carry_slot(int b, int nseg, int seg, int NW, int w, int Dm, int d) {
-  return ((((int64_t)b * nseg + seg) * NW + w) * Dm + d) * NS;
-}
-
 template <int NW, typename TIO, int PASS>
 __global__ __launch_bounds__(NW * 64) void scan_seg_kernel(const ScanParams p) {
   constexpr int K = (TB + NW - 1) / NW;
@@ -254,6 +248,29 @@ void scan_seg_plan(int batch, int dim, int dstate, int len, int *nseg, int *seg_
   if (force < 0 && waves >= (NW > 2 ? 1024 : 257)) return;
   const int64_t target = NW > 2 ? 2048 : 4096;
   int64_t want = force > 1 ? force : (target + waves - 1) / waves;
+  int sc = (int)((nchunks + want - 1) / want);
+  if (sc < 2) sc = 2;
+  const int S = (nchunks + sc - 1) / sc;
+  if (S < 3) return;
+  *nseg = S;
+  *seg_chunks = sc;
+}
+
+// The backward's plan (scan_bwd_small.hip, d_state <= 16): its sequential grid is batch * ceil(dim / 64) workgroups of
+// NW + 2 waves that each walk all halves with one barrier per half; segmented while that grid leaves most of the chip idle,
+// about 2 560 workgroups in all, >= 2 chunks per segment, >= 3 segments.  Twice the reverse-walk work (pass 1 is the bare
+// recurrence).  Measured on MI355X (tools/bench_scan_tp_bwd.py, same box, graph-replay timing): 16-32 workgroups 5.7-6.2 x
+// the sequential kernel, 64 3.6 x, 128 1.5-2.0 x, 256 0.9-1.1 x (three workgroups per CU by LDS: the chip is as busy as the
+// wave-specialised design gets) -> taken up to 192.
+void scan_seg_plan_bwd(int batch, int dim, int dstate, int len, int *nseg, int *seg_chunks) {
+  const int64_t groups = (int64_t)batch * ((dim + 63) / 64);
+  const int nchunks = (len + TB - 1) / TB;
+  *nseg = 1;
+  *seg_chunks = nchunks;
+  const int64_t force = cum_knob("CUM_SCAN_BWD_SEGMENTS", -1);   // AB build: 0 = never, n > 1 = that many segments
+  if (dstate > 2 * NS || force == 0 || groups <= 0 || nchunks < 6) return;
+  if (force < 0 && groups > 192) return;
+  int64_t want = force > 1 ? force : (2560 + groups - 1) / groups;
   int sc = (int)((nchunks + want - 1) / want);
   if (sc < 2) sc = 2;
   const int S = (nchunks + sc - 1) / sc;

@@ -65,6 +65,8 @@ SIGNATURES = {
     "cum_scan_fwd_keeps_y": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "cum_scan_bwd_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "cum_selective_scan_bwd": (c_i32, [ctypes.POINTER(ScanShape), ctypes.POINTER(ScanGradStrides)] + [_P] * 21),
+    "cum_scan_bwd_tp_workspace_elems": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "cum_selective_scan_bwd_tp": (c_i32, [ctypes.POINTER(ScanShape), ctypes.POINTER(ScanGradStrides)] + [_P] * 21),
     "cum_selective_state_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, _P, c_i64, _P, c_i64,
                                            _P, _P, _P, c_i32, _P, _P]),
     "cum_causal_conv1d_fwd": (c_i32, [ctypes.POINTER(ConvShape)] + [_P] * 5),
@@ -152,7 +154,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 12:
+        if L.cum_abi_version() != 13:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -190,19 +190,19 @@ class _MambaInnerFn(torch.autograd.Function):
             return torch.empty(like.shape, dtype=torch.float32, device=dev)
         dcw, dcb, dbias, dA_log, dD = slot(0, w2), slot(1, cb), slot(2, bias), slot(3, A), slot(4, Df)
         dA = torch.empty_like(A)
-        ws = torch.empty(max(lib.cum_scan_bwd_workspace_elems(Bn, Dn, N, L), 1), dtype=torch.float32, device=dev)
+        bwd, ws = ssi.scan_backward_entry(Bn, Dn, N, L, dev)
         su = ssi._shape(xcT, dtT, zv, dyT, Bm, Cm, True)                  # o_* strides := dout's
         gs = hip.ScanGradStrides()
         gs.du_sb, gs.du_sd, gs.du_sl = duT.stride()
         gs.dd_sb, gs.dd_sd, gs.dd_sl = ddT.stride()
         gs.dz_sb, gs.dz_sd, gs.dz_sl = dzT.stride()
         with torch.cuda.device(dev):
-            hip.check(lib.cum_selective_scan_bwd(ctypes.byref(su), ctypes.byref(gs), hip.ptr(xcT), hip.ptr(dtT), hip.ptr(A),
-                                                 hip.ptr(Bm), hip.ptr(Cm), hip.ptr(Df), hip.ptr(zv), hip.ptr(bias),
-                                                 hip.ptr(dyT), hip.ptr(ypre.transpose(1, 2) if ypre is not None else None),
-                                                 hip.ptr(ckpt), hip.ptr(duT), hip.ptr(ddT), hip.ptr(dA),
-                                                 hip.ptr(dBC[0]), hip.ptr(dBC[1]), hip.ptr(dD), hip.ptr(dzT), hip.ptr(dbias),
-                                                 hip.ptr(ws), hip.stream_ptr()))
+            hip.check(bwd(ctypes.byref(su), ctypes.byref(gs), hip.ptr(xcT), hip.ptr(dtT), hip.ptr(A),
+                          hip.ptr(Bm), hip.ptr(Cm), hip.ptr(Df), hip.ptr(zv), hip.ptr(bias),
+                          hip.ptr(dyT), hip.ptr(ypre.transpose(1, 2) if ypre is not None else None),
+                          hip.ptr(ckpt), hip.ptr(duT), hip.ptr(ddT), hip.ptr(dA),
+                          hip.ptr(dBC[0]), hip.ptr(dBC[1]), hip.ptr(dD), hip.ptr(dzT), hip.ptr(dbias),
+                          hip.ptr(ws), hip.stream_ptr()))
         torch.mul(dA, A, out=dA_log)                                       # A = -exp(A_log): dA / dA_log = A
         # d(x_dbl) = (d dt | dB | dC): one buffer, rows readable 64 columns past their end (zero weight columns there)
         pad = cs.rup(S, cs.bk_of(cd)) - S

@@ -78,7 +78,18 @@ def keeps_y(s, time_parallel=True):
     return _KEEP_Y and bool(hip.lib().cum_scan_fwd_keeps_y(s.batch, s.dim, s.dstate, s.len, int(bool(time_parallel))))
 
 
-TIME_PARALLEL = True        # module switch for tests / A-B timing: False pins the sequential forward kernels
+TIME_PARALLEL = True        # module switch for tests / A-B timing: False pins the sequential forward AND backward kernels
+
+
+def scan_backward_entry(bsz, dim, N, L, device):
+    """(C entry point, workspace) of the selective-scan backward for this shape: the time-parallel form
+    (cum_selective_scan_bwd_tp) where its plan segments the shape, else the sequential kernels."""
+    lib = hip.lib()
+    n = lib.cum_scan_bwd_tp_workspace_elems(bsz, dim, N, L) if TIME_PARALLEL else 0
+    if n > 0:
+        return lib.cum_selective_scan_bwd_tp, torch.empty(n, dtype=torch.float32, device=device)
+    return lib.cum_selective_scan_bwd, torch.empty(max(lib.cum_scan_bwd_workspace_elems(bsz, dim, N, L), 1),
+                                                   dtype=torch.float32, device=device)
 
 
 class SelectiveScanFn(torch.autograd.Function):
@@ -146,15 +157,14 @@ class SelectiveScanFn(torch.autograd.Function):
         dC = torch.empty(bsz, L, N, dtype=torch.float32, device=u.device)
         dD = torch.empty_like(D) if D is not None else None
         dbias = torch.empty_like(delta_bias) if delta_bias is not None else None
-        ws = torch.empty(max(lib.cum_scan_bwd_workspace_elems(bsz, dim, N, L), 1), dtype=torch.float32,
-                         device=u.device)
+        bwd, ws = scan_backward_entry(bsz, dim, N, L, u.device)
         with torch.cuda.device(u.device):
-            hip.check(lib.cum_selective_scan_bwd(ctypes.byref(su), ctypes.byref(gs), hip.ptr(u), hip.ptr(delta), hip.ptr(A),
-                                                 hip.ptr(Bm), hip.ptr(Cm), hip.ptr(D), hip.ptr(z),
-                                                 hip.ptr(delta_bias), hip.ptr(dout), hip.ptr(y_pre), hip.ptr(ckpt), hip.ptr(du),
-                                                 hip.ptr(ddelta), hip.ptr(dA), hip.ptr(dB), hip.ptr(dC),
-                                                 hip.ptr(dD), hip.ptr(dz), hip.ptr(dbias), hip.ptr(ws),
-                                                 hip.stream_ptr()))
+            hip.check(bwd(ctypes.byref(su), ctypes.byref(gs), hip.ptr(u), hip.ptr(delta), hip.ptr(A),
+                          hip.ptr(Bm), hip.ptr(Cm), hip.ptr(D), hip.ptr(z),
+                          hip.ptr(delta_bias), hip.ptr(dout), hip.ptr(y_pre), hip.ptr(ckpt), hip.ptr(du),
+                          hip.ptr(ddelta), hip.ptr(dA), hip.ptr(dB), hip.ptr(dC),
+                          hip.ptr(dD), hip.ptr(dz), hip.ptr(dbias), hip.ptr(ws),
+                          hip.stream_ptr()))
         dB, dC = dB.transpose(1, 2), dC.transpose(1, 2)          # (B, N, L) views
         if ctx.b4[0]:
             dB = dB.unsqueeze(1)

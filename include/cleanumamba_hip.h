@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 12
+#define CUM_ABI_VERSION 13
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -120,6 +120,24 @@ int cum_selective_scan_bwd(const cum_scan_shape *s, const cum_scan_grad_strides 
                            const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
                            float *dC, float *dD, void *dz, float *ddelta_bias,
                            float *workspace, void *stream);
+
+/* Time-parallel backward for grids that leave the chip mostly idle (d_state <= 16: the 442K model, the pruned
+ * checkpoints, reached when the reference trains / fine-tunes them, src/network/CleanUMamba.py:289-290): the reverse
+ * recurrence dx_t = C_t dy_t + a_{t+1} dx_{t+1} is the forward's linear operator run backwards, so time splits into
+ * segments of whole 16-step chunks -- pass 1 walks every segment but the first from a zero carry (its leaving carry and
+ * its sum of delta'), pass 2 walks every segment with the carry composed from the later ones and computes all
+ * gradients from the forward's checkpoints (csrc/scan_bwd_small.hip).  Same arguments and results as
+ * cum_selective_scan_bwd (bit-reproducible; equal to it up to the f32 rounding of the segment decay);
+ * workspace: cum_scan_bwd_tp_workspace_elems() elements -- 0 means "the plan keeps this shape sequential: call
+ * cum_selective_scan_bwd". */
+int64_t cum_scan_bwd_tp_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len);
+int cum_selective_scan_bwd_tp(const cum_scan_shape *s, const cum_scan_grad_strides *gs,
+                              const void *u, const void *delta,
+                              const float *A, const float *Bm, const float *Cm, const float *D,
+                              const void *z, const float *delta_bias, const void *dout, const void *y_pre,
+                              const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
+                              float *dC, float *dD, void *dz, float *ddelta_bias,
+                              float *workspace, void *stream);
 
 /* One time step for `batch` concurrent streams (Mamba.step).  state (batch, dim,
  * dstate) contiguous, updated in place.  x, dt, z, out: (batch, dim) contiguous;

@@ -89,11 +89,15 @@ def _segments(shape):
 def test_time_parallel_scan_vs_oracle_and_sequential(cuda, shape, opts, io):
     """SURVEY 8 row a9' (north_star: "wavefront shuffle / prefix-sum for the scan recurrence"): the segmented forward
     (csrc/scan_seg.hip) on grids the sequential kernels would leave mostly idle -- against the f64 oracle (output,
-    last_state, and EVERY gradient through the unchanged backward kernels, which consume the checkpoints the segmented
-    pass wrote) and against the sequential kernels on the same inputs."""
+    last_state, and EVERY gradient through the backward kernels, which consume the checkpoints the segmented pass wrote:
+    the TIME-PARALLEL backward of csrc/scan_bwd_small.hip where its plan segments the shape (d_state <= 16, long enough),
+    else the sequential kernels) and against the sequential forward + backward on the same inputs."""
+    from cleanumamba_amd import hip
     from cleanumamba_amd.mamba_ssm.ops import selective_scan_interface as ssi
     bsz, dim, N, L = shape
     assert _segments(shape) > 0, "the plan does not segment this shape"
+    tp_bwd = hip.lib().cum_scan_bwd_tp_workspace_elems(*shape) > 0
+    assert tp_bwd == (N <= 16 and (L + 15) // 16 >= 6), "time-parallel backward: every small-state shape long enough"
     gen = torch.Generator().manual_seed(sum(shape))
     rn = lambda *s: torch.randn(*s, generator=gen)
     cpu = dict(u=rn(bsz, L, dim).transpose(1, 2), delta=0.5 * rn(bsz, L, dim).transpose(1, 2),
@@ -143,11 +147,44 @@ def test_time_parallel_scan_vs_oracle_and_sequential(cuda, shape, opts, io):
     assert torch.equal(y2.float(), y) and torch.equal(last2, last)
 
 
+def test_time_parallel_backward_is_bit_reproducible_and_takes_16_bit_io(cuda):
+    """The time-parallel backward on the two bench shapes (442K model at B = 16; pruned-E8 block at B = 256 streams-worth
+    of clips is past the plan's limit, so 64 clips): two runs are bit-identical (slabs + fixed-order finalize, no atomics), f16
+    I/O agrees with f32 I/O."""
+    from cleanumamba_amd import hip
+    from cleanumamba_amd.mamba_ssm.ops import selective_scan_interface as ssi
+    for shape in ((16, 128, 16, 624), (64, 48, 8, 1875)):
+        bsz, dim, N, L = shape
+        assert hip.lib().cum_scan_bwd_tp_workspace_elems(*shape) > 0
+        g = torch.Generator(device=cuda).manual_seed(L)
+        rn = lambda *s: torch.randn(*s, generator=g, device=cuda)
+        base = dict(u=rn(bsz, L, dim).transpose(1, 2), delta=0.5 * rn(bsz, L, dim).transpose(1, 2),
+                    A=-torch.exp(0.5 * rn(dim, N)), B=rn(bsz, L, N).transpose(1, 2), C=rn(bsz, L, N).transpose(1, 2),
+                    D=rn(dim), z=rn(bsz, L, dim).transpose(1, 2), delta_bias=0.5 * rn(dim))
+        dout = rn(bsz, L, dim).transpose(1, 2)
+        runs = []
+        for io in (torch.float32, torch.float32, torch.float16):
+            t = {k: (v.to(io) if k in ("u", "delta", "z") else v).detach().requires_grad_(True) for k, v in base.items()}
+            y = ssi.selective_scan_fn(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], z=t["z"],
+                                      delta_bias=t["delta_bias"], delta_softplus=True)
+            (y.float() * dout).sum().backward()
+            runs.append({k: v.grad.float() for k, v in t.items()})
+        for k in runs[0]:
+            assert torch.equal(runs[0][k], runs[1][k]), k
+            assert rel_l2(runs[2][k], runs[0][k]) < 3e-3, k
+
+
 def test_time_parallel_plan():
     """The plan: segmented when the sequential grid brings fewer than two waves per SIMD and the sequence has at least
     three segments of two 16-step chunks; never for the training shapes that fill the chip."""
     assert _segments((16, 2048, 64, 624)) == 0 and _segments((32, 2048, 64, 2499)) == 0      # E8 / E6 training
     assert _segments((1, 2048, 64, 624)) > 0 and _segments((16, 128, 16, 624)) > 0 and _segments((256, 48, 8, 1875)) > 0
+    from cleanumamba_amd import hip
+    tp = hip.lib().cum_scan_bwd_tp_workspace_elems
+    assert tp(16, 2048, 64, 624) == 0 and tp(1, 2048, 64, 624) == 0          # d_state > 16: sequential backward
+    assert tp(16, 2048, 8, 2499) == 0                                        # 512 workgroups: the chip is busy
+    assert tp(16, 128, 16, 624) > 0 and tp(128, 48, 8, 1875) > 0 and tp(2, 70, 13, 257) > 0
+    assert tp(256, 48, 8, 1875) == 0                                         # 256 workgroups: 0.9-1.1 x measured, not taken
     assert _segments((1, 128, 16, 61)) == 0                                                      # 4 chunks: too short
     assert _segments((0, 8, 8, 100)) == 0 and _segments((1, 8, 8, 0)) == 0
 

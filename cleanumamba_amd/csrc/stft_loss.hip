@@ -367,6 +367,15 @@ struct FusedFft {
   __device__ static __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
   __device__ static __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
+  // Between two stages other LANES' stores are read back.  The LDS executes a wave's accesses in order, so no hardware
+  // barrier is needed; what must not happen is the compiler moving a stage's loads above the previous stage's stores
+  // (it sees only this lane's addresses).  A wavefront-scope fence + wave barrier pins that order at zero instructions.
+  __device__ static __forceinline__ void stage_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
   // forward transform of both signals (wave-private buffer: the LDS executes a wave's accesses in order, no barrier)
   __device__ static __forceinline__ void forward(float4 *buf, const float2 *tw, int lane) {
     int L = H;
@@ -379,6 +388,7 @@ struct FusedFft {
         buf[pad(j + H / 2)] = cmul4(sub4(a, b), twiddle(tw, j, H));
       }
       L = H / 2;
+      stage_fence();
     }
 #pragma unroll
     for (int st = 0; st < LOGH / 2; ++st, L >>= 2) {
@@ -401,6 +411,7 @@ struct FusedFft {
           buf[pad(p + 3 * q4)] = sub4(t1, t3);
         }
       }
+      stage_fence();
     }
   }
 
@@ -431,6 +442,7 @@ struct FusedFft {
         st2(p + 2 * q4, make_float2(s0.x - s2.x, s0.y - s2.y));
         st2(p + 3 * q4, make_float2(s1.x - s3.x, s1.y - s3.y));
       }
+      stage_fence();
     }
     if constexpr (LEAD2) {
 #pragma unroll UNR
@@ -440,6 +452,7 @@ struct FusedFft {
         st2(j, make_float2(a.x + b.x, a.y + b.y));
         st2(j + H / 2, make_float2(a.x - b.x, a.y - b.y));
       }
+      stage_fence();
     }
   }
 };
@@ -533,6 +546,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
     const int b = fr / n_frames, f = fr - b * n_frames;
     if (f < p.frame0) continue;
     fused_load_frame<H>(p, b, f, lane, buf);
+    F::stage_fence();
     F::forward(buf, s_tw, lane);
     // bins in mirror pairs (j, H - j): both need exactly Z[j] and Z[H - j] -- one pair of LDS reads, two bins
 #pragma unroll 1
@@ -554,6 +568,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
         }
       }
     }
+    F::stage_fence();                                     // (the next frame's load overwrites what other lanes just read)
   }
   float v[3] = {s1, s2, s3};
 #pragma unroll
@@ -595,6 +610,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
       continue;
     }
     fused_load_frame<H>(p, b, f, lane, buf);
+    F::stage_fence();
     F::forward(buf, s_tw, lane);
     // gradient spectrum gz over the transforms, in place: lanes own disjoint (j, H - j) pairs
 #pragma unroll 1
@@ -624,6 +640,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
       *reinterpret_cast<float2 *>(&buf[pj]) = oj;
       if (m != j) *reinterpret_cast<float2 *>(&buf[pm]) = om;
     }
+    F::stage_fence();
     F::inverse_xy(buf, s_tw, lane);
     // frame gradient: sample 2m in the real part, 2m + 1 in the imaginary part; only the window's support is ever read
 #pragma unroll
@@ -634,6 +651,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_e
         *reinterpret_cast<float2 *>(dst + n) = make_float2(v.x, v.y);
       }
     }
+    F::stage_fence();                                     // (the next frame's load overwrites what other lanes just read)
   }
 }
 

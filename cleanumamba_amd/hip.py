@@ -208,6 +208,7 @@ def scan_chunk():
 # its address is stable across hipGraph replays.
 FFT_R2C, FFT_C2R, FFT_C2C = 0, 1, 2
 _fft_plans = {}
+_FFT_PLAN_LIMIT = 32          # distinct (device, kind, n, batch) plans kept; each holds a hipFFT work area
 
 
 class _FftPlan:
@@ -228,9 +229,18 @@ class _FftPlan:
 def fft(kind, n, batch, src, dst, inverse=False):
     """One batched transform through a cached, caller-owned plan (src, dst: float32 tensors, see cum_fft_exec)."""
     dev = src.device
+    if int(batch) == 0:                 # empty batch: nothing to transform (cum_fft_plan_create wants batch >= 1)
+        return
     key = (dev.index, kind, int(n), int(batch))
     plan = _fft_plans.get(key)
     if plan is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a plan's work area must not come out of a capture's private pool (it outlives the graph): create plans in
+            # the warm-up steps
+            raise RuntimeError("cleanumamba_amd.hip.fft: first use of an FFT plan inside hipGraph capture; run one "
+                               "un-captured step first")
+        if len(_fft_plans) >= _FFT_PLAN_LIMIT:      # bounded: drop the oldest plan (and its work area)
+            _fft_plans.pop(next(iter(_fft_plans)))
         plan = _fft_plans[key] = _FftPlan(kind, int(n), int(batch), dev)
     with torch.cuda.device(dev):
         check(lib().cum_fft_exec(plan.handle, ptr(src), ptr(dst), int(bool(inverse)), ptr(plan.work), stream_ptr()))

@@ -920,6 +920,11 @@ def _gemm_rows(x2, Kp, tail_ok=False):
     # overflowed in f16 is skipped by the loss scaler whatever this GEMM returns).
     c0 = x2.storage_offset() % x2.stride(0) if x2.stride(0) > 0 else 0
     inside = x2.stride(0) >= Kp and c0 + Kp <= x2.stride(0)
+    if inside:
+        # c0 is the column offset only if the parent starts at a multiple of the row stride; whatever the parent, the
+        # over-read of the LAST row must stay inside the storage
+        last_end = x2.storage_offset() + (x2.shape[0] - 1) * x2.stride(0) + Kp
+        inside = last_end * x2.element_size() <= x2.untyped_storage().nbytes()
     if ok and (K == Kp or inside or tail_ok):
         return x2
     if K == Kp:

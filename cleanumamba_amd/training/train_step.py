@@ -162,7 +162,7 @@ class TrainStep:
         flat order is the reverse of the registration order and the encoder registers first) and the model runs the
         fused conv stack, which is where the cut lives; else None."""
         enc = getattr(self.net, "encoder", None)
-        if enc is None or not self.flat or not getattr(self.net, "use_fused_convs", True):
+        if enc is None or not self.flat or not getattr(self.net, "use_fused_convs", False):     # (absent: not our model)
             return None
         fp = self.buckets.flat
         ids = {id(p) for p in enc.parameters()}

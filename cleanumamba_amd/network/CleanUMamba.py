@@ -482,6 +482,10 @@ class CleanUMamba(nn.Module):
             return t.float()                                   # cached path: (S, C, 2)
 
         from ..mamba_ssm.modules.mamba_simple import _proj       # cum_gemm_nt on padded operands: any channel count
+        if dev.type == "cuda":
+            # the drain's GEMM operands come out of the model's pack plan: re-pack if a parameter changed since the last
+            # per-layer hop (the one-launch hop packs its own blob and never touches the plan)
+            self._activate_pack_plan(torch.float32)
 
         def linear_ct(w2d, x):
             """(O, C) x (S, C, T) -> (S, O, T) on the library's GEMM (a handful of columns per stream: rows = S * T)."""

@@ -367,6 +367,41 @@ def test_one_launch_hop_equals_per_layer_hop(cuda, name, normalize):
         assert rel_l2(outs[True], par) < 1e-4
 
 
+def test_one_launch_hop_stream_counts_and_weight_changes(cuda):
+    """The one-launch hop with one stream, with more streams than the chip has CUs (two workgroups share some CUs), and
+    across an in-place weight update in the middle of a stream (the packed weight blob is rebuilt from the parameters'
+    version counters, the stream state is kept): equal to the per-layer hop under the same schedule."""
+    net = _net("pruned500k", cuda, pruned=True)
+    hop = net.total_stride
+    for S in (1, 300):
+        x = (0.1 * torch.randn(S, 12 * hop + 50, generator=torch.Generator().manual_seed(S))).to(cuda)
+        outs = {}
+        with torch.no_grad():
+            for kernel in (True, False):
+                net.reset_stream()
+                net.use_hop_kernel = kernel
+                outs[kernel] = torch.cat([net.feed_batch(x[:, :5 * hop]), net.feed_batch(x[:, 5 * hop:]), net.flush_batch()], 1)
+        assert outs[True].shape == (S, x.shape[1])
+        assert rel_l2(outs[True], outs[False]) < 5e-5
+    x = (0.1 * torch.randn(2, 20 * hop, generator=torch.Generator().manual_seed(9))).to(cuda)
+    outs = {}
+    w0 = net.decoder[3][0].weight.detach().clone()
+    with torch.no_grad():
+        for kernel in (True, False):
+            net.decoder[3][0].weight.copy_(w0)
+            net.reset_stream()
+            net.use_hop_kernel = kernel
+            a = net.feed_batch(x[:, :8 * hop])
+            if kernel:
+                assert net.hop_kernel_status == "active"
+            net.decoder[3][0].weight.mul_(1.5)                  # in place: bumps the parameter's version counter
+            b = net.feed_batch(x[:, 8 * hop:])
+            outs[kernel] = torch.cat([a, b, net.flush_batch()], 1)
+        net.decoder[3][0].weight.copy_(w0)
+    assert rel_l2(outs[True], outs[False]) < 5e-5
+    assert rel_l2(outs[True][:, 10 * hop:], outs[True][:, :10 * hop].new_zeros(1)) > 0          # (not trivially zero)
+
+
 def test_stream_after_flush_starts_a_fresh_running_std(cuda):
     """normalize_input=True: the running mean of the per-frame std (src/network/CleanUMamba.py:399-401) belongs to a
     stream.  A second clip fed after flush() must come out exactly as from a freshly constructed model."""

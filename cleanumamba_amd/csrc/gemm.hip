@@ -846,7 +846,7 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu((s
 #undef CUM_GLDS
 
   if constexpr (ROWS)   // (the single-buffered loop ends with a barrier: the LDS is free; 128 VGPRs: no slab of loads ahead)
-    nt_epilogue_any<T, EPI, 1, 0>(p, &acc, bv, m0, n0, wm, wn, lane,
+    nt_epilogue_any<T, EPI, 1, (EPI == EPI_GLU_BWD && sizeof(T) == 2) ? 1 : 0>(p, &acc, bv, m0, n0, wm, wn, lane,
                                   reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
   else
     nt_epilogue<T, EPI>(p, &acc, bv, m0, n0, wm, wn, g, r);

@@ -78,16 +78,18 @@ struct LnParams {
 };
 
 // grid: rows / 4 workgroups of 4 waves; wave = one row
-template <typename TX, typename TY>
+// MAXCH: 8-element chunks per lane -- 1 for d_model <= 512 (every shipped configuration: a quarter of the registers of the
+// general form, which keeps rows of up to 2048 in registers), else LN_MAXCH
+template <typename TX, typename TY, int MAXCH>
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const LnParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
   const TX *x = static_cast<const TX *>(p.x) + (row / p.len) * p.x_sb + (row % p.len) * p.x_sl;
-  float v[LN_MAXCH][8];
+  float v[MAXCH][8];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < MAXCH; ++i) {
     const int c = lane + 64 * i;
     if (c < p.nch) {
       ld8<TX>(x + 8 * c, v[i]);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const LnParams p
   const float mean = wave_sum(s) / p.dim;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i)
+  for (int i = 0; i < MAXCH; ++i)
     if (lane + 64 * i < p.nch) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const LnParams p
   }
   TY *y = static_cast<TY *>(p.y) + row * p.dim;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < MAXCH; ++i) {
     const int c = lane + 64 * i;
     if (c < p.nch) {
       float w[8], b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[8];
@@ -146,21 +148,21 @@ struct LnBwdParams {
 };
 
 // persistent workgroups: wave w of workgroup g walks rows g*4 + w, + 4*gridDim.x, ...
-template <typename TY, typename TH>
+template <typename TY, typename TH, int MAXCH>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const LnBwdParams p) {
-  __shared__ float red[4][2][LN_MAXCH * 64 * 8];        // per wave: dweight | dbias partials (first `dim` used): 64 KB
+  __shared__ float red[4][2][MAXCH * 64 * 8];           // per wave: dweight | dbias partials (first `dim` used): <= 64 KB
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float aw[LN_MAXCH][8], ab[LN_MAXCH][8];
+  float aw[MAXCH][8], ab[MAXCH][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i)
+  for (int i = 0; i < MAXCH; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) aw[i][j] = ab[i][j] = 0.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < p.rows; row += (int64_t)gridDim.x * 4) {
     const float mean = p.mean[row], rstd = p.rstd[row];
-    float g[LN_MAXCH][8], xh[LN_MAXCH][8];
+    float g[MAXCH][8], xh[MAXCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < MAXCH; ++i) {
       const int c = lane + 64 * i;
       if (c < p.nch) {
         float d[8], x[8], w[8];
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const LnBwdParam
     }
     const float c1 = wave_sum(s1) / p.dim, c2 = wave_sum(s2) / p.dim;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < MAXCH; ++i) {
       const int c = lane + 64 * i;
       if (c < p.nch) {
         float o[8];
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const LnBwdParam
   }
   // four waves -> one partial per workgroup, fixed order
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int i = 0; i < MAXCH; ++i) {
     const int c = lane + 64 * i;
     if (c < p.nch) {
 #pragma unroll
@@ -349,6 +351,21 @@ constexpr int kLnBwdGroups = 256;
 
 using namespace cum;
 
+#define LN_FWD(TX, TY)                                                                              \
+  do {                                                                                              \
+    if (p.nch <= 64)                                                                                \
+      hipLaunchKernelGGL((add_layernorm_fwd_kernel<TX, TY, 1>), grid, block, 0, st, p);            \
+    else                                                                                            \
+      hipLaunchKernelGGL((add_layernorm_fwd_kernel<TX, TY, LN_MAXCH>), grid, block, 0, st, p);     \
+  } while (0)
+#define LN_BWD(TY, TH)                                                                              \
+  do {                                                                                              \
+    if (p.nch <= 64)                                                                                \
+      hipLaunchKernelGGL((add_layernorm_bwd_kernel<TY, TH, 1>), grid, block, 0, st, p);            \
+    else                                                                                            \
+      hipLaunchKernelGGL((add_layernorm_bwd_kernel<TY, TH, LN_MAXCH>), grid, block, 0, st, p);     \
+  } while (0)
+
 static int ln_check(int64_t batch, int32_t len, int32_t dim) {
   CUM_REQUIRE(batch >= 0 && len >= 0 && dim >= 1 && dim <= 64 * 8 * LN_MAXCH, "add_layernorm: d_model must be 1 ... 2048");
   return CUM_OK;
@@ -390,19 +407,19 @@ extern "C" int cum_add_layernorm_fwd(int32_t x_dtype, int32_t y_dtype, int64_t b
     return CUM_OK;
   }
   if (x_dtype == CUM_F16 && y_dtype == CUM_F16)
-    hipLaunchKernelGGL((add_layernorm_fwd_kernel<f16, f16>), grid, block, 0, st, p);
+    LN_FWD(f16, f16);
   else if (x_dtype == CUM_F16)
-    hipLaunchKernelGGL((add_layernorm_fwd_kernel<f16, float>), grid, block, 0, st, p);
+    LN_FWD(f16, float);
   else if (y_dtype == CUM_F16)
-    hipLaunchKernelGGL((add_layernorm_fwd_kernel<float, f16>), grid, block, 0, st, p);
+    LN_FWD(float, f16);
   else if (x_dtype == CUM_BF16 && y_dtype == CUM_BF16)
-    hipLaunchKernelGGL((add_layernorm_fwd_kernel<__bf16, __bf16>), grid, block, 0, st, p);
+    LN_FWD(__bf16, __bf16);
   else if (x_dtype == CUM_BF16)
-    hipLaunchKernelGGL((add_layernorm_fwd_kernel<__bf16, float>), grid, block, 0, st, p);
+    LN_FWD(__bf16, float);
   else if (y_dtype == CUM_BF16)
-    hipLaunchKernelGGL((add_layernorm_fwd_kernel<float, __bf16>), grid, block, 0, st, p);
+    LN_FWD(float, __bf16);
   else
-    hipLaunchKernelGGL((add_layernorm_fwd_kernel<float, float>), grid, block, 0, st, p);
+    LN_FWD(float, float);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }
@@ -446,19 +463,19 @@ extern "C" int cum_add_layernorm_bwd(int32_t y_dtype, int32_t h_dtype, int64_t r
       hipLaunchKernelGGL((add_layernorm_bwd_any_kernel<float, float>), grid, block, 0, st, p);
   } else
   if (y_dtype == CUM_F16 && h_dtype == CUM_F16)
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<f16, f16>), grid, block, 0, st, p);
+    LN_BWD(f16, f16);
   else if (y_dtype == CUM_F16)
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<f16, float>), grid, block, 0, st, p);
+    LN_BWD(f16, float);
   else if (h_dtype == CUM_F16)
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<float, f16>), grid, block, 0, st, p);
+    LN_BWD(float, f16);
   else if (y_dtype == CUM_BF16 && h_dtype == CUM_BF16)
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<__bf16, __bf16>), grid, block, 0, st, p);
+    LN_BWD(__bf16, __bf16);
   else if (y_dtype == CUM_BF16)
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<__bf16, float>), grid, block, 0, st, p);
+    LN_BWD(__bf16, float);
   else if (h_dtype == CUM_BF16)
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<float, __bf16>), grid, block, 0, st, p);
+    LN_BWD(float, __bf16);
   else
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<float, float>), grid, block, 0, st, p);
+    LN_BWD(float, float);
   CUM_CHECK_LAUNCH();
   hipLaunchKernelGGL(add_layernorm_bwd_finalize_kernel, dim3((2 * dim + 63) / 64), dim3(256), 0, st, workspace, groups,
                      dim, dweight, dbias);

@@ -17,7 +17,7 @@
 //   * conv_state / ssm_state of every Mamba block, the running input std, its frame count, the ring phase.
 //
 // The kernel is an INTERPRETER of a short op list the host compiles from the model (cleanumamba_amd/network/hopplan.py:
-// ~75 ops for an E8 model with 3 blocks; copied into LDS once per launch): every op names its LDS places and its
+// ~75 ops for an E8 model with 3 blocks; read by scalar loads: every op names its LDS places and its
 // offsets into the weight blob / the state block, ends with a workgroup barrier, and is one of: input std, first
 // encoder conv (1 input channel: VALU), matrix product (below), ring append + carry, add + LayerNorm, Mamba conv step,
 // Mamba state update, decoder overlap-add.  Why a table and not straight-line code: the first version inlined a
@@ -86,10 +86,17 @@ __device__ int hop_probe_on;
 
 extern __shared__ __attribute__((aligned(16))) float hop_lds[];
 typedef const __attribute__((address_space(1))) f4 *hop_gf4;      // global (not flat) 16-byte loads
+typedef const __attribute__((address_space(4))) int *hop_cint;    // constant: uniform addresses become scalar loads
 
 __device__ __forceinline__ f4 hop_ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 __device__ __forceinline__ void hop_st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
 __device__ __forceinline__ f4 hop_gld4(const float *p) { return *(hop_gf4)p; }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding GLOBAL access
+// (s_waitcnt vmcnt(0)), i.e. parks each of a hop's ~75 ops behind its non-temporal state stores.  Ops hand their results
+// to each other through LDS; the stream state in HBM is re-read either by the thread that wrote it or one hop later,
+// behind the full barrier that ends a hop (the running std, read by all and written by one, keeps a full barrier too).
+__device__ __forceinline__ void hop_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float hop_wave_sum(float v) {
 #pragma unroll
@@ -100,9 +107,9 @@ __device__ __forceinline__ float hop_wave_sum(float v) {
 // sum over the workgroup; every thread gets it.  `red` holds kHopWaves floats.
 __device__ __forceinline__ float hop_block_sum(float v, float *red, int wave, int lane) {
   v = hop_wave_sum(v);
-  __syncthreads();
+  hop_barrier();
   if (lane == 0) red[wave] = v;
-  __syncthreads();
+  hop_barrier();
   float t = 0.f;
 #pragma unroll
   for (int w = 0; w < kHopWaves; ++w) t += red[w];
@@ -158,8 +165,8 @@ __device__ __forceinline__ int hop_fdiv(int a, float inv) { return (int)(((float
 // the latency of the weight stream.  The bookkeeping between two stages is a dozen scalar instructions: a cursor
 // stepped with compares (no integer division -- the first pipelined version decoded item numbers with / and % and
 // round-robin items, 300-600 instructions = 1-2 k cycles per stage) and loads at immediate offsets from one base
-// address per stage.  No load sits behind a branch: a short or finished stage simply loads what follows its tile in the
-// weight blob (the host pads the blob's end), so the compiler's vmcnt counting stays exact.
+// address per stage.  A short stage simply loads what follows its tile in the weight blob (the host pads the blob's end);
+// only the stage behind a wave's last one is not requested.
 // ks / kcs (k slices, chunks per slice) and MT come from the host, which prices the candidates per product
 // (hopplan.py::_split: the MFMA work of the busiest SIMD, per-item and per-stage overheads, the re-read of the weights).
 struct HopCur {
@@ -273,7 +280,7 @@ __device__ __forceinline__ void hop_gemm(const float *__restrict__ wb, const Hop
     while (c.left > 0) {
       HopCur c2 = c;
       advance(c2);
-      load(wB, bB0, bB1, c2);
+      if (c2.left > 0) load(wB, bB0, bB1, c2);
       HOP_FINE(fine);
       ++fine;
       compute(wA, bA0, bA1, c);
@@ -282,7 +289,7 @@ __device__ __forceinline__ void hop_gemm(const float *__restrict__ wb, const Hop
       if (c2.left <= 0) break;
       c = c2;
       advance(c);
-      load(wA, bA0, bA1, c);
+      if (c.left > 0) load(wA, bA0, bA1, c);
       HOP_FINE(fine);
       ++fine;
       compute(wB, bB0, bB1, c2);
@@ -292,7 +299,7 @@ __device__ __forceinline__ void hop_gemm(const float *__restrict__ wb, const Hop
     HOP_FINE(fine);
   }
   if (ks > 1) {
-    __syncthreads();
+    hop_barrier();
     HOP_FINE(30);
     const float inv_ntg = 1.f / (float)ntg;
     for (int u = tid; u < base * MT * 64; u += kHopThreads) {
@@ -326,9 +333,9 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   float *st = state + (int64_t)blockIdx.x * state_stride;
   const int n_ops = plan->n_ops, frame_len = plan->frame_len, hop_len = plan->hop_len, phase_off = plan->phase_off;
-  int *optab = reinterpret_cast<int *>(lds + plan->ops_lds);
-  for (int i = tid; i < n_ops * kHopOpInts; i += kHopThreads) optab[i] = plan->ops[i];
-  __syncthreads();
+  // ops are read with SCALAR loads from the plan (constant address space: s_load_dwordx8 / x16 straight into scalar
+  // registers, served by the scalar cache all workgroups share) -- through LDS they cost 24 v_readfirstlane per op
+  const hop_cint ops = (hop_cint)(uintptr_t)plan->ops;
 
   for (int hop = 0; hop < n_hops; ++hop) {
     const float *frame = in + (int64_t)blockIdx.x * in_stride + (int64_t)hop * hop_len;
@@ -340,16 +347,12 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
     for (int pc = 0; pc < n_ops; ++pc) {
       int f[kHopOpInts];
       {
-        const int4 *src = reinterpret_cast<const int4 *>(optab + pc * kHopOpInts);
+        const hop_cint src = ops + pc * kHopOpInts;
 #pragma unroll
-        for (int i = 0; i < kHopOpInts / 4; ++i) {
-          const int4 v = src[i];
-          f[4 * i] = uniform(v.x), f[4 * i + 1] = uniform(v.y), f[4 * i + 2] = uniform(v.z), f[4 * i + 3] = uniform(v.w);
-        }
+        for (int i = 0; i < kHopOpInts; ++i) f[i] = src[i];
       }
 #ifdef CUM_HOP_PROBE
-      if (tid == 0 && blockIdx.x == 0) hop_probe_on = (pc == CUM_HOP_PROBE_PC && hop == n_hops - 1);
-      __syncthreads();
+      if (tid == 0 && blockIdx.x == 0) hop_probe_on = (pc == CUM_HOP_PROBE_PC && hop == n_hops - 1);   // (thread 0 reads it)
 #endif
       switch (f[0]) {
         case kOpStd: {
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
         default:
           break;
       }
-      __syncthreads();
+      hop_barrier();
       HOP_STAMP(pc + 1);
     }
     if (tid == 0) st[phase_off] = (float)((phase + 1) % 3);

@@ -39,14 +39,14 @@ namespace cum {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHopThreads = 512, kHopWaves = 8;
-constexpr int kHopMaxOps = 160, kHopOpInts = 24, kHopHdrInts = 16;
-constexpr int kHopMagic = 0x486f7032;      // "Hop2"
+constexpr int kHopMaxOps = 160, kHopOpInts = 24, kHopHdrInts = 16, kHopMaxStages = 8192;
+constexpr int kHopMagic = 0x486f7033;      // "Hop3"
 
 enum {
   kOpEnd = 0,      // -
   kOpStd = 1,      // -, std_off
   kOpEnc0 = 2,     // n, ld_h, w1, b1, x (LDS), h (LDS), ph
-  kOpGemm = 3,     // HopG (18 ints), nacc, ks, kcs, mt (16-row tiles per item: 1, 2 or 4)
+  kOpGemm = 3,     // HopG (18 ints), nacc, ks, kcs, mt (16-row tiles per item: 1, 2 or 4); its stages: wtab / stages
   kOpRing = 4,     // n, ldo, ring, src (LDS), po, carry (LDS)
   kOpLn = 5,       // hs, res, out (LDS), w, b, eps bits, dm, dmp, has_res
   kOpConvStep = 6, // di, dip, W, conv_state, conv_w, conv_b, xz (LDS), x (LDS)
@@ -56,8 +56,10 @@ enum {
 
 // int32 header + ops; the host fills it as a flat int32 array (cum_stream_hop_plan_ints()).
 struct HopPlan {
-  int32_t magic, n_ops, frame_len, hop_len, lds_floats, phase_off, ops_lds, pad[kHopHdrInts - 7];
+  int32_t magic, n_ops, frame_len, hop_len, lds_floats, phase_off, ops_lds, n_stages, pad[kHopHdrInts - 8];
   int32_t ops[kHopMaxOps * kHopOpInts];
+  int32_t wtab[kHopMaxOps * kHopWaves];      // per op and wave: first stage | stage count << 16
+  int32_t stages[kHopMaxStages * 4];         // {weight offset, operand offset, nb | first << 3 | last << 4, out}
 };
 
 // -DCUM_HOP_PROBE (tools/hop_phase_probe.py): s_memtime stamp of workgroup 0 after every op of its last hop
@@ -159,81 +161,80 @@ __device__ __forceinline__ int hop_wrap(int a, int n) {      // a mod n for 0 <=
 // floor(a / d) for small non-negative a (< 2^15) and d (<= 2^10) without the ~40-instruction integer division: inv = 1 / d
 __device__ __forceinline__ int hop_fdiv(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
-// A wave's work is a flat sequence of STAGES (item, D consecutive k-chunks of it) over a CONTIGUOUS range of items
-// (tile group fastest, then row group, then k slice); the fragment loads of stage s + 1 are issued before the MFMAs of
-// stage s (two register sets), across item boundaries too: the deep layers' items are 1-8 chunks long and their time is
-// the latency of the weight stream.  The bookkeeping between two stages is a dozen scalar instructions: a cursor
-// stepped with compares (no integer division -- the first pipelined version decoded item numbers with / and % and
-// round-robin items, 300-600 instructions = 1-2 k cycles per stage) and loads at immediate offsets from one base
-// address per stage.  A short stage simply loads what follows its tile in the weight blob (the host pads the blob's end);
-// only the stage behind a wave's last one is not requested.
-// ks / kcs (k slices, chunks per slice) and MT come from the host, which prices the candidates per product
-// (hopplan.py::_split: the MFMA work of the busiest SIMD, per-item and per-stage overheads, the re-read of the weights).
-struct HopCur {
-  int tg, mg, sl, k0, left;
+// A wave's work on a product is a flat list of STAGES the HOST compiled (hopplan.py::_stages): up to 4 consecutive
+// 16-deep k chunks of one work item (tile group, group of MT 16-row tiles, k slice) that are consecutive in the weight
+// blob AND in the LDS operand (a stage never straddles two input rows of a strided conv), with the blob offset of its
+// first fragment, the LDS offset of its first operand chunk, its chunk count, whether it opens an item (accumulators
+// start at zero) or closes one (epilogue, or the partial sums of a k slice into the scratch) and where the result goes.
+// The wave fetches ITS list for the op with one 16-byte load per lane (lane i = stage i, <= 64 stages) -- requested one
+// op ahead -- and reads a stage's four words with v_readlane; the fragment loads of stage s + 1 are issued before the
+// MFMAs of stage s (two register sets).  History: the cursor that walked items and chunks in the kernel cost ~380
+// instructions per op and wave, and that path length -- not the weights' latency, not the MFMAs of 16-row tiles that
+// hold 1-8 real rows -- was the deep layers' time.
+typedef int i4 __attribute__((ext_vector_type(4)));
+struct HopStage {
+  int woff, xoff, meta, out;
 };
+__device__ __forceinline__ HopStage hop_stage(const i4 &v, int i) {
+  HopStage t;
+  t.woff = __builtin_amdgcn_readlane(v[0], i);
+  t.xoff = __builtin_amdgcn_readlane(v[1], i);
+  t.meta = __builtin_amdgcn_readlane(v[2], i);
+  t.out = __builtin_amdgcn_readlane(v[3], i);
+  return t;
+}
+
 template <int NACC, int MT>
-__device__ __forceinline__ void hop_gemm(const float *__restrict__ wb, const HopG &g, int ks, int kcs, int tid, int wave,
-                                         int lane) {
+__device__ __forceinline__ void hop_gemm(const float *__restrict__ wb, const HopG &g, int ks, const i4 &dsc, int count,
+                                         int tid, int lane) {
   constexpr int D = 4;
   const int lr = lane & 15, lg = lane >> 4;
-  const int ntg = g.ntg, kcn = g.kcn, M = g.M, kpr = g.kpr;
+  const int ntg = g.ntg, M = g.M;
   const int mgs = (M + 16 * MT - 1) / (16 * MT);
   const int base = ntg * mgs;
   constexpr int blk = NACC * MT * 256;
-  const float *xbase = hop_lds + g.x + lr * g.xs + 4 * lg;
-  const hop_gf4 wbase = (hop_gf4)(wb + g.w) + lane;
+  const float *xlane = hop_lds + lr * g.xs + 4 * lg;
+  const hop_gf4 wlane = (hop_gf4)wb + lane;
+  const int w2 = g.kcn * 64;                       // second accumulator's fragments, in 16-byte units
   const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
   f4 acc[NACC][MT];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[a][mt] = zero;
 
-  auto advance = [&](HopCur &c) {
-    c.k0 += D;
-    if (c.k0 >= min(kcn, c.sl * kcs + kcs)) {
-      --c.left;
-      if (++c.tg == ntg) {
-        c.tg = 0;
-        if (++c.mg == mgs) {
-          c.mg = 0;
-          ++c.sl;
-        }
+  // fragment (and, for a closing stage of an unsplit product, bias) loads of a stage
+  auto load = [&](f4 (&wv)[D][NACC], f4 &b0, f4 &b1, const HopStage &t) {
+    const hop_gf4 wp = wlane + (t.woff >> 2);
+    const int nb = t.meta & 7;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (d < nb) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) wv[d][a] = wp[a * w2 + d * 64];
       }
-      c.k0 = c.sl * kcs;
+    }
+    if ((t.meta & 16) && ks == 1) {
+      const int n0 = (t.out & 0xffff) + 4 * lg;
+      if (g.bias >= 0) b0 = hop_gld4(wb + g.bias + n0);
+      if (NACC > 1) b1 = hop_gld4(wb + g.bias2 + n0);
     }
   };
-  // fragment (and bias) loads of a stage: D chunks from one base address
-  auto load = [&](f4 (&wv)[D][NACC], f4 &b0, f4 &b1, const HopCur &c) {
-    hop_gf4 wp = wbase + ((int64_t)c.tg * NACC * kcn + c.k0) * 64;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-      hop_gf4 wa = wp + (int64_t)a * kcn * 64;
-#pragma unroll
-      for (int d = 0; d < D; ++d) wv[d][a] = wa[d * 64];
-    }
-    const int n0 = c.tg * 16 + 4 * lg;
-    const f4 bq = hop_gld4(wb + max(g.bias, 0) + n0);          // (always one load; "no bias" selects zero afterwards)
-    b0 = g.bias >= 0 ? bq : zero;
-    if (NACC > 1) b1 = hop_gld4(wb + g.bias2 + n0);
-  };
-  auto compute = [&](const f4 (&wv)[D][NACC], const f4 &b0, const f4 &b1, const HopCur &c) {
-    const int m0 = c.mg * (16 * MT);
-    const int kc0 = c.sl * kcs, kc1 = min(kcn, kc0 + kcs);
-    if (c.k0 == kc0) {
+  auto compute = [&](const f4 (&wv)[D][NACC], const f4 &b0, const f4 &b1, const HopStage &t) {
+    const int nb = t.meta & 7;
+    if (t.meta & 8) {
 #pragma unroll
       for (int a = 0; a < NACC; ++a)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[a][mt] = zero;
     }
-    const float *xp = xbase + m0 * g.xs;
-    const int nb = min(D, kc1 - c.k0);
+    const float *xp = xlane + t.xoff;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       if (d < nb) {
-        const int kc = c.k0 + d;
-        const int sg = (kc >= kpr) + (kc >= 2 * kpr) + (kc >= 3 * kpr);      // kcn <= 4 kpr
-        const int xo = sg * g.seg + (kc - sg * kpr) * 16;
         f4 xv[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xv[mt] = hop_ld4(xp + mt * 16 * g.xs + xo);
+        for (int mt = 0; mt < MT; ++mt) xv[mt] = hop_ld4(xp + mt * 16 * g.xs + d * 16);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -243,15 +244,16 @@ __device__ __forceinline__ void hop_gemm(const float *__restrict__ wb, const Hop
               acc[a][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[d][a][j], xv[mt][j], acc[a][mt], 0, 0, 0);
       }
     }
-    if (c.k0 + D >= kc1) {          // last stage of the item
+    if (t.meta & 16) {              // last stage of the item
       if (ks == 1) {
+        const int n0 = t.out & 0xffff, m0 = t.out >> 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int m = m0 + mt * 16 + lr;
-          if (m < M) hop_epi<NACC>(g, c.tg * 16 + 4 * lg, m, acc[0][mt], acc[NACC - 1][mt], b0, b1);
+          if (m < M) hop_epi<NACC>(g, n0 + 4 * lg, m, acc[0][mt], acc[NACC - 1][mt], b0, b1);
         }
       } else {
-        float *P = hop_lds + g.scratch + ((c.sl * mgs + c.mg) * ntg + c.tg) * blk;
+        float *P = hop_lds + t.out;
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -259,42 +261,35 @@ __device__ __forceinline__ void hop_gemm(const float *__restrict__ wb, const Hop
       }
     }
   };
-  {
-    f4 wA[D][NACC], wB[D][NACC], bA0, bA1 = zero, bB0, bB1 = zero;
-    // this wave's items: [wave * ipw, wave * ipw + ipw) of base * ks
-    const int items = base * ks, ipw = (items + kHopWaves - 1) / kHopWaves;
-    const int i0 = wave * ipw;
-    HopCur c;
-    {
-      const int q1 = uniform(hop_fdiv(i0, 1.f / (float)ntg));
-      c.tg = i0 - q1 * ntg;
-      c.sl = uniform(hop_fdiv(q1, 1.f / (float)mgs));
-      c.mg = q1 - c.sl * mgs;
-      c.k0 = c.sl * kcs;
-      c.left = min(ipw, items - i0);
-    }
+  if (count > 0) {
+    f4 wA[D][NACC], wB[D][NACC], bA0 = zero, bA1 = zero, bB0 = zero, bB1 = zero;
+    HopStage tA = hop_stage(dsc, 0), tB;
     HOP_FINE(0);
-    load(wA, bA0, bA1, c);
+    load(wA, bA0, bA1, tA);
     HOP_FINE(1);
     int fine = 2;
-    while (c.left > 0) {
-      HopCur c2 = c;
-      advance(c2);
-      if (c2.left > 0) load(wB, bB0, bB1, c2);
+    for (int i = 0;;) {
+      if (i + 1 < count) {
+        tB = hop_stage(dsc, i + 1);
+        load(wB, bB0, bB1, tB);
+      }
       HOP_FINE(fine);
       ++fine;
-      compute(wA, bA0, bA1, c);
+      compute(wA, bA0, bA1, tA);
       HOP_FINE(fine);
       ++fine;
-      if (c2.left <= 0) break;
-      c = c2;
-      advance(c);
-      if (c.left > 0) load(wA, bA0, bA1, c);
+      if (i + 1 >= count) break;
+      if (i + 2 < count) {
+        tA = hop_stage(dsc, i + 2);
+        load(wA, bA0, bA1, tA);
+      }
       HOP_FINE(fine);
       ++fine;
-      compute(wB, bB0, bB1, c2);
+      compute(wB, bB0, bB1, tB);
       HOP_FINE(fine);
       ++fine;
+      i += 2;
+      if (i >= count) break;
     }
     HOP_FINE(fine);
   }
@@ -336,6 +331,16 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
   // ops are read with SCALAR loads from the plan (constant address space: s_load_dwordx8 / x16 straight into scalar
   // registers, served by the scalar cache all workgroups share) -- through LDS they cost 24 v_readfirstlane per op
   const hop_cint ops = (hop_cint)(uintptr_t)plan->ops;
+  const hop_cint wtab = (hop_cint)(uintptr_t)plan->wtab;
+  const __attribute__((address_space(1))) i4 *stages = (const __attribute__((address_space(1))) i4 *)plan->stages;
+  // this wave's stage list of the op about to run (lane i = stage i), requested while the op in front of it ran
+  i4 dsc = i4{0, 0, 0, 0};
+  int dcount = 0;
+  if (ops[0] == kOpGemm) {
+    const int wt = wtab[wave];
+    dcount = wt >> 16;
+    if (lane < dcount) dsc = stages[(wt & 0xffff) + lane];
+  }
 
   for (int hop = 0; hop < n_hops; ++hop) {
     const float *frame = in + (int64_t)blockIdx.x * in_stride + (int64_t)hop * hop_len;
@@ -350,6 +355,17 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
         const hop_cint src = ops + pc * kHopOpInts;
 #pragma unroll
         for (int i = 0; i < kHopOpInts; ++i) f[i] = src[i];
+      }
+      // the next op's stage list (the next hop's first op behind the last): in flight while this op runs
+      i4 ndsc = i4{0, 0, 0, 0};
+      int ncount = 0;
+      {
+        const int pn = pc + 1 == n_ops ? 0 : pc + 1;
+        if (ops[pn * kHopOpInts] == kOpGemm) {
+          const int wt = wtab[pn * kHopWaves + wave];
+          ncount = wt >> 16;
+          if (lane < ncount) ndsc = stages[(wt & 0xffff) + lane];
+        }
       }
 #ifdef CUM_HOP_PROBE
       if (tid == 0 && blockIdx.x == 0) hop_probe_on = (pc == CUM_HOP_PROBE_PC && hop == n_hops - 1);   // (thread 0 reads it)
@@ -399,18 +415,18 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
           g.pitch = f[15], g.row_off = f[16], g.act = f[17], g.nlimit = f[18];
           if (f[19] == 1) {
             if (f[22] == 1)
-              hop_gemm<1, 1>(w, g, f[20], f[21], tid, wave, lane);
+              hop_gemm<1, 1>(w, g, f[20], dsc, dcount, tid, lane);
             else if (f[22] == 2)
-              hop_gemm<1, 2>(w, g, f[20], f[21], tid, wave, lane);
+              hop_gemm<1, 2>(w, g, f[20], dsc, dcount, tid, lane);
             else
-              hop_gemm<1, 4>(w, g, f[20], f[21], tid, wave, lane);
+              hop_gemm<1, 4>(w, g, f[20], dsc, dcount, tid, lane);
           } else {
             if (f[22] == 1)
-              hop_gemm<2, 1>(w, g, f[20], f[21], tid, wave, lane);
+              hop_gemm<2, 1>(w, g, f[20], dsc, dcount, tid, lane);
             else if (f[22] == 2)
-              hop_gemm<2, 2>(w, g, f[20], f[21], tid, wave, lane);
+              hop_gemm<2, 2>(w, g, f[20], dsc, dcount, tid, lane);
             else
-              hop_gemm<2, 4>(w, g, f[20], f[21], tid, wave, lane);
+              hop_gemm<2, 4>(w, g, f[20], dsc, dcount, tid, lane);
           }
         } break;
         case kOpRing: {
@@ -539,6 +555,8 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
       }
       hop_barrier();
       HOP_STAMP(pc + 1);
+      dsc = ndsc;
+      dcount = ncount;
     }
     if (tid == 0) st[phase_off] = (float)((phase + 1) % 3);
     __syncthreads();

@@ -95,6 +95,82 @@ def test_every_shipped_checkpoint_gets_a_plan_inside_its_ranges(name):
     assert plan.flops_per_hop > 0
 
 
+@pytest.mark.parametrize("name", ["442k", "pruned500k", "e6_pruned2m"])
+def test_stage_lists_compute_every_product(name):
+    """The per-wave stage lists the kernel walks (hopplan._stages), emulated in numpy on the packed weight blob and a
+    random LDS image: every product of the hop comes out as W . x of its op (k order, k split and epilogue placement
+    included), every (tile, row) is produced exactly once, and the lists fit the kernel's tables."""
+    from cleanumamba_amd.network import hopplan
+    plan = hopplan.HopPlan(_net(name))
+    ints = plan.plan.numpy()
+    blob = plan.weights.numpy().astype(np.float64)
+    lds_floats = int(ints[4])
+    rng = np.random.default_rng(0)
+    lds = rng.standard_normal(lds_floats + 4096)
+    wtab0 = hopplan._HDR_INTS + hopplan._MAX_OPS * hopplan._OP_INTS
+    stg0 = wtab0 + hopplan._MAX_OPS * hopplan._WAVES
+    total = 0
+    for k, op in enumerate(plan.ops):
+        if op[0] != hopplan._OP_GEMM:
+            assert not ints[wtab0 + 8 * k:wtab0 + 8 * k + 8].any()
+            continue
+        (_, w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias, bias2, add, pitch, row_off, act, nlimit, nacc, ks,
+         kcs, mt) = op
+        # reference: out[a][n][m] = sum_k W_a[n][k] X[m][k] from the op's own description
+        frag = blob[w:w + ntg * nacc * kcn * 256].reshape(ntg, nacc, kcn, 4, 16, 4)        # [tile][acc][kc][g][r][j]
+        W = frag.transpose(1, 0, 4, 2, 3, 5).reshape(nacc, ntg * 16, kcn * 16)             # k = kc * 16 + 4 g + j
+        X = np.empty((M, kcn * 16))
+        for kc in range(kcn):
+            sg = kc // kpr
+            for m in range(M):
+                a0 = x + m * xs + sg * seg + (kc - sg * kpr) * 16
+                X[m, kc * 16:kc * 16 + 16] = lds[a0:a0 + 16]
+        ref = np.einsum("ank,mk->anm", W, X)
+        # the kernel's walk
+        mgs = (M + 16 * mt - 1) // (16 * mt)
+        got = np.full((nacc, ntg * 16, mgs * mt * 16), np.nan)
+        part = {}
+        for wave in range(hopplan._WAVES):
+            wt = int(ints[wtab0 + 8 * k + wave])
+            start, count = wt & 0xffff, wt >> 16
+            assert count <= hopplan._MAX_WAVE_STAGES and count == len(plan.stages[k][wave])
+            total += count
+            acc = None
+            for t in ints[stg0 + 4 * start:stg0 + 4 * (start + count)].reshape(count, 4):
+                woff, xoff, meta, out = (int(v) for v in t)
+                nb, first, last = meta & 7, meta >> 3 & 1, meta >> 4 & 1
+                assert 1 <= nb <= 4 and woff % 4 == 0 and xoff % 4 == 0
+                if first:
+                    acc = np.zeros((nacc, 16, mt * 16))
+                for d in range(nb):
+                    for a in range(nacc):
+                        ch = blob[woff + (a * kcn + d) * 256:woff + (a * kcn + d) * 256 + 256].reshape(4, 16, 4)   # [g][r][j]
+                        Wc = ch.transpose(1, 0, 2).reshape(16, 16)
+                        for r in range(mt * 16):
+                            a0 = xoff + r * xs + d * 16
+                            acc[a, :, r] += Wc @ lds[a0:a0 + 16]
+                if last:
+                    if ks == 1:
+                        n0, m0 = out & 0xffff, out >> 16
+                        assert np.isnan(got[:, n0:n0 + 16, m0:m0 + mt * 16]).all(), "a tile produced twice"
+                        got[:, n0:n0 + 16, m0:m0 + mt * 16] = acc
+                    else:
+                        assert scratch <= out and out + nacc * mt * 256 <= scratch + cap and out not in part
+                        part[out] = acc
+                    acc = None
+            assert acc is None
+        if ks > 1:
+            base, blk = ntg * mgs, nacc * mt * 256
+            for b in range(base):
+                bm, tg = b // ntg, b % ntg
+                tot = sum(part.pop(scratch + (sl * base + b) * blk) for sl in range(ks))
+                got[:, tg * 16:tg * 16 + 16, bm * mt * 16:(bm + 1) * mt * 16] = tot
+            assert not part
+        assert not np.isnan(got).any()
+        np.testing.assert_allclose(got[:, :, :M], ref, rtol=1e-9, atol=1e-9)
+    assert total == int(ints[7]) <= hopplan._MAX_STAGES
+
+
 def test_models_outside_the_kernel_keep_the_per_layer_hop():
     from cleanumamba_amd.network import CleanUMamba, hopplan
     big = CleanUMamba(channels_input=1, channels_output=1, channels_H=64, max_H=768, encoder_n_layers=8, kernel_size=4,

@@ -21,8 +21,7 @@ from . import convstack as cs
 _OP_END, _OP_STD, _OP_ENC0, _OP_GEMM, _OP_RING, _OP_LN, _OP_CONVSTEP, _OP_SSM, _OP_OVERLAP = range(9)
 _ACT_NONE, _ACT_RELU, _ACT_SOFTPLUS = 0, 1, 2
 _HDR_INTS, _OP_INTS, _MAX_OPS, _MAX_LAYERS, _MAX_BLOCKS = 16, 24, 160, 12, 8
-_MAX_STAGES, _MAX_WAVE_STAGES = 8192, 64      # csrc/hop.hip::kHopMaxStages; a wave's list of one op is one 64-lane load
-_MAGIC = 0x486f7033
+_MAGIC = 0x486f7032
 _BIG = 1 << 30
 _WAVES = 8           # waves of the kernel's workgroup (csrc/hop.hip::kHopWaves)
 # every stream re-reads all weights from L2 once per hop: above this the per-layer path (streams batched as GEMM rows)
@@ -104,42 +103,6 @@ def _split(ntg, kcn, M, nacc, cap):
     return best[1], best[2]
 
 
-def _stages(op):
-    """Per-wave stage lists of one matrix product, as csrc/hop.hip::hop_gemm walks them: [[(weight offset, operand offset,
-    meta, out)] per wave].  Work items (tile group fastest, then group of ``mt`` 16-row tiles, then k slice) are dealt to
-    the waves in contiguous runs; an item's k range is cut into stages of <= 4 chunks that stay inside one k segment
-    (the 4 input rows of a strided conv are 4 segments of the same LDS image), walked in ascending k: the order of the
-    fma chain -- and so every bit of the result -- is the k order, whatever the split.
-    meta = chunks | first stage of the item << 3 | last << 4;  out of a last stage = first output channel | first row
-    << 16 (unsplit product: the epilogue runs in place) or the LDS offset of the slice's partial sums (k split)."""
-    (_, w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias, bias2, add, pitch, row_off, act, nlimit, nacc, ks, kcs,
-     mt) = op
-    mgs = (M + 16 * mt - 1) // (16 * mt)
-    base = ntg * mgs
-    items = base * ks
-    ipw = (items + _WAVES - 1) // _WAVES
-    blk = nacc * mt * 256
-    waves = []
-    for wave in range(_WAVES):
-        lst = []
-        for it in range(wave * ipw, min(items, wave * ipw + ipw)):
-            tg, q = it % ntg, it // ntg
-            mg, sl = q % mgs, q // mgs
-            k, k1, first = sl * kcs, min(kcn, sl * kcs + kcs), 1
-            while k < k1:
-                sg = k // kpr
-                e = min(k + 4, k1, (sg + 1) * kpr)
-                last = int(e == k1)
-                out = tg * 16
-                if last:
-                    out = (tg * 16) | ((mg * 16 * mt) << 16) if ks == 1 else scratch + ((sl * mgs + mg) * ntg + tg) * blk
-                lst.append((w + (tg * nacc * kcn + k) * 256, x + mg * 16 * mt * xs + sg * seg + (k - sg * kpr) * 16,
-                            (e - k) | first << 3 | last << 4, out))
-                k, first = e, 0
-        waves.append(lst)
-    return waves
-
-
 def unsupported_reason(model):
     """None if the one-launch hop can run this model, else why not."""
     E = model.encoder_n_layers
@@ -177,7 +140,7 @@ class HopPlan:
         hop = model.total_stride
         frame_len = model.valid_length(1)
         blob = _Blob()
-        ints = np.zeros(_HDR_INTS + _MAX_OPS * _OP_INTS + _MAX_OPS * _WAVES + _MAX_STAGES * 4, dtype=np.int32)
+        ints = np.zeros(_HDR_INTS + _MAX_OPS * _OP_INTS, dtype=np.int32)
         if ints.size != hip.lib().cum_stream_hop_plan_ints():
             raise RuntimeError("hopplan.py and csrc/hop.hip disagree about the plan's size")
         state_off = 4                     # [std, frames seen, phase, -]
@@ -372,25 +335,9 @@ class HopPlan:
         self.lds_bytes = _rup(4 * lds_floats, 16)
         if self.lds_bytes > hip.lib().cum_stream_hop_max_lds_bytes():
             raise ValueError(f"a hop of this model needs {self.lds_bytes} bytes of LDS")
+        ints[:7] = [_MAGIC, len(ops), frame_len, hop, lds_floats, hdr["phase_off"], ops_lds]
         for k, op in enumerate(ops):
             ints[_HDR_INTS + k * _OP_INTS:_HDR_INTS + k * _OP_INTS + len(op)] = op
-        # the products' stage lists: wtab[op][wave] = first stage | count << 16, then the stages themselves
-        wtab0 = _HDR_INTS + _MAX_OPS * _OP_INTS
-        stg0 = wtab0 + _MAX_OPS * _WAVES
-        n_stages = 0
-        self.stages = {}
-        for k, op in enumerate(ops):
-            if op[0] != _OP_GEMM:
-                continue
-            self.stages[k] = _stages(op)
-            for wave, lst in enumerate(self.stages[k]):
-                if len(lst) > _MAX_WAVE_STAGES or n_stages + len(lst) > min(_MAX_STAGES, 65535):
-                    raise ValueError("a product of this model has more stages than the hop kernel's tables hold")
-                ints[wtab0 + k * _WAVES + wave] = n_stages | len(lst) << 16
-                for t in lst:
-                    ints[stg0 + 4 * n_stages:stg0 + 4 * n_stages + 4] = t
-                    n_stages += 1
-        ints[:8] = [_MAGIC, len(ops), frame_len, hop, lds_floats, hdr["phase_off"], ops_lds, n_stages]
         self.ops = ops
         self.hdr, self.encs, self.decs, self.blks = hdr, encs, decs, blks
         self.plan = torch.from_numpy(ints).to(dev)

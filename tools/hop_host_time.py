@@ -1,6 +1,15 @@
 import json, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os
+if os.environ.get("CUM_HOPPLAN_OLD"):        # same-box A/B against an older plan format: tools/_ab/hopplan_old.py + its CUM_LIB
+    import importlib.util
+    import cleanumamba_amd.hip  # noqa: F401
+    spec = importlib.util.spec_from_file_location("cleanumamba_amd.network.hopplan", os.environ["CUM_HOPPLAN_OLD"])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["cleanumamba_amd.network.hopplan"] = mod
+    import cleanumamba_amd.network.convstack  # noqa: F401
+    spec.loader.exec_module(mod)
 from cleanumamba_amd.network import CleanUMamba
 dev = torch.device("cuda")
 with np.load("tests/golden/ckpt_pruned500k.npz") as f:

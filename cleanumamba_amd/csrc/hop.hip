@@ -336,10 +336,10 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
   // this wave's stage list of the op about to run (lane i = stage i), requested while the op in front of it ran
   i4 dsc = i4{0, 0, 0, 0};
   int dcount = 0;
-  if (ops[0] == kOpGemm) {
+  {
     const int wt = wtab[wave];
     dcount = wt >> 16;
-    if (lane < dcount) dsc = stages[(wt & 0xffff) + lane];
+    dsc = stages[(wt & 0xffff) + min(lane, max(dcount - 1, 0))];
   }
 
   for (int hop = 0; hop < n_hops; ++hop) {
@@ -357,15 +357,14 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
         for (int i = 0; i < kHopOpInts; ++i) f[i] = src[i];
       }
       // the next op's stage list (the next hop's first op behind the last): in flight while this op runs
-      i4 ndsc = i4{0, 0, 0, 0};
-      int ncount = 0;
+      i4 ndsc;
+      int ncount;
+      // (no branch around the request -- other ops have an empty list and fetch stage 0: behind a branch the compiler
+      //  cannot count the loads in flight and drains them all, this one included, in front of the op's first stage)
       {
-        const int pn = pc + 1 == n_ops ? 0 : pc + 1;
-        if (ops[pn * kHopOpInts] == kOpGemm) {
-          const int wt = wtab[pn * kHopWaves + wave];
-          ncount = wt >> 16;
-          if (lane < ncount) ndsc = stages[(wt & 0xffff) + lane];
-        }
+        const int wt = wtab[(pc + 1 == n_ops ? 0 : pc + 1) * kHopWaves + wave];
+        ncount = wt >> 16;
+        ndsc = stages[(wt & 0xffff) + min(lane, max(ncount - 1, 0))];
       }
 #ifdef CUM_HOP_PROBE
       if (tid == 0 && blockIdx.x == 0) hop_probe_on = (pc == CUM_HOP_PROBE_PC && hop == n_hops - 1);   // (thread 0 reads it)

@@ -72,31 +72,33 @@ class _Blob:
         return off
 
 
-def _split(ntg, kcn, M, nacc, cap, kpr):
-    """(mt, ks) for one matrix product of the hop: 16-row tiles per work item and k slices, by pricing the stage lists the
-    candidates compile to (``_stages``) with constants fitted to the per-op stamps of tools/hop_phase_probe.py (shader
-    cycles): an op costs ~3 k whatever it does; a wave has ONE stage in flight, so a stage takes the longer of the L2
-    latency of its fragments (~1.3 k) and its MFMAs (32 cycles each; two waves share a SIMD's matrix pipe once more than
-    four waves have work); closing an item ~0.4 k; a split product pays a barrier and the combine pass.  The product's
-    time is its busiest wave's."""
+def _split(ntg, kcn, M, nacc, cap):
+    """(mt, ks) for one matrix product of the hop: 16-row tiles per work item and k slices, by a small cost model of
+    csrc/hop.hip::hop_gemm (cycles): a wave walks ceil(items / 8) items; an item is kcs chunks x mt x nacc x 4 MFMAs of
+    32 cycles, two waves share a SIMD's matrix pipe; every stage of 4 chunks and every item cost bookkeeping; smaller
+    mt re-reads the weights from L2 once per row group; a split product pays a barrier and the combine pass."""
     best = None
     mt_max = 1 if M <= 16 else 2 if M <= 32 else 4
     for mt in (1, 2, 4):
         if mt > mt_max:
             continue
-        base = ntg * ((M + 16 * mt - 1) // (16 * mt))
+        mgs = (M + 16 * mt - 1) // (16 * mt)
+        base = ntg * mgs
         for ks in range(1, min(kcn, 8) + 1):
             if ks > 1 and ks * base * nacc * mt * 256 > cap:
                 break
             kcs = (kcn + ks - 1) // ks
             if ks > 1 and (ks - 1) * kcs >= kcn:
                 continue                                  # an empty last slice
-            waves = _stages([_OP_GEMM, 0, 0, 0, ntg, kcn, 0, kpr, 0, M, cap, 0, -1, -1, -1, 0, 0, 0, 0, nacc, ks, kcs, mt])
-            per_simd = 2 if sum(1 for lst in waves if lst) > 4 else 1
-            cost = 3000 + max(sum(max(1300, per_simd * (t[2] & 7) * mt * nacc * 128 + 200) + 400 * (t[2] >> 4 & 1)
-                                  for t in lst) for lst in waves)
+            items = base * ks
+            ipw = (items + _WAVES - 1) // _WAVES
+            busy = min(_WAVES, (items + ipw - 1) // ipw)            # waves that have work
+            per_simd = 2 if busy > 4 else 1
+            stages = (kcs + 3) // 4
+            cost = ipw * (per_simd * kcs * mt * nacc * 4 * 32 + stages * 150 + 250) + 1500     # + first-load latency
+            cost += mgs * ks * ntg * nacc * kcn * 1024 / ks / 64 / 4                          # weight bytes over L2 -> CU
             if ks > 1:
-                cost += 1200 + base * mt * 64 / 512 * (60 + 15 * ks)
+                cost += 600 + base * mt * 64 / 512 * (40 + 12 * ks)
             if best is None or cost < best[0]:
                 best = (cost, mt, ks)
     return best[1], best[2]
@@ -321,7 +323,7 @@ class HopPlan:
 
         def gemm(w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias=-1, bias2=-1, add=-1, pitch=0, row_off=0,
                  act=_ACT_NONE, nlimit=_BIG, nacc=1):
-            mt, ks = _split(ntg, kcn, M, nacc, cap, kpr)
+            mt, ks = _split(ntg, kcn, M, nacc, cap)
             assert kcn <= 4 * kpr
             ops.append([_OP_GEMM, w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias, bias2, add, pitch, row_off,
                         act, nlimit, nacc, ks, (kcn + ks - 1) // ks, mt])

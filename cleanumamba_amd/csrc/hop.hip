@@ -350,6 +350,10 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
     HOP_STAMP(0);
 
     for (int pc = 0; pc < n_ops; ++pc) {
+#ifdef CUM_HOP_PROBE
+      if (tid == 0 && blockIdx.x == 0) hop_probe_on = (pc == CUM_HOP_PROBE_PC && hop == n_hops - 1);   // (thread 0 reads it)
+#endif
+      HOP_FINE(34);
       int f[kHopOpInts];
       {
         const hop_cint src = ops + pc * kHopOpInts;
@@ -366,9 +370,7 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
         ncount = wt >> 16;
         ndsc = stages[(wt & 0xffff) + min(lane, max(ncount - 1, 0))];
       }
-#ifdef CUM_HOP_PROBE
-      if (tid == 0 && blockIdx.x == 0) hop_probe_on = (pc == CUM_HOP_PROBE_PC && hop == n_hops - 1);   // (thread 0 reads it)
-#endif
+      HOP_FINE(35);
       switch (f[0]) {
         case kOpStd: {
           // running mean of the per-frame std (src/network/CleanUMamba.py:399-401), unbiased as torch.std
@@ -505,11 +507,25 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
               const float dt = dtv[d], x = xv[d];
               float *ss = sstate + d * N;
               float acc = 0.f;
-              for (int n = 0; n < N; ++n) {
-                const float a = __builtin_amdgcn_exp2f(dt * A[d * N + n] * kLog2e);
-                const float v = fmaf(a, ss[n], dt * Bv[n] * x);
-                ss[n] = v;
-                acc = fmaf(Cv[n], v, acc);
+              if ((N & 3) == 0) {                     // (rows of 16-byte quads: four loads in flight, not one float at a time)
+                for (int n = 0; n < N; n += 4) {
+                  const f4 a4 = hop_gld4(A + d * N + n), s4 = hop_ld4(ss + n);
+                  f4 v4;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    const float a = __builtin_amdgcn_exp2f(dt * a4[j] * kLog2e);
+                    v4[j] = fmaf(a, s4[j], dt * Bv[n + j] * x);
+                    acc = fmaf(Cv[n + j], v4[j], acc);
+                  }
+                  hop_st4(ss + n, v4);
+                }
+              } else {
+                for (int n = 0; n < N; ++n) {
+                  const float a = __builtin_amdgcn_exp2f(dt * A[d * N + n] * kLog2e);
+                  const float v = fmaf(a, ss[n], dt * Bv[n] * x);
+                  ss[n] = v;
+                  acc = fmaf(Cv[n], v, acc);
+                }
               }
               const float z = zv[d];
               val = (acc + (Dv ? Dv[d] : 0.f) * x) * (z * sigmoidf_(z));
@@ -528,31 +544,54 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
           const bool relu = f[12] != 0, last = f[13] != 0;
           float *dst = lds + f[14];
           const float inv_q = 1.f / (float)lq;
-          for (int idx = tid; idx < 2 * L * lq; idx += kHopThreads) {
-            const int r = hop_fdiv(idx, inv_q), c = (idx - r * lq) * 4;
-            f4 v = f4{0.f, 0.f, 0.f, 0.f};
-            if (c < cq) {
-              const int t = r >> 1, q = r & 1;
-              v = hop_ld4(Y + t * ldy + q * cq + c) + hop_gld4(b2 + c);
-              if (t > 0) {
-                v += hop_ld4(Y + (t - 1) * ldy + (q + 2) * cq + c);
-              } else {
-                v += hop_ld4(tail + q * cq + c);
-                hop_st4(tail + q * cq + c, hop_ld4(Y + (L - 1) * ldy + (q + 2) * cq + c));
+          const int total = 2 * L * lq;
+          // the global operands (skip rows, written two hops ago; bias) of up to four passes are requested before the
+          // first one is used: a pass per round trip to HBM otherwise
+          constexpr int kAhead = 4;
+          for (int i0 = tid; i0 < total; i0 += kAhead * kHopThreads) {
+            f4 sk[kAhead], bq[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+              const int idx = i0 + u * kHopThreads;
+              const int r = hop_fdiv(min(idx, total - 1), inv_q), c = (min(idx, total - 1) - r * lq) * 4;
+              sk[u] = f4{0.f, 0.f, 0.f, 0.f};
+              bq[u] = sk[u];
+              if (idx < total && c < cq) {
+                bq[u] = hop_gld4(b2 + c);
+                if (skip) sk[u] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(skip + r * skip_ld + c));
               }
-              if (relu) v = f4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-              if (skip) v += __builtin_nontemporal_load(reinterpret_cast<const f4 *>(skip + r * skip_ld + c));
             }
-            if (!last)
-              hop_st4(dst + r * po + c, v);
-            else if (c == 0)
-              o[r] = v[0] * stdv;
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+              const int idx = i0 + u * kHopThreads;
+              if (idx >= total) break;
+              const int r = hop_fdiv(idx, inv_q), c = (idx - r * lq) * 4;
+              f4 v = f4{0.f, 0.f, 0.f, 0.f};
+              if (c < cq) {
+                const int t = r >> 1, q = r & 1;
+                v = hop_ld4(Y + t * ldy + q * cq + c) + bq[u];
+                if (t > 0) {
+                  v += hop_ld4(Y + (t - 1) * ldy + (q + 2) * cq + c);
+                } else {
+                  v += hop_ld4(tail + q * cq + c);
+                  hop_st4(tail + q * cq + c, hop_ld4(Y + (L - 1) * ldy + (q + 2) * cq + c));
+                }
+                if (relu) v = f4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                v += sk[u];
+              }
+              if (!last)
+                hop_st4(dst + r * po + c, v);
+              else if (c == 0)
+                o[r] = v[0] * stdv;
+            }
           }
         } break;
         default:
           break;
       }
+      HOP_FINE(36);
       hop_barrier();
+      HOP_FINE(37);
       HOP_STAMP(pc + 1);
       dsc = ndsc;
       dcount = ncount;

@@ -50,9 +50,11 @@ for k, op in enumerate(plan.ops):
 print(f"hop total {tot}")
 fine = (ctypes.c_ulonglong * 161)()
 lib.cum_stream_hop_probe_read(fine, 161)
-ff = np.array(fine[120:151], dtype=np.int64)
-ff = ff[ff > 0]
-print("fine stamps inside the probed gemm op (wave 0): entry, first loads issued, then (loads issued, stage computed) ...:")
-print("  ", [int(v - ff[0]) for v in ff])
+ff = np.array(fine[120:161], dtype=np.int64)
+t0 = ff[34] if ff[34] > 0 else ff[ff > 0].min()
+print("fine stamps of the probed op (-DCUM_HOP_PROBE_PC, thread 0), cycles after the op's top: 34 top, 35 op decoded and the "
+      "next op's stage list requested, [product: 0 entry, 1 first stage's loads issued, 2.. (loads issued, stage computed) "
+      "..., 30 slices combined], 36 body done, 37 behind the barrier:")
+print("  ", {int(i): int(v - t0) for i, v in enumerate(ff) if v > 0})
 for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1]):
     print(f"  {k:24s} {v:9d}  {100.0 * v / tot:5.1f} %")

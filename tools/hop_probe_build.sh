@@ -7,7 +7,7 @@ for f in *.hip; do
   o=../../tools/_ab/obj/${f%.hip}.o
   flags=""
   case $f in scan_bwd*.hip) flags="-fno-slp-vectorize";; esac
-  if [ $f = hop.hip ]; then flags="-DCUM_HOP_PROBE"; o=../../tools/_ab/obj/hop_probe.o; fi
+  if [ $f = hop.hip ]; then flags="-DCUM_HOP_PROBE ${HOP_PROBE_PC:+-DCUM_HOP_PROBE_PC=$HOP_PROBE_PC}"; o=../../tools/_ab/obj/hop_probe.o; fi
   if [ ! -f $o ] || [ $f -nt $o ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-value $flags -c $f -o $o & fi
 done
 wait

@@ -46,8 +46,8 @@ enum {
   kOpEnd = 0,      // -
   kOpStd = 1,      // -, std_off
   kOpEnc0 = 2,     // n, ld_h, w1, b1, x (LDS), h (LDS), ph
-  kOpGemm = 3,     // HopG (18 ints), nacc, ks, kcs, mt (16-row tiles per item: 1, 2 or 4); its stages: wtab / stages
-  kOpRing = 4,     // n, ldo, ring, src (LDS), po, carry (LDS)
+  kOpGemm = 3,     // HopG (18 ints), nacc, ks, kcs, mt (16-row tiles per item: 1, 2 or 4), ring (state offset | -1); its stages: wtab / stages
+  kOpRing = 4,     // n, ldo, ring, src (LDS), po, carry (LDS)   (not emitted any more: merged into the product in front)
   kOpLn = 5,       // hs, res, out (LDS), w, b, eps bits, dm, dmp, has_res
   kOpConvStep = 6, // di, dip, W, conv_state, conv_w, conv_b, xz (LDS), x (LDS)
   kOpSsm = 7,      // di, dip, N, ssm_state, A, D, dt, x, Bv, Cv, z, y (LDS)
@@ -135,7 +135,15 @@ enum { kActNone = 0, kActRelu = 1, kActSoftplus = 2 };
 struct HopG {
   int w, x, scratch, ntg, kcn, xs, kpr, seg, M, scratch_floats;
   int dst, bias, bias2, add, pitch, row_off, act, nlimit;
+  // an encoder layer's output also goes to its ring in the stream state (rows (rbase + m) mod n3, 16 ntg floats each)
+  float *ringp;
+  int rbase, n3;
 };
+
+__device__ __forceinline__ int hop_wrap(int a, int n) {      // a mod n for 0 <= a < 3 n
+  a -= a >= n ? n : 0;
+  return a - (a >= n ? n : 0);
+}
 
 template <int NACC>
 __device__ __forceinline__ void hop_epi(const HopG &g, int n0, int m, f4 v0, f4 v1, f4 b0, f4 b1) {
@@ -151,11 +159,7 @@ __device__ __forceinline__ void hop_epi(const HopG &g, int n0, int m, f4 v0, f4 
   }
   if (g.add >= 0) v0 += hop_ld4(hop_lds + g.add + n0);
   hop_st4(hop_lds + g.dst + (m + g.row_off) * g.pitch + n0, v0);
-}
-
-__device__ __forceinline__ int hop_wrap(int a, int n) {      // a mod n for 0 <= a < 3 n
-  a -= a >= n ? n : 0;
-  return a - (a >= n ? n : 0);
+  if (g.ringp) __builtin_nontemporal_store(v0, reinterpret_cast<f4 *>(g.ringp + hop_wrap(g.rbase + m, g.n3) * (16 * g.ntg) + n0));
 }
 
 // floor(a / d) for small non-negative a (< 2^15) and d (<= 2^10) without the ~40-instruction integer division: inv = 1 / d
@@ -414,6 +418,22 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
           g.w = f[1], g.x = f[2], g.scratch = f[3], g.ntg = f[4], g.kcn = f[5], g.xs = f[6], g.kpr = f[7], g.seg = f[8];
           g.M = f[9], g.scratch_floats = f[10], g.dst = f[11], g.bias = f[12], g.bias2 = f[13], g.add = f[14];
           g.pitch = f[15], g.row_off = f[16], g.act = f[17], g.nlimit = f[18];
+          // f[23] >= 0: the product is an encoder layer's output (rows 2.. of the next layer's input): its n = M new rows
+          // also go to the layer's ring, and the two ring rows in front of them (written a hop ago) become rows 0, 1 --
+          // requested here, stored behind the product.  State traffic is non-temporal: 32 streams per XCD move more
+          // bytes per hop than their L2 holds, and what has to stay there is the weight blob every one of them re-reads.
+          g.ringp = nullptr, g.rbase = 0, g.n3 = 1;
+          f4 cv = f4{0.f, 0.f, 0.f, 0.f};
+          const int lq = 4 * g.ntg;
+          if (f[23] >= 0) {
+            g.ringp = st + f[23];
+            g.n3 = 3 * g.M;
+            g.rbase = g.n3 - 2 + phase * g.M;
+            if (tid < 2 * lq) {
+              const int q = tid >= lq, c = (tid - q * lq) * 4;
+              cv = hop_ld4(g.ringp + hop_wrap(g.rbase - 2 + q + g.n3, g.n3) * (4 * lq) + c);
+            }
+          }
           if (f[19] == 1) {
             if (f[22] == 1)
               hop_gemm<1, 1>(w, g, f[20], dsc, dcount, tid, lane);
@@ -428,6 +448,10 @@ __global__ __launch_bounds__(kHopThreads) void stream_hop_kernel(const HopPlan *
               hop_gemm<2, 2>(w, g, f[20], dsc, dcount, tid, lane);
             else
               hop_gemm<2, 4>(w, g, f[20], dsc, dcount, tid, lane);
+          }
+          if (f[23] >= 0 && tid < 2 * lq) {
+            const int q = tid >= lq, c = (tid - q * lq) * 4;
+            hop_st4(lds + g.dst + q * g.pitch + c, cv);
           }
         } break;
         case kOpRing: {

@@ -57,13 +57,19 @@ def test_every_shipped_checkpoint_gets_a_plan_inside_its_ranges(name):
     E = net.encoder_n_layers
     kinds = [op[0] for op in plan.ops]
     assert kinds.count(hopplan._OP_GEMM) == (2 * E - 1) + 2 + 4 * len(net.tsfm_Mamba_layers) + 2 * E
-    assert kinds.count(hopplan._OP_RING) == E and kinds.count(hopplan._OP_OVERLAP) == E
+    assert kinds.count(hopplan._OP_RING) == 0 and kinds.count(hopplan._OP_OVERLAP) == E
+    # every encoder layer's 1x1 + GLU product also appends its rows to the layer's ring
+    rings = [op[23] for op in plan.ops if op[0] == hopplan._OP_GEMM and op[23] >= 0]
+    assert rings == [e["ring"] for e in plan.encs]
+    for op in plan.ops:
+        if op[0] == hopplan._OP_GEMM and op[23] >= 0:
+            assert op[19] == 2 and op[16] == 2 and 16 * op[4] == plan.encs[rings.index(op[23])]["ld_out"]
     assert kinds.count(hopplan._OP_LN) == len(net.tsfm_Mamba_layers) + 1
     for op in plan.ops:
         if op[0] != hopplan._OP_GEMM:
             continue
         (_, w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias, bias2, add, pitch, row_off, act, nlimit, nacc, ks,
-         kcs, mt) = op
+         kcs, mt, ring) = op
         assert w % 4 == 0 and w + ntg * nacc * kcn * 256 <= nw           # a fragment chunk: 64 lanes x 4 floats = 1 KiB
         assert 0 <= x < ops_lds and x % 4 == 0 and xs % 4 == 0 and (xs == 0 or xs % 8 == 4 or xs % 8 == 0)
         assert kcn <= 4 * kpr and 0 <= dst < ops_lds and pitch % 4 == 0
@@ -115,7 +121,7 @@ def test_stage_lists_compute_every_product(name):
             assert not ints[wtab0 + 8 * k:wtab0 + 8 * k + 8].any()
             continue
         (_, w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias, bias2, add, pitch, row_off, act, nlimit, nacc, ks,
-         kcs, mt) = op
+         kcs, mt, _ring) = op
         # reference: out[a][n][m] = sum_k W_a[n][k] X[m][k] from the op's own description
         frag = blob[w:w + ntg * nacc * kcn * 256].reshape(ntg, nacc, kcn, 4, 16, 4)        # [tile][acc][kc][g][r][j]
         W = frag.transpose(1, 0, 4, 2, 3, 5).reshape(nacc, ntg * 16, kcn * 16)             # k = kc * 16 + 4 g + j

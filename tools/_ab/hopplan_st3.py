@@ -111,7 +111,7 @@ def _stages(op):
     meta = chunks | first stage of the item << 3 | last << 4;  out of a last stage = first output channel | first row
     << 16 (unsplit product: the epilogue runs in place) or the LDS offset of the slice's partial sums (k split)."""
     (_, w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias, bias2, add, pitch, row_off, act, nlimit, nacc, ks, kcs,
-     mt) = op[:23]
+     mt) = op
     mgs = (M + 16 * mt - 1) // (16 * mt)
     base = ntg * mgs
     items = base * ks
@@ -320,11 +320,11 @@ class HopPlan:
         ops = []
 
         def gemm(w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias=-1, bias2=-1, add=-1, pitch=0, row_off=0,
-                 act=_ACT_NONE, nlimit=_BIG, nacc=1, ring=-1):
+                 act=_ACT_NONE, nlimit=_BIG, nacc=1):
             mt, ks = _split(ntg, kcn, M, nacc, cap, kpr)
             assert kcn <= 4 * kpr
             ops.append([_OP_GEMM, w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias, bias2, add, pitch, row_off,
-                        act, nlimit, nacc, ks, (kcn + ks - 1) // ks, mt, ring])
+                        act, nlimit, nacc, ks, (kcn + ks - 1) // ks, mt])
 
         if hdr["normalize"]:
             ops.append([_OP_STD, 0, hdr["std_off"]])
@@ -336,9 +336,8 @@ class HopPlan:
                 gemm(e["w1"], R0, R2, e["nt1"], e["kc1"], 2 * pi, e["ld_in"] // 16, pi, e["n"], cap2, R1, bias=e["b1"],
                      pitch=ph, act=_ACT_RELU)
             gemm(e["w2"], R1, R2, e["ntg2"], e["kc2"], ph, e["kc2"], 0, e["n"], cap2, R0, bias=e["b2"],
-                 bias2=e["b2"] + e["ld_out"], pitch=po, row_off=2, nacc=2, ring=e["ring"])
-            # (ring: the n new rows also go to the layer's ring, the two rows in front of them become rows 0, 1 of R0 --
-            #  a separate op until the second half of round 5)
+                 bias2=e["b2"] + e["ld_out"], pitch=po, row_off=2, nacc=2)
+            ops.append([_OP_RING, e["n"], e["ld_out"], e["ring"], R0 + 2 * po, po, R0])
         x_enc = R0 + 2 * (hdr["ld_last"] + 4)
         gemm(hdr["t1_w"], x_enc, R2, hdr["t1_nt"], hdr["t1_kc"], 0, hdr["t1_kc"], 0, 1, cap2, v_hs, bias=hdr["t1_b"])
         for k, b in enumerate(blks):

@@ -51,7 +51,7 @@ print(f"hop total {tot}")
 fine = (ctypes.c_ulonglong * 161)()
 lib.cum_stream_hop_probe_read(fine, 161)
 ff = np.array(fine[120:161], dtype=np.int64)
-t0 = ff[34] if ff[34] > 0 else ff[ff > 0].min()
+t0 = ff[34] if ff[34] > 0 else (ff[ff > 0].min() if (ff > 0).any() else 0)
 print("fine stamps of the probed op (-DCUM_HOP_PROBE_PC, thread 0), cycles after the op's top: 34 top, 35 op decoded and the "
       "next op's stage list requested, [product: 0 entry, 1 first stage's loads issued, 2.. (loads issued, stage computed) "
       "..., 30 slices combined], 36 body done, 37 behind the barrier:")

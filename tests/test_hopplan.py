@@ -118,7 +118,7 @@ def test_stage_lists_compute_every_product(name):
     total = 0
     for k, op in enumerate(plan.ops):
         if op[0] != hopplan._OP_GEMM:
-            assert not ints[wtab0 + 8 * k:wtab0 + 8 * k + 8].any()
+            assert not ints[wtab0 + hopplan._WAVES * k:wtab0 + hopplan._WAVES * (k + 1)].any()
             continue
         (_, w, x, scratch, ntg, kcn, xs, kpr, seg, M, cap, dst, bias, bias2, add, pitch, row_off, act, nlimit, nacc, ks,
          kcs, mt, _ring) = op
@@ -137,7 +137,7 @@ def test_stage_lists_compute_every_product(name):
         got = np.full((nacc, ntg * 16, mgs * mt * 16), np.nan)
         part = {}
         for wave in range(hopplan._WAVES):
-            wt = int(ints[wtab0 + 8 * k + wave])
+            wt = int(ints[wtab0 + hopplan._WAVES * k + wave])
             start, count = wt & 0xffff, wt >> 16
             assert count <= hopplan._MAX_WAVE_STAGES and count == len(plan.stages[k][wave])
             total += count

@@ -429,7 +429,10 @@ int cum_stream_overlap_add(int32_t dtype, int32_t streams, int32_t L2, int32_t C
  * overlap-add :476-488, with the skip order fixed as SURVEY fact 9 describes) for `n_hops` consecutive hops of `streams`
  * concurrent streams; a workgroup owns one stream, activations stay in LDS, f32 throughout (exact-f32 matrix cores).
  *   plan     device int32[cum_stream_hop_plan_ints()]: sizes, LDS regions, offsets into `weights` and into a stream's
- *            state block, in the field order of csrc/hop.hip::HopPlan (built by cleanumamba_amd/network/hopplan.py)
+ *            state block, in the field order of csrc/hop.hip::HopPlan (built by cleanumamba_amd/network/hopplan.py):
+ *            a 16-int header, the op list (24 ints per op), per op and wave the position and length of the wave's stage
+ *            list, and the stage lists of the matrix products (4 ints per stage: blob offset, LDS operand offset, chunk
+ *            count | first | last flags, destination) -- the kernel walks what the host compiled, it derives nothing
  *   weights  device f32 blob: every matrix zero-padded and in MFMA fragment order ([tile][16-deep k chunk][lane][4]),
  *            biases / LayerNorm parameters / -exp(A_log) / D padded to the pitches the plan names
  *   state    device f32 [streams][state_stride]: encoder rings, decoder tails, conv / SSM states, running std, ring phase

@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 13
+#define CUM_ABI_VERSION 14
 
 int cum_abi_version(void);
 const char *cum_last_error(void);

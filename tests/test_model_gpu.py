@@ -402,6 +402,37 @@ def test_one_launch_hop_stream_counts_and_weight_changes(cuda):
     assert rel_l2(outs[True][:, 10 * hop:], outs[True][:, :10 * hop].new_zeros(1)) > 0          # (not trivially zero)
 
 
+@pytest.mark.parametrize("name", ["442k", "pruned500k", "e6_pruned2m"])
+def test_one_launch_hop_is_bit_reproducible_under_any_chunking(cuda, name):
+    """The one-launch hop walks a call's hops inside the kernel: how the audio is cut into calls must not change a bit of
+    the output, and neither may a second run (the ops of a hop are ordered by workgroup barriers that wait for LDS only --
+    a missing ordering of the global stream state would show up here as run-to-run or schedule-to-schedule noise).
+    300 streams: more workgroups than CUs."""
+    net = _net(name, cuda, pruned=name != "442k")
+    hop, S = net.total_stride, 300
+    L = net.frame_length + 47 * hop
+    x = (0.1 * torch.randn(S, L, generator=torch.Generator().manual_seed(5))).to(cuda)
+    x[::7] *= 5.0
+    first = net.frame_length
+    schedules = {"one call": [L - first], "hop by hop": [hop] * 47, "ragged": [3 * hop + 1, hop - 1, 16 * hop, 5, 11 * hop, 16 * hop - 5]}
+    outs = {}
+    with torch.no_grad():
+        for tag, sizes in list(schedules.items()) + [("one call again", schedules["one call"])]:
+            assert sum(sizes) == L - first
+            net.reset_stream()
+            chunks, i = [net.feed_batch(x[:, :first])], first
+            for n in sizes:
+                chunks.append(net.feed_batch(x[:, i:i + n]))
+                i += n
+            assert net.hop_kernel_status == "active"
+            chunks.append(net.flush_batch())
+            outs[tag] = torch.cat(chunks, 1)
+    ref = outs["one call"]
+    assert ref.shape == (S, L) and float(ref.abs().max()) > 0
+    for tag, out in outs.items():
+        assert torch.equal(out, ref), tag
+
+
 def test_stream_after_flush_starts_a_fresh_running_std(cuda):
     """normalize_input=True: the running mean of the per-frame std (src/network/CleanUMamba.py:399-401) belongs to a
     stream.  A second clip fed after flush() must come out exactly as from a freshly constructed model."""

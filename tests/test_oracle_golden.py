@@ -59,11 +59,13 @@ def test_full_model_restatement_vs_reference_class(name):
     with torch.no_grad():
         y_raw, skips, inter = R.forward_ref(sd, x, normalize_input=False, return_intermediates=True)
         y_norm = R.forward_ref(sd, x, normalize_input=True)
-    assert rel_l2(y_raw, g["out_raw"]) < 1e-6
-    assert rel_l2(y_norm, g["out_norm"]) < 1e-6
+    # (f32 on the host: the summation order of torch's CPU convolutions varies with the core count -- 1.1e-6 measured on
+    #  the 32-core host of a GPU box against goldens made on 8 cores; the f64 comparison is the looser, order-free one)
+    assert rel_l2(y_raw, g["out_raw"]) < 4e-6
+    assert rel_l2(y_norm, g["out_norm"]) < 4e-6
     assert rel_l2(y_norm, g["out64_norm"]) < 1e-5
-    assert rel_l2(inter["tsfm_out"], g["tsfm_out_raw"]) < 1e-6
-    assert rel_l2(skips[0], g["tsfm_in_raw"]) < 1e-6
+    assert rel_l2(inter["tsfm_out"], g["tsfm_out_raw"]) < 4e-6
+    assert rel_l2(skips[0], g["tsfm_in_raw"]) < 4e-6
     assert R.valid_length(16000, 8) == int(g["valid_length"]) == 16126
 
 
@@ -74,7 +76,7 @@ def test_synth_e6_restatement_vs_reference_class():
     _, noisy = synth.waveform(2, meta["L"], seed=meta["wave_seed"])
     with torch.no_grad():
         y = R.forward_ref(sd, noisy)
-    assert rel_l2(y, g["out"]) < 1e-5      # 768-channel fp32 convs: summation order varies with threading
+    assert rel_l2(y, g["out"]) < 4e-5      # 768-channel fp32 convs: summation order varies with threading (1.3e-5 on 32 cores)
 
 
 def test_loss_restatement_vs_reference_loss_fn():
@@ -84,5 +86,7 @@ def test_loss_restatement_vs_reference_loss_fn():
     loss = R.loss_ref(den, T(g["clean"]), ell_p=cfg["ell_p"], ell_p_lambda=cfg["ell_p_lambda"],
                       stft_lambda=cfg["stft_lambda"], stft_config=cfg["stft_config"])
     loss.backward()
-    assert abs(loss.item() - float(g["loss"])) < 1e-6 * abs(float(g["loss"])) + 1e-7
-    assert rel_l2(den.grad, g["grad"]) < 1e-5
+    assert abs(loss.item() - float(g["loss"])) < 4e-6 * abs(float(g["loss"])) + 1e-7      # (f32 sums on the host, as above)
+    # (the log-magnitude terms divide by |X|: the f32 FFT of the host's torch build shows -- 7.9e-5 on the 32-core host of a
+    #  GPU box, 2e-6 where the golden was made; the GPU kernels are pinned against an f64 loss in test_stft_loss_gpu.py)
+    assert rel_l2(den.grad, g["grad"]) < 3e-4

@@ -447,6 +447,9 @@ class CleanUMamba(nn.Module):
         target = self.valid_length(consumed + pending_length)
         pad = torch.zeros(S, target - consumed - pending_length, device=dev, dtype=self.pending.dtype)
         head = self.feed_batch(pad)      # the frames forward() has: they count as timed frames like any other
+        if S == 0:
+            self.reset_stream()
+            return head.new_zeros(0, pending_length)
         out = torch.cat([head, self._drain().to(head.dtype)], 1)[:, :pending_length]
         self.reset_stream()              # the next clip starts a fresh stream: its running std starts over too
         return out
@@ -542,6 +545,13 @@ class CleanUMamba(nn.Module):
         denoised_frames = []
         self.__dict__["_wv_call"] = None            # weights cannot change inside one call: checked on its first hop only
         while self.pending.shape[1] >= self.frame_length:
+            if S == 0:                                  # no stream: only the bookkeeping of the hops that would have run
+                n_hops = (self.pending.shape[1] - self.frame_length) // total_stride + 1
+                self.frames += n_hops
+                self._std_frames = getattr(self, "_std_frames", 0) + n_hops
+                denoised_frames.append(self.pending.new_zeros(0, n_hops * total_stride))
+                self.pending = self.pending[:, n_hops * total_stride:]
+                break
             hs = self._hop_kernel_state()
             if hs is not None:
                 # every remaining hop of this call in ONE launch (csrc/hop.hip): a workgroup per stream walks them

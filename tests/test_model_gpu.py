@@ -433,6 +433,32 @@ def test_one_launch_hop_is_bit_reproducible_under_any_chunking(cuda, name):
         assert torch.equal(out, ref), tag
 
 
+def test_streaming_with_no_stream_and_with_crumbs(cuda):
+    """Edge cases of feed_batch / flush_batch: zero concurrent streams (every call returns (0, m) with the m a stream would
+    get), and chunks shorter than a frame / a hop (nothing comes out until a hop is complete; the total is the input's
+    length), on the one-launch hop."""
+    net = _net("pruned500k", cuda, pruned=True)
+    hop, F = net.total_stride, net.frame_length
+    L = F + 3 * hop + 7
+    cuts = [10, F, F + 5, L]
+    shapes = {}
+    with torch.no_grad():
+        for S in (0, 2):
+            x = (0.1 * torch.randn(S, L, generator=torch.Generator().manual_seed(1))).to(cuda)
+            net.reset_stream()
+            outs, i = [], 0
+            for c in cuts:
+                outs.append(net.feed_batch(x[:, i:c]))
+                i = c
+            outs.append(net.flush_batch())
+            shapes[S] = [tuple(o.shape) for o in outs]
+            assert torch.cat(outs, 1).shape == (S, L)
+            if S:
+                par = net(x.unsqueeze(1))[:, 0, :L]
+                assert par.shape == (S, L)
+    assert [m for _, m in shapes[0]] == [m for _, m in shapes[2]] == [0, hop, 0, 3 * hop, L - 4 * hop]
+
+
 def test_stream_after_flush_starts_a_fresh_running_std(cuda):
     """normalize_input=True: the running mean of the per-frame std (src/network/CleanUMamba.py:399-401) belongs to a
     stream.  A second clip fed after flush() must come out exactly as from a freshly constructed model."""

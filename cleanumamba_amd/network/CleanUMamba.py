@@ -216,6 +216,8 @@ class CleanUMamba(nn.Module):
             noisy_audio = noisy_audio.unsqueeze(1)
         B, C, L = noisy_audio.shape
         assert C == 1
+        if B == 0 and not return_skip_connections:          # an empty batch: the torch modules return an empty result too
+            return noisy_audio.new_zeros(0, self.channels_output, L)
         fused = getattr(self, "use_fused_convs", True) and noisy_audio.is_cuda
         if fused and not cs.supported(self):
             raise NotImplementedError("fused conv stack covers kernel 4 / stride 2 / ungrouped / sigmoid-GLU "

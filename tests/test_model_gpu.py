@@ -433,6 +433,21 @@ def test_one_launch_hop_is_bit_reproducible_under_any_chunking(cuda, name):
         assert torch.equal(out, ref), tag
 
 
+def test_forward_of_an_empty_batch_and_of_a_one_sample_clip(cuda):
+    """An empty batch comes back empty (as from the reference's torch modules); a clip of ONE sample with
+    normalize_input is NaN exactly as in the reference (`std` of one sample, src/network/CleanUMamba.py:260-262),
+    without normalisation it is finite -- and, as in the reference (:318-319 crops only under normalize_input), as long as
+    the padded signal."""
+    net = _net("pruned500k", cuda, pruned=True)
+    with torch.no_grad():
+        assert net(torch.zeros(0, 1, 16000, device=cuda)).shape == (0, 1, 16000)
+        one = torch.full((2, 1, 1), 0.3, device=cuda)
+        assert net.normalize_input and torch.isnan(net(one)).all()
+        net.normalize_input = False
+        y = net(one)
+        assert y.shape == (2, 1, net.valid_length(1)) and torch.isfinite(y).all()
+
+
 def test_streaming_with_no_stream_and_with_crumbs(cuda):
     """Edge cases of feed_batch / flush_batch: zero concurrent streams (every call returns (0, m) with the m a stream would
     get), and chunks shorter than a frame / a hop (nothing comes out until a hop is complete; the total is the input's

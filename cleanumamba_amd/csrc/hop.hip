@@ -17,10 +17,11 @@
 //   * conv_state / ssm_state of every Mamba block, the running input std, its frame count, the ring phase.
 //
 // The kernel is an INTERPRETER of a short op list the host compiles from the model (cleanumamba_amd/network/hopplan.py:
-// ~75 ops for an E8 model with 3 blocks; read by scalar loads: every op names its LDS places and its
+// 65 ops for an E8 model with 3 blocks; read by scalar loads): every op names its LDS places and its
 // offsets into the weight blob / the state block, ends with a workgroup barrier, and is one of: input std, first
-// encoder conv (1 input channel: VALU), matrix product (below), ring append + carry, add + LayerNorm, Mamba conv step,
-// Mamba state update, decoder overlap-add.  Why a table and not straight-line code: the first version inlined a
+// encoder conv (1 input channel: VALU), matrix product (below; an encoder layer's output product also appends its rows
+// to the layer's ring and fetches the two carry rows), add + LayerNorm, Mamba conv step, Mamba state update, decoder
+// overlap-add.  The products themselves are compiled further, into per-wave STAGE LISTS (see hop_gemm).  Why a table and not straight-line code: the first version inlined a
 // specialised matrix product per layer (115 KB of code walked once per hop: instruction-fetch bound, 370 us per hop);
 // the second called one shared body per layer (arguments through scratch memory, generic pointers -> flat loads and
 // vmcnt(0) in front of every MFMA: 10 k cycles of fixed cost per product).  Here each product body exists once, its
@@ -28,7 +29,7 @@
 //
 // Matrix products run on v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fma chain) with the WEIGHTS as the A operand,
 // packed by the host in fragment order ([tile][16-deep k chunk][lane][4]: one coalesced 1 KiB load per wave and chunk;
-// a wave issues the loads of up to 8 chunks at once), and the activations as the B operand straight out of LDS
+// a wave has the loads of two stages of up to 4 chunks in flight), and the activations as the B operand straight out of LDS
 // (ds_read_b128); a lane then holds 4 consecutive output channels of one row, so GLU pairs (the two 16-row tiles of a
 // pair share their B fragments) and bias / ReLU / sigmoid epilogues are lane-local.  All k extents are multiples of 16
 // and the packed weights are zero-padded, so padding columns come out as exact zeros and need no guards.

@@ -1,3 +1,4 @@
+# Instruction / scalar-data cache and wave counters of the one-launch streaming hop (GPU box): rocprofv3 --pmc passes over tools/bench_streaming.py
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
 i=0
 for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CU_CYCLES SQ_LEVEL_WAVES"; do

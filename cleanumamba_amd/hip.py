@@ -214,6 +214,7 @@ _FFT_PLAN_LIMIT = 32          # distinct (device, kind, n, batch) plans kept; ea
 class _FftPlan:
     def __init__(self, kind, n, batch, device):
         self.handle, wb = ctypes.c_void_p(), c_i64()
+        self.captured = False           # set once a hipGraph capture has recorded an exec of this plan: never evicted
         with torch.cuda.device(device):
             check(lib().cum_fft_plan_create(kind, n, batch, ctypes.byref(self.handle), ctypes.byref(wb)))
             self.work = torch.empty(max(int(wb.value), 16), dtype=torch.uint8, device=device) if wb.value > 0 else None
@@ -239,8 +240,16 @@ def fft(kind, n, batch, src, dst, inverse=False):
             # the warm-up steps
             raise RuntimeError("cleanumamba_amd.hip.fft: first use of an FFT plan inside hipGraph capture; run one "
                                "un-captured step first")
-        if len(_fft_plans) >= _FFT_PLAN_LIMIT:      # bounded: drop the oldest plan (and its work area)
-            _fft_plans.pop(next(iter(_fft_plans)))
+        if len(_fft_plans) >= _FFT_PLAN_LIMIT:
+            # bounded: drop the oldest plan (and its work area) that no captured hipGraph has recorded -- a graph holds the
+            # plan's handle and work address, destroying either under it makes the next replay a use-after-free
+            victim = next((k for k, pl in _fft_plans.items() if not pl.captured), None)
+            if victim is None:
+                raise RuntimeError(f"cleanumamba_amd.hip.fft: {_FFT_PLAN_LIMIT} FFT plans are all held by captured "
+                                   "hipGraphs; none can be dropped for a new (n, batch)")
+            _fft_plans.pop(victim)
         plan = _fft_plans[key] = _FftPlan(kind, int(n), int(batch), dev)
+    if torch.cuda.is_current_stream_capturing():
+        plan.captured = True            # pinned for the life of the process (the graph that recorded it may be replayed)
     with torch.cuda.device(dev):
         check(lib().cum_fft_exec(plan.handle, ptr(src), ptr(dst), int(bool(inverse)), ptr(plan.work), stream_ptr()))

@@ -151,6 +151,11 @@ class CleanUMamba(nn.Module):
         state.pop("_hop_graph", None)       # captured hipGraph of the streaming hop
         state.pop("_hop_plan", None)        # packed weights / plan of the one-launch hop
         state.pop("_hop_kernel_why", None)
+        if state.pop("_hop_state", None) is not None:
+            # a live stream of the one-launch hop keeps its state in the plan's device blocks, which are not pickled: the
+            # copy starts a fresh stream (what is left in the per-layer fields is the first frame's state, stale by now)
+            state["pending"] = state["pending"][:, :0].clone()
+            state.update(inference_params=None, encoder_decoder_state={}, input_std=0, _std_frames=0)
         return state
 
     # ------------------------------------------------------------------ geometry
@@ -386,6 +391,11 @@ class CleanUMamba(nn.Module):
         self.__dict__.pop("_hop_plan", None)
         self.__dict__.pop("_hop_kernel_why", None)      # (shapes may have changed: ask again)
         self.__dict__.pop("_plist", None)
+        self.__dict__.pop("_wv_call", None)
+        hs = self.__dict__.get("_hop_state")
+        if hs is not None:                              # a live stream of the one-launch hop holds its own weight blob:
+            hs["plan_weights"] = None                   # re-pack it on the next call (``param.data`` writes are invisible
+                                                        # to _weights_version)
 
     # ----------------------------------------------------------------- streaming
     def reset_time_per_frame(self):
@@ -597,7 +607,12 @@ class CleanUMamba(nn.Module):
             if wv is None:
                 wv = self.__dict__["_wv_call"] = self._weights_version()
             if hs["plan_weights"] != wv:                    # weights changed under a live stream: re-pack them
-                hs["plan"], hs["plan_weights"] = hopplan.HopPlan(self), wv
+                try:
+                    hs["plan"], hs["plan_weights"] = hopplan.HopPlan(self), wv
+                except ValueError as exc:                   # (same guard as at creation; here the stream state already
+                    # lives in the old plan's layout, which the per-layer hop cannot take over mid-stream)
+                    raise RuntimeError("the weights changed under a live stream into a model the one-launch hop cannot "
+                                       f"run ({exc}); flush() / reset_stream() before changing them") from exc
             return hs
         if not getattr(self, "use_hop_kernel", True) or getattr(self, "stream_bf16", False) \
                 or not getattr(self, "stream_incremental", True):

@@ -28,6 +28,7 @@ _WAVES = 8           # waves of the kernel's workgroup (csrc/hop.hip::kHopWaves)
 # every stream re-reads all weights from L2 once per hop: above this the per-layer path (streams batched as GEMM rows)
 # is the right design
 MAX_PARAMS = 3_000_000
+_MAX_LD_OUT = 1024            # widest encoder-layer output row the kernel's one-pass carry copy covers (512 threads x float4 x 2 rows)
 
 
 def _rup(x, m):
@@ -149,6 +150,10 @@ def unsupported_reason(model):
         return "more than one input / output channel"
     if sum(p.numel() for p in model.parameters()) > MAX_PARAMS:
         return "weights too large to be re-read per stream"
+    # csrc/hop.hip moves an encoder layer's two carry rows with ONE pass of the 512-thread workgroup, a float4 per thread
+    # (`tid < 2 * lq`, lq = ld_out / 4): rows wider than 1 024 floats would be copied in part
+    if any(_rup(model.encoder[i][2].weight.shape[0] // 2, 16) > _MAX_LD_OUT for i in range(E)):
+        return "an encoder layer wider than 1 024 channels"
     if any(p.dtype != torch.float32 for p in model.parameters()):
         return "parameters are not f32"
     for blk in model.tsfm_Mamba_layers:

@@ -141,7 +141,10 @@ def mrstft_loss_ref(x, y, fft_sizes=(512, 1024, 2048), hop_sizes=(50, 120, 240),
                     win_lengths=(240, 600, 1200), sc_lambda=0.5, mag_lambda=0.5, band="full"):
     sc, mag = 0.0, 0.0
     for fs, hs, wl in zip(fft_sizes, hop_sizes, win_lengths):
-        w = torch.hann_window(wl, dtype=x.dtype, device=x.device)
+        # the reference's window is an f32 buffer (src/util/stft_loss.py:100 register_buffer of torch.hann_window): in
+        # f64 (module.double()) it holds the f32 values, not an f64 hann -- mirrored, so that an f64 run of this
+        # restatement meets an f64 run of the reference to 1e-12 instead of 1e-9 / 3e-5 (value / gradient)
+        w = torch.hann_window(wl, dtype=torch.float32, device=x.device).to(x.dtype)
         xm, ym = stft_mag(x, fs, hs, wl, w), stft_mag(y, fs, hs, wl, w)
         if band == "high":
             k = xm.shape[1] // 2

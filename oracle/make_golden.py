@@ -18,6 +18,9 @@ What is pinned by what:
            (src/util/util.py:313-322).
   ckpt_* / e2e_* of the other seven pruned checkpoints (`python -m oracle.make_golden pruned`): same recipe as
            pruned500k -- every loadable checkpoint the reference ships (src/examples/loading_pretrained_models.py:7-19).
+  loss64 : the same loss through the reference's modules in f64 (`python -m oracle.make_golden loss64`).
+  e2e_*_autocast : the reference class under torch.autocast("cpu", bf16) on the e2e_*_synth weights / input, and its own
+           distance to its f32 output (`python -m oracle.make_golden autocast`).
   lr_schedule : values returned by the reference's LinearWarmupCosineDecay.step() (src/util/util.py:115-161), fresh
            and resumed runs, past the wrap-around (`python -m oracle.make_golden lr`).
 """
@@ -186,6 +189,27 @@ def e2e_synth(ref, name, cfg, L, seed):
     print(name, "done", float(y.abs().mean()))
 
 
+def e2e_synth_autocast(ref, name, cfg, L, seed):
+    """The REFERENCE class under the reference's own training arithmetic -- torch.autocast (src/training/train.py:278-280;
+    device "cpu" here, bf16 the 16-bit type the CPU backend autocasts to) -- on the weights and input of e2e_<name>: its
+    output and its rel-L2 distance to its own f32 output.  tests/test_train_gpu.py holds the product's 16-bit error to a
+    multiple of THIS number instead of to a constant measured on the product."""
+    torch.manual_seed(0)
+    net = ref.CleanUMamba(**cfg).float().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synth.fill_state_dict(shapes, seed=seed), strict=True)
+    _, noisy = synth.waveform(2, L, seed=77)
+    with torch.no_grad():
+        y32 = net(noisy.clone())
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y16 = net(noisy.clone())
+    y16 = y16.float()
+    err = ((y16.double() - y32.double()).norm() / y32.double().norm()).item()
+    np.savez_compressed(os.path.join(OUT, f"e2e_{name}_autocast.npz"), out_bf16=npf(y16), ref_err_bf16=np.float64(err),
+                        out_dtype=np.frombuffer(str(y16.dtype).encode(), dtype=np.uint8))
+    print(name, "autocast(cpu, bf16): rel-L2 to the reference's own f32 output", err)
+
+
 def make_loss(ref):
     import importlib
     util = importlib.import_module("src.util.util")
@@ -202,6 +226,27 @@ def make_loss(ref):
                         grad=npf(den.grad), reconstruct=npf(dic["reconstruct"]), stft_sc=npf(dic["stft_sc"]),
                         stft_mag=npf(dic["stft_mag"]),
                         cfg=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8))
+
+
+def make_loss64(ref):
+    """The reference's loss_fn + MultiResolutionSTFTLoss evaluated in f64 (module .double(): its hann windows too) on the
+    inputs of loss.npz: value and gradient free of the host's f32 FFT / summation-order noise, so that the restatement can
+    be held to 1e-9 on ANY host (tests/test_oracle_golden.py; the f32 comparison against loss.npz stays, loose)."""
+    import importlib
+    util = importlib.import_module("src.util.util")
+    stft = importlib.import_module("src.util.stft_loss")
+    cfg = json.load(open(os.path.join(REF, "configs/config.json")))["train_config"]["loss_config"]
+    g = torch.Generator().manual_seed(4000)
+    clean = 0.05 * torch.randn(2, 1, 16000, generator=g)
+    den = (clean + 0.02 * torch.randn(2, 1, 16000, generator=g))
+    clean, den = clean.double(), den.double().requires_grad_(True)
+    mr = stft.MultiResolutionSTFTLoss(**cfg["stft_config"]).double()
+    kw = {k: v for k, v in cfg.items() if k != "stft_config"}
+    loss, dic = util.loss_fn(lambda x: den, (clean, clean.clone()), mrstftloss=mr, **kw)
+    loss.backward()
+    assert loss.dtype == torch.float64 and den.grad.dtype == torch.float64
+    np.savez_compressed(os.path.join(OUT, "loss64.npz"), loss64=npf(loss), grad64=npf(den.grad))
+    print("loss64", float(loss))
 
 
 PRUNED = {  # fixture name -> shipped file (checkpoints/pruned/)
@@ -238,6 +283,13 @@ def main():
             e2e_from_ckpt(ref, name, os.path.join(REF, "checkpoints/pruned", fn), 16000, True)
     if what in ("lr", "all"):
         make_lr(ref)
+    if what in ("loss64", "all"):
+        make_loss64(ref)
+    if what in ("autocast", "all"):
+        e8 = json.load(open(os.path.join(REF, "configs/exp/models/DNS-CleanUMamba-3N-E8.json")))["network_config"]
+        e6 = json.load(open(os.path.join(REF, "configs/exp/models/DNS-CleanUMamba-3N-E6.json")))["network_config"]
+        e2e_synth_autocast(ref, "e8_synth", e8, 6000, seed=8)
+        e2e_synth_autocast(ref, "e6_synth", e6, 4000, seed=6)
     if what != "all":
         return
     for i, (b, d, n, l) in enumerate([(2, 8, 8, 33), (2, 48, 13, 257), (1, 128, 16, 61), (2, 64, 64, 96)]):

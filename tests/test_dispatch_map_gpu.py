@@ -9,6 +9,7 @@ cum_gemm_tn_tile), so the statement "verified on the 256 x 256 kernel" is the la
 Reference: the layers behind these GEMMs are src/network/CleanUMamba.py:108-113 (encoder), 121-130 (decoder), 139 / 194
 (1x1 around the bottleneck) and the four projections of upstream Mamba.forward (called at :288-290)."""
 import ctypes
+import os
 
 import pytest
 import torch
@@ -368,3 +369,61 @@ def test_e6_b32_f32_forward_against_the_oracle_on_two_clips(cuda):
     err = record("e6b32.f32_forward_vs_oracle", rel_l2(y[pick], ref))
     assert err < 1e-4
     assert rel_l2(y[31:32], ref[1:2]) < 1e-4
+
+
+def test_e8_b16_step_against_the_oracle_on_two_clips(cuda):
+    """BASELINE config 3 at its OWN batch and length, end to end against the CPU oracle (the call bench.py's
+    cpu_baseline times, used here as the checker): E8, 16 clips of 10 s, f32.  Forward of the whole batch on the HIP
+    path, clips 0 and 15 against oracle.cleanumamba_ref.forward_ref (north_star's 1e-4); the training loss (L1 +
+    multi-resolution STFT, the reference's configs/config.json terms) of those two clips against oracle loss_ref; then the
+    backward of that loss through the B = 16 network (the fourteen other clips carry a zero cotangent, every backward
+    kernel runs at its benched size) against the oracle's backward on the two clips: the last decoder layer's weight
+    gradient (behind no ReLU) to 1e-5, every parameter's gradient norm to 2 % (ReLU-gate flips between two f32
+    implementations, tests/test_model_gpu.py::test_full_width_model_forward_and_gradients).
+    Reference: src/network/CleanUMamba.py:252-324, src/util/util.py:215-327, src/training/train.py:278-285."""
+    from oracle import cleanumamba_ref as R
+    from oracle import synth
+    from cleanumamba_amd.network import CleanUMamba
+    from cleanumamba_amd.util.stft_loss import MultiResolutionSTFTLoss
+    from cleanumamba_amd.util.util import loss_fn
+    stft = {"sc_lambda": 0.5, "mag_lambda": 0.5, "band": "full", "hop_sizes": [50, 120, 240],
+            "win_lengths": [240, 600, 1200], "fft_sizes": [512, 1024, 2048]}
+    torch.manual_seed(0)
+    net = CleanUMamba(**E8)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(cuda).train()
+    clean, noisy = synth.waveform(B, CLIP, seed=1234)
+    pick = [0, B - 1]
+    y = net(noisy.to(cuda))
+    assert y.shape == (B, 1, CLIP)
+    mr = MultiResolutionSTFTLoss(**stft).to(cuda)
+    ysel = y[pick]
+    loss, _ = loss_fn(lambda x: ysel, (clean[pick].to(cuda), noisy[pick].to(cuda)), mrstftloss=mr)
+    loss.backward()
+    torch.cuda.synchronize()
+    # the oracle on the same two clips (CPU; about 15 s on the box's cores)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    yr = R.forward_ref(sdr, noisy[pick])
+    lr = R.loss_ref(yr, clean[pick], stft_config=stft)
+    lr.backward()
+    err = record("e8b16.f32_forward_vs_oracle", rel_l2(y[pick].detach(), yr.detach()))
+    assert err < 1e-4
+    assert rel_l2(y[B - 1:B].detach(), yr[1:2].detach()) < 1e-4
+    lerr = record("e8b16.loss_vs_oracle", abs(loss.item() - lr.item()) / abs(lr.item()))
+    assert lerr < 1e-4
+    named = dict(net.named_parameters())
+    last = f"decoder.{E8['encoder_n_layers'] - 1}.2.weight"
+    gerr = record("e8b16.last_layer_wgrad_vs_oracle", rel_l2(named[last].grad, sdr[last].grad))
+    assert gerr < 1e-5
+    worst = 0.0
+    for k, p in named.items():
+        gr = sdr[k].grad
+        assert p.grad is not None and gr is not None, k
+        a, b = p.grad.double().norm().item(), gr.double().norm().item()
+        worst = max(worst, abs(a - b) / max(b, 1e-30))
+        assert abs(a - b) < 2e-2 * b, (k, a, b)
+    record("e8b16.worst_gradnorm_dev_vs_oracle", worst)
+    tot_a = sum((p.grad.double() ** 2).sum().item() for p in named.values()) ** 0.5
+    tot_b = sum((sdr[k].grad.double() ** 2).sum().item() for k in named) ** 0.5
+    assert abs(tot_a - tot_b) < 2e-2 * tot_b

@@ -513,3 +513,61 @@ def test_c5_scale_batched_streaming_equals_forward(cuda):
     assert err < 1e-4
     worst = max(rel_l2(seq[s:s + 1], par[s:s + 1]) for s in range(0, S, 17))
     assert worst < 1e-4
+
+
+def test_c5_at_its_own_size_256_streams_of_30_s(cuda):
+    """BASELINE config 5 at its OWN size: 256 concurrent streams x 30 s @ 16 kHz (1 875 hops per stream) of the pruned-E8
+    492K checkpoint through feed_batch in 16-hop calls (117 call boundaries, the ring phase of every encoder layer wraps
+    hundreds of times, the f32 frame counter of the running std reaches 1 875) + flush_batch.
+    (a) normalisation off: three sampled streams equal the parallel forward on their whole 30 s signal to 1e-4
+        (src/network/CleanUMamba.py:568-582, the reference's one numeric property, at config 5's duration);
+    (b) the whole (256, 480 000) output is bit-identical when the same audio is cut into 61-hop calls instead;
+    (c) running std on (the shipped default): 16-hop and 61-hop cuts bit-identical and finite, and two streams equal the
+        per-layer hop (the round 1-4 path: other kernels, same arithmetic) to 1e-4 over all 1 875 hops."""
+    S, SECONDS = 256, 30
+    net = _net("pruned500k", cuda, pruned=True)
+    hop, F = net.total_stride, net.frame_length
+    L = SECONDS * 16000
+    x = 0.1 * torch.randn(S, L, device=cuda, generator=torch.Generator(device=cuda).manual_seed(2024))
+    x[7] *= 0.01                                      # a quiet and a loud stream among them
+    x[200] *= 5.0
+
+    def run(per_call):
+        net.reset_stream()
+        chunks = [net.feed_batch(x[:, :F])]
+        for i in range(F, L, per_call * hop):
+            chunks.append(net.feed_batch(x[:, i:i + per_call * hop]))
+        assert net.hop_kernel_status == "active", net.hop_kernel_status
+        chunks.append(net.flush_batch())
+        return torch.cat(chunks, 1)
+
+    with torch.no_grad():
+        net.normalize_input = False
+        a16 = run(16)
+        assert a16.shape == (S, L) and bool(torch.isfinite(a16).all())
+        pick = [0, 128, 255]
+        par = net(x[pick].unsqueeze(1))[:, 0, :L]
+        err = record("c5_full.3_streams_vs_forward", rel_l2(a16[pick], par))
+        assert err < 1e-4
+        for j, s in enumerate(pick):
+            assert rel_l2(a16[s:s + 1], par[j:j + 1]) < 1e-4
+        tail = slice(L - 4 * hop, L)                  # the last hops + the flush drain on their own
+        assert rel_l2(a16[pick][:, tail], par[:, tail]) < 1e-4
+        a61 = run(61)
+        assert torch.equal(a16, a61), "the cut of the audio into calls changed the bits"
+        del a61, par
+        net.normalize_input = True
+        n16 = run(16)
+        assert bool(torch.isfinite(n16).all())
+        n61 = run(61)
+        assert torch.equal(n16, n61)
+        del n61
+        ref = _net("pruned500k", cuda, pruned=True)
+        ref.use_hop_kernel = False
+        two = [7, 200]
+        chunks = [ref.feed_batch(x[two, i:i + 64 * hop]) for i in range(0, L, 64 * hop)]
+        chunks.append(ref.flush_batch())
+        per_layer = torch.cat(chunks, 1)
+        assert per_layer.shape == (2, L)
+        err = record("c5_full.running_std_one_launch_vs_per_layer", rel_l2(n16[two], per_layer))
+        assert err < 1e-4

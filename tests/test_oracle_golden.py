@@ -90,3 +90,30 @@ def test_loss_restatement_vs_reference_loss_fn():
     # (the log-magnitude terms divide by |X|: the f32 FFT of the host's torch build shows -- 7.9e-5 on the 32-core host of a
     #  GPU box, 2e-6 where the golden was made; the GPU kernels are pinned against an f64 loss in test_stft_loss_gpu.py)
     assert rel_l2(den.grad, g["grad"]) < 3e-4
+
+
+def test_loss_restatement_vs_reference_loss_fn_in_f64():
+    """The tight pin, free of the host's f32 FFT / summation-order noise: the restatement in f64 against the reference's
+    own loss_fn + MultiResolutionSTFTLoss run in f64 (oracle/make_golden.py::make_loss64) -- value and gradient."""
+    g, g64 = load_golden("loss"), load_golden("loss64")
+    cfg = golden_json(g["cfg"])
+    den = T(g["denoised"]).double().requires_grad_(True)
+    loss = R.loss_ref(den, T(g["clean"]).double(), ell_p=cfg["ell_p"], ell_p_lambda=cfg["ell_p_lambda"],
+                      stft_lambda=cfg["stft_lambda"], stft_config=cfg["stft_config"])
+    loss.backward()
+    assert abs(loss.item() - float(g64["loss64"])) < 1e-12 * abs(float(g64["loss64"]))
+    assert rel_l2(den.grad, g64["grad64"]) < 1e-10
+    # and the f64 gradient is what the f32 golden scatters around (6e-5: the golden's own f32 noise)
+    assert rel_l2(g["grad"], g64["grad64"]) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["442k", "pruned500k"])
+def test_full_model_restatement_in_f64_vs_reference_class(name):
+    """Order-free form of test_full_model_restatement_vs_reference_class: the restatement in f64 against the f64 recompute
+    stored beside the reference class's f32 output (the two f32 runs differ by the host's summation order only)."""
+    sd, _ = load_ckpt(name)
+    g = load_golden("e2e_" + name)
+    with torch.no_grad():
+        y64 = R.forward_ref({k: v.double() for k, v in sd.items()}, T(g["input"]).double(), normalize_input=True)
+    assert rel_l2(y64, g["out64_norm"]) < 1e-12
+    assert rel_l2(y64, g["out_norm"]) < 1e-5          # the reference class's own f32 output around it (f32 noise: 2e-6 / 8e-6)

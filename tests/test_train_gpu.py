@@ -53,7 +53,15 @@ def test_autocast_forward_vs_reference_output(cuda, name, dtype):
         with torch.autocast("cuda", dtype=dtype):
             y = net(noisy.to(cuda))
         assert y.dtype == torch.float32
-        assert record(f"autocast_fwd[{name}-{dtype}]", rel_l2(y, g["out"])) < AUTOCAST_TOL[(name, dtype)]
+        err = record(f"autocast_fwd[{name}-{dtype}]", rel_l2(y, g["out"]))
+        assert err < AUTOCAST_TOL[(name, dtype)]
+        if dtype == torch.bfloat16:
+            # ... and to the reference's OWN 16-bit error: the reference class under torch.autocast (bf16, the CPU backend's
+            # autocast type; oracle/make_golden.py::e2e_synth_autocast) sits 4.6 % (E8) / 12.2 % (E6) from its f32 output
+            # on these weights -- the product's bf16 distance to the same f32 output may not exceed 1.5 x that
+            ref_err = float(load_golden(name + "_autocast")["ref_err_bf16"])
+            record(f"autocast_fwd[{name}-{dtype}].reference_own", ref_err)
+            assert err <= 1.5 * ref_err, (err, ref_err)
         if dtype == torch.float16:             # torch.autocast("cuda") with no dtype IS fp16: the reference's call
             with torch.autocast("cuda"):
                 y2 = net(noisy.to(cuda))

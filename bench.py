@@ -501,11 +501,32 @@ def _free_port():
     return port
 
 
-def _cpus_of_rank(local_rank, local_world, sys_root="/sys", allowed=None):
+def _visible_devices(env=None):
+    """How the device masks re-number the GPUs: None = no mask (HIP order = bus order), a list of physical indices when ONE of
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES is set to plain integers, "unknown" otherwise (UUID
+    tokens, or a ROCr mask stacked under a HIP one)."""
+    env = os.environ if env is None else env
+    hipm = env.get("HIP_VISIBLE_DEVICES", env.get("CUDA_VISIBLE_DEVICES"))
+    rocr = env.get("ROCR_VISIBLE_DEVICES")
+    if hipm is None and rocr is None:
+        return None
+    if hipm is not None and rocr is not None:
+        return "unknown"
+    try:
+        return [int(t) for t in (hipm if hipm is not None else rocr).split(",") if t.strip() != ""]
+    except ValueError:
+        return "unknown"
+
+
+def _cpus_of_rank(local_rank, local_world, sys_root="/sys", allowed=None, visible=None, info=None):
     """CPU set for one rank of a node: the cores of the NUMA node its GPU hangs off (AMD display-class PCI devices in bus
-    order = HIP's device order), shared evenly with the other ranks of that node; an even contiguous split of the
-    allowed cores when sysfs does not tell.  Pure host logic (no GPU call): runs in the rank before anything else."""
+    order = HIP's device order, re-numbered through the visible-devices mask when one is set: `visible`, default
+    _visible_devices()), shared evenly with the other ranks of that node; an even contiguous split of the allowed cores when
+    sysfs does not tell or the mask cannot be mapped.  `info` (a dict) receives what was chosen (bdf, numa_node, how) for the
+    bench line.  Pure host logic (no GPU call): runs in the rank before anything else."""
     allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    visible = _visible_devices() if visible is None else visible
+    info = {} if info is None else info
 
     def cpulist(text):
         out = []
@@ -515,6 +536,8 @@ def _cpus_of_rank(local_rank, local_world, sys_root="/sys", allowed=None):
                 out += range(int(a), int(b or a) + 1)
         return out
     try:
+        if visible == "unknown":
+            raise ValueError("device mask cannot be mapped to bus order")
         gpus = []
         pci = os.path.join(sys_root, "bus", "pci", "devices")
         for bdf in sorted(os.listdir(pci)):
@@ -523,21 +546,26 @@ def _cpus_of_rank(local_rank, local_world, sys_root="/sys", allowed=None):
                 vendor = f.read().strip()
             with open(os.path.join(d, "class")) as f:
                 cls = f.read().strip()
-            if vendor == "0x1002" and cls.startswith(("0x0302", "0x0380", "0x0300", "0x1200")):
+            # function 0 only: the accelerator itself, not an audio / USB function of the same board
+            if vendor == "0x1002" and cls.startswith(("0x0302", "0x0380", "0x0300", "0x1200")) and bdf.endswith(".0"):
                 with open(os.path.join(d, "numa_node")) as f:
-                    gpus.append(int(f.read().strip()))
-        if len(gpus) >= local_world and gpus[local_rank] >= 0:
-            node = gpus[local_rank]
+                    gpus.append((int(f.read().strip()), bdf))
+        if visible:                                   # HIP device i = physical device visible[i]
+            gpus = [gpus[v] for v in visible]
+        if len(gpus) >= local_world and gpus[local_rank][0] >= 0:
+            node, bdf = gpus[local_rank]
             with open(os.path.join(sys_root, "devices", "system", "node", f"node{node}", "cpulist")) as f:
                 cores = [c for c in cpulist(f.read()) if c in set(allowed)]
-            peers = [r for r in range(local_world) if gpus[r] == node]
+            peers = [r for r in range(local_world) if gpus[r][0] == node]
             share = len(cores) // len(peers)
             if share >= 1:
                 i = peers.index(local_rank)
+                info.update(bdf=bdf, numa_node=node, how="sysfs" + (" through the device mask" if visible else ""))
                 return cores[i * share:(i + 1) * share]
     except (OSError, ValueError, IndexError):
         pass
     share = max(1, len(allowed) // max(local_world, 1))
+    info.update(bdf=None, numa_node=None, how="even split of the allowed cores")
     return allowed[local_rank * share:(local_rank + 1) * share] or allowed
 
 
@@ -603,12 +631,12 @@ def main():
         # before the launcher's deadline, and the launcher relays every rank's stderr when it gives up
         import faulthandler
         faulthandler.dump_traceback_later(max(30.0, 0.8 * args.rank_timeout), exit=False)
-    cpus = None
+    cpus, pin_info = None, {}
     if world > 1 and not args.no_pin:
         # every rank on the cores of its GPU's NUMA node, before any GPU call: the eager multi-rank step spends ~16 ms of
         # Python per 20 ms step, a rank that migrates between sockets is the scaling curve's jitter
         try:
-            cpus = _cpus_of_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            cpus = _cpus_of_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), info=pin_info)
             os.sched_setaffinity(0, cpus)
             torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))      # no more threads than cores
         except (OSError, ValueError):
@@ -751,7 +779,7 @@ def main():
                "host_ms_per_step_by_rank": [round(h, 3) for h in host_ms_ranks],
                "modes": modes or None, "collective_ranks_observed": rccl_ranks,
                "backend": (os.environ.get("CUM_DIST_BACKEND", "nccl") if exchanging else None),
-               "cpu_affinity_rank0": (f"{len(cpus)} cores: {cpus[0]}-{cpus[-1]}" if cpus else None),
+               "cpu_affinity_rank0": (dict(pin_info, cores=f"{len(cpus)}: {cpus[0]}-{cpus[-1]}") if cpus else None),
                "exchange": ("none" if world == 1 and not alone else
                             "three graphs: all-reduce (AVG) of the decoder + bottleneck gradients (106 MB) beside the captured "
                             "encoder backward, all-reduce of the encoder's (59 MB) after it, then the captured optimizer section"

@@ -196,6 +196,19 @@ def test_bench_pins_ranks_to_the_numa_node_of_their_gpu(tmp_path):
     got = [bench._cpus_of_rank(r, 4, str(sysr), allowed) for r in range(4)]
     assert got[0] == [0, 1, 2, 3, 4, 5, 6, 7] and got[1] == [16, 17, 18, 19, 20, 21, 22, 23]
     assert got[2] == [8, 9, 10, 11, 12, 13, 14, 15] and got[3] == [24, 25, 26, 27, 28, 29, 30, 31]
+    # a device mask re-numbers the GPUs: HIP device i is physical device visible[i]
+    info = {}
+    got = [bench._cpus_of_rank(r, 2, str(sysr), allowed, visible=[3, 0], info=info) for r in range(2)]
+    assert got[0] == list(range(8, 16)) + list(range(24, 32)) and got[1] == list(range(0, 8)) + list(range(16, 24))
+    assert info["numa_node"] == 0 and info["bdf"] == "0000:10:00.0" and "mask" in info["how"]
+    # a mask that cannot be mapped (UUIDs, or two stacked masks): the even split, and the line says so
+    got = [bench._cpus_of_rank(r, 4, str(sysr), allowed, visible="unknown", info=info) for r in range(4)]
+    assert got == [list(range(8 * r, 8 * r + 8)) for r in range(4)] and info["how"].startswith("even split")
+    assert bench._visible_devices({}) is None
+    assert bench._visible_devices({"HIP_VISIBLE_DEVICES": "2,3"}) == [2, 3]
+    assert bench._visible_devices({"ROCR_VISIBLE_DEVICES": "1"}) == [1]
+    assert bench._visible_devices({"HIP_VISIBLE_DEVICES": "GPU-abcdef"}) == "unknown"
+    assert bench._visible_devices({"HIP_VISIBLE_DEVICES": "0", "ROCR_VISIBLE_DEVICES": "1,2"}) == "unknown"
     # no sysfs: contiguous even split of what the process may use
     got = [bench._cpus_of_rank(r, 4, str(tmp_path / "nothing"), set(range(8))) for r in range(4)]
     assert got == [[0, 1], [2, 3], [4, 5], [6, 7]]

@@ -34,25 +34,106 @@ namespace cum {
 #define PROBE(i) do { } while (0)
 #endif
 
-constexpr int NA = 5;         // reverse steps per 8-step half that take their decay factors from LDS (80 KB at NW = 8)
-// BC = 0: B_t / C_t through scalar loads, generic strides; 1: scalar loads, unit stride, all NS states valid;
-// 2: the chunk's B / C tiles staged in LDS by the whole workgroup (one coalesced load per chunk, broadcast
-// ds_read_b128 per step): no SGPR pressure -- the scalar variants keep 256 B/C values per chunk in flight and spend
-// ~20 % of their VALU instructions moving spilled SGPRs through VGPR lanes.
-// FULL: dstate == NW * NS known at compile time (every wave owns NS valid states, slab rows are 8-byte aligned pairs).
+// ---- Lane <-> state-slot permutation (the "xor scatter").
+// The per-step sums over the 64 channels of a wave (dB_t[n], dC_t[n]: 16 values per lane) are a reduce-scatter over the
+// lanes.  With every lane holding state n in the SAME register, one exchange level costs two instructions per eliminated
+// register (v_permlane*_swap + v_add, or two bank-masked DPP adds): 32 cross-lane instructions + 5 hazard pads per step,
+// 30 % of the kernel's instruction stream (profiles/r04_scan_bwd_experiments.md).  Here lane l keeps state  k ^ h(l)  in
+// register slot k, with  h(l) = b0 ^ 2 b1 ^ 7 b2  (b_i = bit i of l).  Then the partner lane of a DPP exchange holds the
+// state this lane keeps in the NEIGHBOUR slot, and "my slot k + partner's slot k ^ m" is ONE v_add_f32_dpp that
+// eliminates one register:
+//   level 1: lanes l, l ^ 1 (quad_perm [1,0,3,2]), slots k, k ^ 1      8 -> 4 registers per array, 4 instructions
+//   level 2: lanes l, l ^ 2 (quad_perm [2,3,0,1]), slots k, k ^ 2      4 -> 2, 2 instructions
+//   level 3: lanes l, l ^ 7 (row_half_mirror),     slots k, k ^ 4      2 -> 1, 1 instruction  (h(l ^ 7) = h(l) ^ 4)
+//   level 4: lanes l, l ^ 8 (row_ror:8), bank-masked: lanes 0-7 of a row keep the dB sum, lanes 8-15 the dC sum
+// = 16 DPP adds per step (and no pad: the two odd hazard slots carry the step's two pair sums).  The sum over the four
+// 16-lane rows is deferred: the 8 per-step registers of a half are reduce-scattered over the rows with 4 + 2 swaps, so a
+// half ends with two registers in which EVERY lane holds one finished total:
+//   lane l:  array = bit 3 of l (0: dB, 1: dC),  state = h(l & 7),  step = 4 * (register) + 3 - (2 * (r & 1) + (r >> 1)), r = l >> 4
+// and leaves through two 64-lane stores per half instead of eight 16-lane ones.
+// What the permutation costs: B_t / C_t must reach a lane in ITS slot order.  Bit 2 of h swaps the two 16-byte halves of
+// the wave's 8-state slice (an address bit); bits 0, 1 permute inside a float4, so the half-chunk's B / C tiles are staged
+// in LDS in four variants v (position q of variant v holds state q ^ v), each row rotated by 16 v floats so that the
+// eight distinct float4 a wave reads per step fall on eight different bank groups.  Checkpoints, A and dA are permuted
+// by their addresses (4-byte accesses).  tools/xor_scatter_model.py is the numpy model of the lane algebra.
+__device__ __forceinline__ int lane_hmask(int lane) {
+  const int b2 = (lane >> 2) & 1;
+  return ((lane ^ b2) & 1) | ((((lane >> 1) ^ b2) & 1) << 1) | (b2 << 2);
+}
+
+// One reverse step's reduction.  b[k] = dx * (delta' u) of slot k (formed by the caller with scalar multiplies: eight
+// free-standing registers -- halves of packed results handed to an asm as read-write operands cost a register copy per
+// pair), xt[k] = x_t of slot k, read only: the dC products dy * x_t are formed INSIDE the block, each into a register the
+// dB chain has just finished with (b1, b3, b5, b7 after level 1, b2, b6 after level 2), so that the sixteen products
+// never exist together (eight registers less at the kernel's 256-register peak) and serve as the hazard cover of the
+// other chain (a VALU result needs two wait states before a DPP read).  On return X = row-level totals (level 4 above),
+// q0 = p1x + p1y, q1 = p2x + p2y (the step's two pair sums: two more hazard slots).
+__device__ __forceinline__ void xor_reduce16(float (&b)[8], const float (&xt)[8], float dy, float p1x, float p1y, float p2x,
+                                             float p2y, float &X, float &q0, float &q1) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %3, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %5, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %7, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32 %1, %19, %11\n\t"                                                     // c0 -> b1
+      "v_mul_f32 %3, %19, %12\n\t"                                                     // c1 -> b3
+      "v_mul_f32 %5, %19, %13\n\t"                                                     // c2 -> b5
+      "v_mul_f32 %7, %19, %14\n\t"                                                     // c3 -> b7
+      "v_add_f32_dpp %0, %2, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %6, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32 %2, %19, %15\n\t"                                                     // c4 -> b2
+      "v_mul_f32 %6, %19, %16\n\t"                                                     // c5 -> b6
+      "v_add_f32_dpp %1, %3, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"    // c0 += c1
+      "v_add_f32_dpp %5, %7, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"    // c2 += c3
+      "v_mul_f32 %3, %19, %17\n\t"                                                     // c6 -> b3
+      "v_mul_f32 %7, %19, %18\n\t"                                                     // c7 -> b7
+      "v_add_f32_dpp %2, %6, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"    // c4 += c5
+      "v_add_f32_dpp %1, %5, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"    // c01 += c23
+      "v_add_f32_dpp %3, %7, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"    // c6 += c7
+      "v_add_f32 %9, %20, %21\n\t"
+      "v_add_f32_dpp %0, %4, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"        // dB: level 3
+      "v_add_f32_dpp %2, %3, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"    // c45 += c67
+      "v_add_f32 %10, %22, %23\n\t"
+      "v_add_f32_dpp %8, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"              // level 4, dB lanes
+      "v_add_f32_dpp %1, %2, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"        // dC: level 3
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %8, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc"                   // level 4, dC lanes
+      : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "=&v"(X),
+        "=&v"(q0), "=&v"(q1)
+      : "v"(xt[0]), "v"(xt[1]), "v"(xt[2]), "v"(xt[3]), "v"(xt[4]), "v"(xt[5]), "v"(xt[6]), "v"(xt[7]), "v"(dy), "v"(p1x),
+        "v"(p1y), "v"(p2x), "v"(p2y));
+}
+
+// a + b after a half / row exchange: lanes 0-31 (even rows) end with the two-half (two-row) sums of a, the others with b's
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  swap32(a, b);
+  return a + b;
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  swap16(a, b);
+  return a + b;
+}
+
+// FULL: dstate == NW * NS known at compile time (every wave owns NS valid states).
 // YIN: the forward kept y before the gate (ScanParams::ypre_in): the reverse step then neither rebuilds sum_n C x_t (one
 // packed fma per state pair, one add and one LDS store per step) nor does phase C sum it over the waves.
-template <int NW, int BC, typename TIO, bool FULL, bool YIN = false>
+template <int NW, typename TIO, bool FULL, bool YIN = false>
 __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
-  constexpr bool FAST = BC == 1;
-  constexpr bool LDSBC = BC == 2;
   constexpr int K = (TB + NW - 1) / NW;
   constexpr int NT = NW * 64;
   constexpr int NP = NW * NS;
-  constexpr int BCK = LDSBC ? (TB * NP + NT - 1) / NT : 1;
-  __shared__ __attribute__((aligned(16))) float s_B[LDSBC ? TB : 1][LDSBC ? NP : 4];
-  __shared__ __attribute__((aligned(16))) float s_C[LDSBC ? TB : 1][LDSBC ? NP : 4];
-  __shared__ __attribute__((aligned(16))) float4 s_op[TB][64];   // per (t, d): {delta', delta' u, dy, -}: one 16-byte read per step
+  static_assert(NT == SUB * NP, "one B / C element per thread and half");
+  // reverse steps per 8-step half that take their decay factors from LDS (16 KB each at NW = 8); the variant that also
+  // keeps the per-wave partial y in LDS gives one up to stay inside 160 KB
+  constexpr int NA = (!YIN && NW == 8) ? 4 : 5;
+  // the current half's B / C tiles: [B | C][variant][row][64 floats, rotated by 16 * variant]
+  __shared__ __attribute__((aligned(16))) float s_bc[2][4][SUB][64];
+  __shared__ __attribute__((aligned(16))) float4 s_op[TB][64];   // per (t, d): {delta', delta' u, dy, u}: one 16-byte read per step
+  // per (t, d), for phase C only: {dout * d silu(z) / dz (-> dz = that * y), d softplus (-> ddelta), y before the gate, -}.
+  // (Phase A's values used to wait in 12 registers per lane across both walks; at 256 registers a spilled value costs a
+  //  scratch reload + s_waitcnt vmcnt(0), which also waits for every row and checkpoint load in flight.)
+  __shared__ __attribute__((aligned(16))) float4 s_fin[TB][64];
   // per wave, step slot and channel: {sum_n g * A' (-> ddelta), sum_n dx * B (-> ddelta, du)}: one 8-byte store per step
   __shared__ __attribute__((aligned(8))) float2 s_p12[NW][SUB][64];
   __shared__ float s_y[YIN ? 1 : NW][YIN ? 1 : SUB][64];   // sum_n C * x_t  (-> dz)
@@ -72,71 +153,110 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   const int n0 = w * NS;
   const int nvalid = FULL ? NS : ((N - n0) < NS ? (N - n0) : NS);
   const int nchunks = p.nchunks;
+  const int hm = lane_hmask(lane);       // slot k of this lane holds state n0 + (k ^ hm)
 
   f2 Ap[NP2], dAacc[NP2], dxc[NP2];
 #pragma unroll
-  for (int j = 0; j < NS; ++j) {
+  for (int k = 0; k < NS; ++k) {
+    const int j = k ^ hm;
     const int jj = j < nvalid ? j : nvalid - 1;
     const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
-    Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
-    dAacc[j / 2][j % 2] = 0.f;
-    dxc[j / 2][j % 2] = 0.f;
+    Ap[k / 2][k % 2] = (j < nvalid) ? a : 0.f;
+    dAacc[k / 2][k % 2] = 0.f;
+    dxc[k / 2][k % 2] = 0.f;
   }
   const float Dd = p.D ? p.D[dc] : 0.f;
   const float bias = p.bias ? p.bias[dc] : 0.f;
-  const TIO *up = static_cast<const TIO *>(p.u) + b * p.s.u_sb + dc * p.s.u_sd;
-  const TIO *dtp = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb + dc * p.s.dt_sd;
+  // wave-uniform bases (scalar registers) + one 32-bit element offset per lane and tensor (scan_check_shape bounds them)
+  const TIO *up = static_cast<const TIO *>(p.u) + b * p.s.u_sb;
+  const TIO *dtp = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb;
   const bool has_z = p.z != nullptr;
-  const TIO *zp = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb + dc * p.s.z_sd : up;
-  const TIO *dop = static_cast<const TIO *>(p.dout) + b * p.s.o_sb + dc * p.s.o_sd;
-  const TIO *yip = YIN ? static_cast<const TIO *>(p.ypre_in) + b * p.s.o_sb + dc * p.s.o_sd : dop;
-  TIO *dup = static_cast<TIO *>(p.du) + b * p.gs.du_sb + dc * p.gs.du_sd;
-  TIO *ddtp = static_cast<TIO *>(p.ddelta) + b * p.gs.dd_sb + dc * p.gs.dd_sd;
-  TIO *dzp = has_z ? static_cast<TIO *>(p.dz) + b * p.gs.dz_sb + dc * p.gs.dz_sd : nullptr;
+  const TIO *zp = has_z ? static_cast<const TIO *>(p.z) + b * p.s.z_sb : up;
+  const TIO *dop = static_cast<const TIO *>(p.dout) + b * p.s.o_sb;
+  const TIO *yip = YIN ? static_cast<const TIO *>(p.ypre_in) + b * p.s.o_sb : dop;
+  TIO *dup = static_cast<TIO *>(p.du) + b * p.gs.du_sb;
+  TIO *ddtp = static_cast<TIO *>(p.ddelta) + b * p.gs.dd_sb;
+  TIO *dzp = has_z ? static_cast<TIO *>(p.dz) + b * p.gs.dz_sb : nullptr;
+  const int u_o = dc * (int)p.s.u_sd, dt_o = dc * (int)p.s.dt_sd, z_o = has_z ? dc * (int)p.s.z_sd : u_o;
+  const int o_o = dc * (int)p.s.o_sd;
+  const int du_o = dc * (int)p.gs.du_sd, dd_o = dc * (int)p.gs.dd_sd, dz_o = dc * (int)p.gs.dz_sd;
   const int du_sl = (int)p.gs.du_sl, dd_sl = (int)p.gs.dd_sl, dz_sl = (int)p.gs.dz_sl;
-  const float *Bw = p.Bm + b * p.s.B_sb + n0 * p.s.B_sn;
-  const float *Cw = p.Cm + b * p.s.C_sb + n0 * p.s.C_sn;
-  float *wsB = p.ws_dB + ((int64_t)b * p.ngroups + g) * L * N + n0;
-  float *wsC = p.ws_dC + ((int64_t)b * p.ngroups + g) * L * N + n0;
   const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
   const int o_sl = (int)p.s.o_sl;
   const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
   const int softplus = p.s.delta_softplus;
 
-  // dB / dC slab stores: the first lane of every quad owns one total (wave_reduce_scatter8x2q): quads 0 / 1 of row q the
-  // dB sums of states 2q / 2q + 1 of the wave's slice, quads 2 / 3 the dC sums
-  const unsigned qoff = 2u * (lane >> 4) + ((lane >> 2) & 1);
-  const bool st_on = (lane & 3) == 0 && (int)qoff < nvalid;
+  // dB / dC slab stores (see the header): this lane's array, state and step offset inside a group of four steps
+  const int st_state = lane_hmask(lane & 7);
+  const int st_row = lane >> 4;
+  const int st_step = 3 - (2 * (st_row & 1) + (st_row >> 1));
+  const int st_lim = st_state < nvalid ? st_step : (1 << 24);      // (a slot without a state never passes the step test)
+  // wave-uniform slab bases (scalar registers) + one 32-bit element offset per lane; which slab a lane stores to is
+  // selected where it stores (two v_cndmask per store, two stores per half) instead of living in a 64-bit register pair
+  // per lane across the walks
+  float *const sB = p.ws_dB + ((int64_t)b * p.ngroups + g) * L * N + n0;
+  float *const sC = p.ws_dC + ((int64_t)b * p.ngroups + g) * L * N + n0;
+  const int st_o = st_state + st_step * N;
+  int lane8 = lane & 8;
 
   float accD = 0.f, accBias = 0.f;
 
-  // raw (t, d) rows of the chunk about to be processed; fetched one chunk ahead
-  float ru[K], rdl[K], rz[K], rdo[K], ry[K], rb[BCK], rc[BCK];
+  // this thread's element of a half's B / C tiles: row tid / NP of the half, state tid % NP
+  const int bc_row = tid / NP, bc_n = tid % NP;
+  const bool bc_ok = bc_n < N;
   const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
+  const int B_o = (bc_ok ? bc_n : N - 1) * B_sn, C_o = (bc_ok ? bc_n : N - 1) * C_sn;
+  auto stage_bc = [&](float bv, float cv) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int q = ((bc_n ^ v) + 16 * v) & 63;
+      s_bc[0][v][bc_row][q] = bv;
+      s_bc[1][v][bc_row][q] = cv;
+    }
+  };
+  // this lane's two float4 of a row: variant hm & 3, halves swapped by bit 2 of hm
+  typedef const __attribute__((address_space(3))) float *lds_cfp;
+  lds_cfp lB0 = (lds_cfp)&s_bc[0][hm & 3][0][((n0 + 16 * (hm & 3)) & 63) + 4 * (hm >> 2)];
+  lds_cfp lB1 = (lds_cfp)&s_bc[0][hm & 3][0][((n0 + 16 * (hm & 3)) & 63) + 4 * (1 - (hm >> 2))];
+  asm volatile("" : "+v"(lB0), "+v"(lB1));   // (kept in vector registers; the per-step offsets are immediates)
+  constexpr int kCoff = 4 * SUB * 64;          // s_bc[1] - s_bc[0] in floats
+
+  // raw (t, d) rows of the NEXT chunk to be processed and its two B / C elements, kept as loaded (a conversion beside the
+  // load makes the wave wait for the row right where it asks for it; so does packing two 16-bit loads into one register).
+  // They are requested in front of the first half's walk -- not a whole chunk ahead in phase A: the second half's walk
+  // is the kernel's register peak (both entering states are still live there), and rows requested after it are dead
+  // again (phase A turns them into LDS records) before the next one
+  TIO ru[K], rdl[K], rz[K], rdo[K], ry[K];
+  float rb[2], rc[2];
   auto load_rows = [&](int c) {
     const int t0 = c * TB, tlast = L - 1 - t0;
-    if constexpr (LDSBC) {
 #pragma unroll
-      for (int k = 0; k < BCK; ++k) {
-        const int e = tid + k * NT;
-        const int tl = e / NP, n = e % NP;
-        const int t = t0 + (tl <= tlast ? tl : tlast);
-        const int nc = n < N ? n : N - 1;
-        const float bvv = Bb[t * B_sl + nc * B_sn], cvv = Cb[t * C_sl + nc * C_sn];
-        rb[k] = n < N ? bvv : 0.f;
-        rc[k] = n < N ? cvv : 0.f;
-      }
+    for (int hf = 0; hf < 2; ++hf) {
+      const int tl = hf * SUB + bc_row;
+      const int t = t0 + (tl <= tlast ? tl : tlast);
+      const float bvv = Bb[B_o + t * B_sl], cvv = Cb[C_o + t * C_sl];
+      rb[hf] = bc_ok ? bvv : 0.f;
+      rc[hf] = bc_ok ? cvv : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int tl = w + k * NW;
       const int tc = t0 + (tl <= tlast ? tl : tlast);  // clamped address, masked value
-      ru[k] = (float)up[tc * u_sl];
-      rdl[k] = (float)dtp[tc * dt_sl];
-      rz[k] = (float)zp[tc * z_sl];
-      rdo[k] = (float)dop[tc * o_sl];
-      if constexpr (YIN) ry[k] = (float)yip[tc * o_sl];
+      ru[k] = up[u_o + tc * u_sl];
+      rdl[k] = dtp[dt_o + tc * dt_sl];
+      rz[k] = zp[z_o + tc * z_sl];
+      rdo[k] = dop[o_o + tc * o_sl];
+      if constexpr (YIN) ry[k] = yip[o_o + tc * o_sl];
     }
+  };
+  // checkpoint of this wave's slice, straight into slot order: slot k = row k ^ hm of the (b, c, h, w, g) block, column
+  // pi(lane) (scan_common.h, wide layout) -- eight 4-byte loads, each 8 whole 32-byte sectors per wave; a wave-uniform
+  // base + one 32-bit offset per lane, the row selected by ONE xor (row and column bits do not overlap)
+  const int ck_o = hm * 64 + ckpt_pi(lane);
+  auto ckpt_load_slots = [&](int c, int h, f2 (&x)[NP2]) {
+    const float *q = p.ckpt_in + ckpt_wide_block(b, nchunks, c, h, NW, w, Dm, g);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) x[k / 2][k % 2] = q[ck_o ^ (k * 64)];
   };
   load_rows(nchunks - 1);
 #ifdef CUM_SCAN_PROBE
@@ -147,19 +267,19 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * TB;
     const int tlast = L - 1 - t0;  // last valid local step of this chunk (>= 0)
-    // per-lane slab (dB or dC) + this chunk's first row + per-lane column: the per-step row offset is then an immediate
-    float *const cBC = ((lane & 8) ? wsC : wsB) + (int64_t)t0 * N + qoff;
     // state entering the chunk: needed by both halves, requested now so that its latency hides behind phase A
     f2 x0[NP2], x8[NP2];   // x8: state entering the second half (local step 8), read only if the chunk reaches it
-    ckpt_load(p.ckpt_in, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, dc), x0);
-    ckpt_load(p.ckpt_in, ckpt_slot(b, nchunks, c, tlast >= SUB ? 1 : 0, NW, w, Dm, dc), x8);
-    float eu[K], ez[K], edo[K], edt[K], esg[K], ey[K];
+    // (requesting the first half's state only behind the second half's walk would free eight registers there; measured
+    //  at compile time it costs the allocator more than it frees: 52 spilled registers against 9)
+    const bool two = tlast >= SUB;
+    ckpt_load_slots(c, 0, x0);
+    ckpt_load_slots(c, two ? 1 : 0, x8);
     // ---- phase A: per-(t, d) quantities, once, into LDS
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int tl = w + k * NW;
       const bool ok = dok && tl < TB && tl <= tlast;
-      const float uv = ru[k], dv = rdl[k], zv = rz[k], dov = rdo[k];
+      const float uv = (float)ru[k], dv = (float)rdl[k], zv = (float)rz[k], dov = (float)rdo[k];
       const float pre = dv + bias;
       float dtv = pre, sg = 1.f;
       if (softplus) {
@@ -167,65 +287,40 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         sg = pre <= 20.f ? sigmoidf_(pre) : 1.f;
       }
       dtv = ok ? dtv : 0.f;
-      float dy = ok ? dov : 0.f;
-      if (has_z) dy *= zv * sigmoidf_(zv);
-      if (tl < TB) s_op[tl][lane] = make_float4(dtv, ok ? dtv * uv : 0.f, ok ? dy : 0.f, 0.f);
-      eu[k] = uv; ez[k] = zv; edo[k] = dov; edt[k] = dtv; esg[k] = sg;
-      if constexpr (YIN) ey[k] = ry[k];
-    }
-    if constexpr (LDSBC) {
-#pragma unroll
-      for (int k = 0; k < BCK; ++k) {
-        const int e = tid + k * NT;
-        if (e < TB * NP) {
-          (&s_B[0][0])[e] = rb[k];
-          (&s_C[0][0])[e] = rc[k];
-        }
+      float dy = ok ? dov : 0.f, dzf = 0.f;
+      if (has_z) {
+        const float sz = sigmoidf_(zv);
+        dy *= zv * sz;
+        dzf = dov * sz * (1.f + zv * (1.f - sz));
+      }
+      if (tl < TB) {
+        s_op[tl][lane] = make_float4(dtv, ok ? dtv * uv : 0.f, ok ? dy : 0.f, uv);
+        s_fin[tl][lane] = make_float4(dzf, sg, YIN ? (float)ry[k] : 0.f, 0.f);
       }
     }
-    if (c > 0) load_rows(c - 1);
+    // B / C tiles of the half walked first: the second one if the chunk reaches it (rows past the clip's end hold the last
+    // row's values and meet zero dt / du / dy); the first half's element waits in two registers
+    stage_bc(two ? rb[1] : rb[0], two ? rc[1] : rc[0]);
+    const float hb0 = rb[0], hc0 = rc[0];
     PROBE(0);
     __syncthreads();
     PROBE(1);
 
-    // this wave's slices of the B / C tiles: addresses kept in vector registers (left to itself the compiler re-creates the
-    // wave-uniform address from a scalar before every step's reads)
-    typedef const __attribute__((address_space(3))) float *lds_cfp;
-    lds_cfp lB = (lds_cfp)&s_B[0][LDSBC ? n0 : 0], lC = (lds_cfp)&s_C[0][LDSBC ? n0 : 0];
-    asm volatile("" : "+v"(lB), "+v"(lC));
     f2 xs[SUB][NP2];   // states before each step of the half being processed
-    // Operands of one time step: B_t / C_t slices (SGPRs via s_load) and the per-(t, d) values from LDS.  They are
-    // fetched one step ahead of their use so that neither the scalar-load nor the LDS latency is exposed.
+    // Operands of one time step: B_t / C_t in slot order and the per-(t, d) values, all from LDS.  They are
+    // fetched one step ahead of their use so that the LDS latency is not exposed.
     struct StepOps {
       f2 bv[NP2], cv[NP2];
-      f2 a[NP2];        // decay factors, only for steps whose slot is < NA
       float dt, du, dy;
     };
-    auto fetch = [&](int tl, StepOps &o, int aslot = -1) {
-      const int tc = tl <= tlast ? tl : tlast;
-      if (aslot >= 0 && aslot < NA) {
-        const float4 a0 = s_a[aslot][0][tid], a1 = s_a[aslot][1][tid];
-        o.a[0] = f2{a0.x, a0.y}; o.a[1] = f2{a0.z, a0.w}; o.a[2] = f2{a1.x, a1.y}; o.a[3] = f2{a1.z, a1.w};
-      }
-      if constexpr (LDSBC) {
-        // (row tl itself, not the clamped tc: rows past the clip's end hold the last row's values and meet zero dt / du / dy,
-        //  and a compile-time tl makes these addresses immediates)
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(3))) f4v *lds_c4p;
-        const f4v b0 = *(lds_c4p)(lB + tl * NP), b1 = *(lds_c4p)(lB + tl * NP + 4);
-        const f4v c0 = *(lds_c4p)(lC + tl * NP), c1 = *(lds_c4p)(lC + tl * NP + 4);
-        o.bv[0] = f2{b0.x, b0.y}; o.bv[1] = f2{b0.z, b0.w}; o.bv[2] = f2{b1.x, b1.y}; o.bv[3] = f2{b1.z, b1.w};
-        o.cv[0] = f2{c0.x, c0.y}; o.cv[1] = f2{c0.z, c0.w}; o.cv[2] = f2{c1.x, c1.y}; o.cv[3] = f2{c1.z, c1.w};
-      } else {
-        float bs[NS], cs[NS];
-        load_bc<FAST>(opaque(Bw + (t0 + tc) * B_sl), B_sn, nvalid, bs);
-        load_bc<FAST>(opaque(Cw + (t0 + tc) * C_sl), C_sn, nvalid, cs);
-#pragma unroll
-        for (int j = 0; j < NP2; ++j) {
-          o.bv[j] = f2{bs[2 * j], bs[2 * j + 1]};
-          o.cv[j] = f2{cs[2 * j], cs[2 * j + 1]};
-        }
-      }
+    auto fetch = [&](int tl, StepOps &o) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      typedef const __attribute__((address_space(3))) f4v *lds_c4p;
+      const int r = (tl % SUB) * 64;     // row of the half's tile (compile-time: an immediate offset)
+      const f4v b0 = *(lds_c4p)(lB0 + r), b1 = *(lds_c4p)(lB1 + r);
+      const f4v c0 = *(lds_c4p)(lB0 + r + kCoff), c1 = *(lds_c4p)(lB1 + r + kCoff);
+      o.bv[0] = f2{b0.x, b0.y}; o.bv[1] = f2{b0.z, b0.w}; o.bv[2] = f2{b1.x, b1.y}; o.bv[3] = f2{b1.z, b1.w};
+      o.cv[0] = f2{c0.x, c0.y}; o.cv[1] = f2{c0.z, c0.w}; o.cv[2] = f2{c1.x, c1.y}; o.cv[3] = f2{c1.z, c1.w};
       const float4 op = s_op[tl][lane];
       o.dt = op.x; o.du = op.y; o.dy = op.z;
     };
@@ -243,25 +338,28 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    // one reverse step; xp = state before step tl; slot = tl % SUB
-    auto rev_step = [&](const f2 (&xp)[NP2], int tl, int slot, const StepOps &o) {
+    // one reverse step; xp = state before step tl; slot = tl % SUB; returns the step's row-level dB / dC totals
+    auto rev_step = [&](const f2 (&xp)[NP2], int slot, const StepOps &o) -> float {
       const float dt = o.dt, du = o.du, dy = o.dy;
-      f2 p1, p2, yp = {0.f, 0.f};   // even / odd states summed apart, joined below
-      float ra[8], rb[8];   // the dB / dC contributions of this step, as the reduction takes them (scan_reduce.h)
+      // decay factors: parked in LDS by the recomputed step (slots < NA), requested at the top of their OWN step -- a step
+      // ahead they would hold eight more registers across the previous step's peak -- and first used behind dx and the
+      // sixteen products
+      f2 ap[NP2];
+      if (slot < NA) {
+        const float4 a0 = s_a[slot][0][tid], a1 = s_a[slot][1][tid];
+        ap[0] = f2{a0.x, a0.y}; ap[1] = f2{a0.z, a0.w}; ap[2] = f2{a1.x, a1.y}; ap[3] = f2{a1.z, a1.w};
+      }
+      f2 p1, p2, yp = {0.f, 0.f};   // even / odd states summed apart, joined in the reduction's hazard slots
+      float rdx[NS], rxt[NS];
 #pragma unroll
       for (int j = 0; j < NP2; ++j) {
-        const f2 a = slot < NA ? o.a[j] : exp2_2(dt * Ap[j]);
+        const f2 a = slot < NA ? ap[j] : exp2_2(dt * Ap[j]);
         // the state after this step is the saved state before the next one (recomputed only for the half's last step)
         const f2 xt = slot + 1 < SUB ? xs[slot + 1][j] : a * xp[j] + du * o.bv[j];
         const f2 dx = o.cv[j] * dy + dxc[j];
         if constexpr (!YIN) yp = o.cv[j] * xt + yp;
-        // (scalar multiplies on purpose: sixteen free-standing registers for the exchanges instead of eight register
-        //  copies out of packed results)
-        float *const qB = j < 2 ? ra : rb, *const qC = j < 2 ? ra + 4 : rb + 4;
-        qB[2 * (j & 1)] = dx.x * du;
-        qB[2 * (j & 1) + 1] = dx.y * du;
-        qC[2 * (j & 1)] = dy * xt.x;
-        qC[2 * (j & 1) + 1] = dy * xt.y;
+        rdx[2 * j] = dx.x * du; rdx[2 * j + 1] = dx.y * du;      // (scalar multiplies on purpose: see xor_reduce16)
+        rxt[2 * j] = xt.x; rxt[2 * j + 1] = xt.y;
         dxc[j] = a * dx;
         const f2 gg = dxc[j] * xp[j];
         dAacc[j] = gg * dt + dAacc[j];
@@ -273,15 +371,36 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
           p2 = dx * o.bv[j] + p2;
         }
       }
-      {
-        float *const q = reinterpret_cast<float *>(&s_p12[w][slot][lane]);
-        q[0] = p1.x + p1.y;
-        q[1] = p2.x + p2.y;
-      }
+      float X, q0, q1;
+      xor_reduce16(rdx, rxt, dy, p1.x, p1.y, p2.x, p2.y, X, q0, q1);
+      s_p12[w][slot][lane] = make_float2(q0, q1);
       if constexpr (!YIN) s_y[w][slot][lane] = yp.x + yp.y;
-      const float tot = wave_reduce_scatter8x2q_s(ra, rb);
-      if (tl <= tlast && st_on) cBC[tl * N] = tot;
       __builtin_amdgcn_sched_barrier(0);
+      return X;
+    };
+    // the reverse walk of one half (cur holds the operands of its last step): after every second step the two steps'
+    // totals meet across the lane halves, after every fourth across the rows -> one finished register per four steps
+    auto rev_walk = [&](int base, StepOps &cur, StepOps &nxt) {
+      float Xo = 0.f, Yo = 0.f;
+#pragma unroll
+      for (int s = SUB - 1; s >= 0; --s) {
+        if (s > 0) fetch(base + s - 1, nxt);
+        const float X = rev_step(xs[s], s, cur);
+        if (s > 0) cur = nxt;
+        if (s & 1) {
+          Xo = X;
+        } else {
+          const float Y = swap32_add(Xo, X);       // lanes 0-31: step s + 1, lanes 32-63: step s
+          if (s & 2) {
+            Yo = Y;
+          } else {
+            const float Z = swap16_add(Yo, Y);     // rows 0..3: steps s + 3, s + 1, s + 2, s
+            asm volatile("" : "+v"(lane8));        // (keeps the select below at the store)
+            float *const slab = lane8 ? sC : sB;
+            if (base + s + st_lim <= tlast) slab[st_o + (t0 + base + s) * N] = Z;
+          }
+        }
+      }
     };
     // phase C for one half: combine the per-wave partial sums, write du / ddelta / dz
     auto finish_half = [&](int half) {
@@ -291,7 +410,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         const int slot = tl - half * SUB;
         if (tl < TB && slot >= 0 && slot < SUB && tl <= tlast && dok) {
           const int t = t0 + tl;
-          float q1 = 0.f, q2 = 0.f, y = YIN ? ey[k] : Dd * eu[k];
+          const float4 op = s_op[tl][lane], fin = s_fin[tl][lane];   // {delta', -, dy, u}, {dout dsilu, dsoftplus, y, -}
+          float q1 = 0.f, q2 = 0.f, y = YIN ? fin.z : Dd * op.w;
 #pragma unroll
           for (int ww = 0; ww < NW; ++ww) {
             const float2 q = s_p12[ww][slot][lane];
@@ -299,18 +419,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
             q2 += q.y;
             if constexpr (!YIN) y += s_y[ww][slot][lane];
           }
-          const float zv = ez[k], dov = edo[k];
-          float dy = dov;
-          if (has_z) {
-            const float sz = sigmoidf_(zv);
-            dy = dov * zv * sz;
-            dzp[t * dz_sl] = (TIO)(dov * y * sz * (1.f + zv * (1.f - sz)));
-          }
-          const float ddt = kLn2 * q1 + eu[k] * q2;  // d loss / d delta'
-          const float dpre = ddt * esg[k];
-          dup[t * du_sl] = (TIO)fmaf(dy, Dd, edt[k] * q2);
-          ddtp[t * dd_sl] = (TIO)dpre;
-          accD = fmaf(dy, eu[k], accD);
+          if (has_z) dzp[dz_o + t * dz_sl] = (TIO)(fin.x * y);
+          const float ddt = kLn2 * q1 + op.w * q2;  // d loss / d delta'
+          const float dpre = ddt * fin.y;
+          dup[du_o + t * du_sl] = (TIO)fmaf(op.z, Dd, op.x * q2);
+          ddtp[dd_o + t * dd_sl] = (TIO)dpre;
+          accD = fmaf(op.z, op.w, accD);
           accBias += dpre;
         }
       }
@@ -318,7 +432,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
 
     StepOps cur, nxt;
     // ---- second half (local steps 8..15), only if the chunk reaches it
-    if (tlast >= SUB) {
+    if (two) {
       f2 x[NP2];
 #pragma unroll
       for (int j = 0; j < NP2; ++j) x[j] = x8[j];
@@ -334,15 +448,11 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         }
       }
       PROBE(2);
-#pragma unroll
-      for (int s = SUB - 1; s >= 0; --s) {     // reverse 15..8 (cur holds step 15's operands)
-        if (s > 0) fetch(SUB + s - 1, nxt, s - 1);
-        rev_step(xs[s], SUB + s, s, cur);
-        if (s > 0) cur = nxt;
-      }
+      rev_walk(SUB, cur, nxt);                 // reverse 15..8 (cur holds step 15's operands)
       PROBE(3);
       __syncthreads();
       PROBE(4);
+      stage_bc(hb0, hc0);                      // the first half's B / C tiles (every reader of the second's is past the barrier)
       finish_half(1);
       PROBE(5);
       __syncthreads();  // partial-sum buffers are reused by the first half
@@ -365,19 +475,17 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
         }
       }
       PROBE(7);
-#pragma unroll
-      for (int s = SUB - 1; s >= 0; --s) {
-        if (s > 0) fetch(s - 1, nxt, s - 1);
-        rev_step(xs[s], s, s, cur);
-        if (s > 0) cur = nxt;
-      }
+      // the next chunk's rows (see the declaration of ru); behind the recompute, whose first step waited for this chunk's
+      // entering state: a request in front of it would put these loads under that wait
+      if (c > 0) load_rows(c - 1);
+      rev_walk(0, cur, nxt);
       PROBE(8);
       __syncthreads();
       PROBE(9);
       finish_half(0);
       PROBE(10);
     }
-    // The next chunk's phase A writes only s_op / s_B / s_C (their readers finished before
+    // The next chunk's phase A writes only s_op / s_bc (their readers finished before
     // the last barrier) and its first rev_step runs after that phase's barrier, which
     // every wave reaches only after this finish_half.
   }
@@ -385,8 +493,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   if (dok) {
     float *wa = p.ws_dA + ((int64_t)b * Dm + d) * N + n0;
 #pragma unroll
-    for (int j = 0; j < NS; ++j)
-      if (j < nvalid) wa[j] = dAacc[j / 2][j % 2];
+    for (int k = 0; k < NS; ++k)
+      if ((k ^ hm) < nvalid) wa[k ^ hm] = dAacc[k / 2][k % 2];
   }
   __syncthreads();
   s_p12[w][0][lane] = make_float2(accD, accBias);
@@ -509,22 +617,12 @@ __global__ void scan_bwd_finalize_kernel(const ScanParams p, float *dA, float *d
 template <int NW, typename TIO>
 static int launch_bwd_io(const ScanParams &p, hipStream_t st) {
   dim3 grid((p.s.dim + 63) / 64, p.s.batch), block(NW * 64);
-#ifdef CUM_AB   // CUM_SCAN_BWD_LDS=0: B_t / C_t through scalar loads instead of the LDS tile (-6.5 % per launch)
-  if (cum_knob("CUM_SCAN_BWD_LDS", 1) == 0) {
-    if (p.s.B_sn == 1 && p.s.C_sn == 1 && p.s.dstate == NS * NW)
-      hipLaunchKernelGGL((scan_bwd_kernel<NW, 1, TIO, false>), grid, block, 0, st, p);
-    else
-      hipLaunchKernelGGL((scan_bwd_kernel<NW, 0, TIO, false>), grid, block, 0, st, p);
-    CUM_CHECK_LAUNCH();
-    return CUM_OK;
-  }
-#endif
   if (p.s.dstate == NS * NW && p.ypre_in && p.z)     // (y only enters dz; shapes with a ragged last wave rebuild it)
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO, true, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, TIO, true, true>), grid, block, 0, st, p);
   else if (p.s.dstate == NS * NW)
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, TIO, true>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((scan_bwd_kernel<NW, 2, TIO, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((scan_bwd_kernel<NW, TIO, false>), grid, block, 0, st, p);
   CUM_CHECK_LAUNCH();
   return CUM_OK;
 }
@@ -570,6 +668,19 @@ static int scan_bwd_impl(const cum_scan_shape *s, const cum_scan_grad_strides *g
                 "scan_bwd: gradient time strides must be non-negative and fit in 31 bits");
   }
   CUM_REQUIRE((z == nullptr) == (dz == nullptr), "scan_bwd: z and dz must be given together");
+  if (s->dstate > 2 * NS) {
+    // scan_bwd_kernel addresses a clip's u / delta / z / dout / du / ddelta / dz through a wave-uniform base + ONE 32-bit
+    // byte offset per lane: the clip's extent (channel and time strides) has to fit
+    const int64_t lim = (1LL << 29), Lm = s->len > 0 ? s->len - 1 : 0, Dl = s->dim - 1;
+    CUM_REQUIRE(s->u_sd >= 0 && s->dt_sd >= 0 && s->z_sd >= 0 && s->o_sd >= 0 && gs->du_sd >= 0 && gs->dd_sd >= 0 &&
+                    gs->dz_sd >= 0,
+                "scan_bwd: negative channel strides are not supported");
+    CUM_REQUIRE(Dl * s->u_sd + Lm * s->u_sl < lim && Dl * s->dt_sd + Lm * s->dt_sl < lim &&
+                    Dl * s->z_sd + Lm * s->z_sl < lim && Dl * s->o_sd + Lm * s->o_sl < lim &&
+                    Dl * gs->du_sd + Lm * gs->du_sl < lim && Dl * gs->dd_sd + Lm * gs->dd_sl < lim &&
+                    Dl * gs->dz_sd + Lm * gs->dz_sl < lim && (int64_t)s->dim * NS < lim,
+                "scan_bwd: one clip's tensors must span fewer than 2^29 elements (d_state > 16)");
+  }
   hipStream_t st = (hipStream_t)stream;
   if (s->batch == 0 || s->len == 0) {
     (void)hipMemsetAsync(dA, 0, sizeof(float) * (size_t)s->dim * s->dstate, st);
@@ -600,11 +711,13 @@ static int scan_bwd_impl(const cum_scan_shape *s, const cum_scan_grad_strides *g
   switch ((s->dstate + NS - 1) / NS) {
     case 1:
     case 2: rc = launch_bwd_small(p, st); break;
+#ifndef CUM_ONLY8   // (compile-time experiments on the d_state-64 kernel alone)
     case 3: rc = launch_bwd<3>(p, st); break;
     case 4: rc = launch_bwd<4>(p, st); break;
     case 5: rc = launch_bwd<5>(p, st); break;
     case 6: rc = launch_bwd<6>(p, st); break;
     case 7: rc = launch_bwd<7>(p, st); break;
+#endif
     default: rc = launch_bwd<8>(p, st); break;
   }
   if (rc) return rc;

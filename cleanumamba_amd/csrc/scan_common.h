@@ -44,8 +44,9 @@ struct ScanParams {
   float *carry;
 };
 
-// Checkpoint buffer: the NS states a lane (channel d) of wave w holds, entering half h of chunk c of clip b, as
-// 32 contiguous bytes -- [(b, c, h, w, d)][NS]: two 16-byte accesses per lane, 2 KB contiguous per wave.
+// Checkpoint buffer, d_state <= 16 (one or two waves per workgroup): the NS states a lane (channel d) of wave w holds,
+// entering half h of chunk c of clip b, as 32 contiguous bytes -- [(b, c, h, w, d)][NS]: two 16-byte accesses per lane,
+// 2 KB contiguous per wave.
 __device__ __forceinline__ int64_t ckpt_slot(int b, int nchunks, int c, int h, int NW, int w, int Dm, int d) {
   return (((((int64_t)b * nchunks + c) * 2 + h) * NW + w) * Dm + d) * NS;
 }
@@ -63,6 +64,33 @@ __device__ __forceinline__ void ckpt_load(const float *ck, int64_t slot, f2 (&x)
   const float4 *q = reinterpret_cast<const float4 *>(ck + slot);
   const float4 a = q[0], c = q[1];
   x[0] = f2{a.x, a.y}; x[1] = f2{a.z, a.w}; x[2] = f2{c.x, c.y}; x[3] = f2{c.z, c.w};
+}
+
+// Checkpoint buffer, d_state > 16 (NW >= 3 waves per workgroup; written by scan_fwd_kernel / scan_fwd_lds_kernel /
+// scan_seg_kernel, read by scan_bwd_kernel): per (b, c, h, w, 64-channel group g) a block of 8 x 64 floats, STATE-major --
+// [state n of the wave's slice][column pi(lane)], pi(l) = (l & 7) * 8 + (l >> 3).  The backward kernel keeps state
+// k ^ h(lane) in register slot k (scan_bwd.hip, "xor scatter"), h a function of lane & 7: in this layout its load of slot
+// k touches 8 whole 32-byte sectors per wave (lanes with equal lane & 7 sit side by side in one row), where a lane-major
+// layout made it 64 partial ones -- and the forward's 8 stores per checkpoint are 256 contiguous bytes each instead of
+// two interleaved half-sector passes.  The group axis is padded to whole groups (cum_scan_ckpt_elems).
+constexpr bool ckpt_is_wide(int NW) { return NW >= 3; }
+__device__ __forceinline__ int ckpt_pi(int lane) { return (lane & 7) * 8 + (lane >> 3); }
+__device__ __forceinline__ int64_t ckpt_wide_block(int b, int nchunks, int c, int h, int NW, int w, int Dm, int g) {
+  const int G = (Dm + 63) >> 6;
+  return (((((int64_t)b * nchunks + c) * 2 + h) * NW + w) * G + g) * (64 * NS);
+}
+__device__ __forceinline__ float ckpt_elem(const float (&x)[NS], int n) { return x[n]; }
+__device__ __forceinline__ float ckpt_elem(const f2 (&x)[NS / 2], int n) { return x[n / 2][n % 2]; }
+// the state a lane holds in natural order (x[n] = state n of the wave's slice) -> the layout its NW asks for
+template <int NW, typename X>
+__device__ __forceinline__ void ckpt_put(float *ck, int b, int nchunks, int c, int h, int w, int Dm, int d, const X &x) {
+  if constexpr (ckpt_is_wide(NW)) {
+    float *q = ck + ckpt_wide_block(b, nchunks, c, h, NW, w, Dm, d >> 6) + ckpt_pi(d & 63);
+#pragma unroll
+    for (int n = 0; n < NS; ++n) q[n * 64] = ckpt_elem(x, n);
+  } else {
+    ckpt_store(ck, ckpt_slot(b, nchunks, c, h, NW, w, Dm, d), x);
+  }
 }
 
 // carry buffer of the time-parallel forms (scan_seg.hip forward, scan_bwd_small.hip backward): [(b, seg, w, d)][NS] f32

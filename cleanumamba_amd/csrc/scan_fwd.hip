@@ -85,7 +85,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
       ez[k] = rz[k];
     }
     if (c + 1 < nchunks) load_rows(t0 + TB);  // prefetch the next chunk's rows
-    if (p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, d), x);
+    if (p.ckpt && dok) ckpt_put<NW>(p.ckpt, b, nchunks, c, 0, w, Dm, d, x);
     __syncthreads();
     // ---- phase B: 16 sequential steps.  Operands (s_load for B/C, ds_read for delta'/du) are fetched TWO steps
     //      at a time, one pair ahead of their use: scalar loads return out of order, so any wait on them is a
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
         }
         s_y[w][tp + h][lane] = y;
         if (tp + h == SUB - 1 && p.ckpt && dok)   // state entering the second half of the chunk
-          ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 1, NW, w, Dm, d), x);
+          ckpt_put<NW>(p.ckpt, b, nchunks, c, 1, w, Dm, d, x);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (tp + 2 < TB) cur = nxt;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
       }
     }
     if (c + 1 < nchunks) load_rows(t0 + TB);
-    if (p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, d), x);
+    if (p.ckpt && dok) ckpt_put<NW>(p.ckpt, b, nchunks, c, 0, w, Dm, d, x);
     __syncthreads();
     float4 b0 = *reinterpret_cast<const float4 *>(&s_B[0][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[0][n0 + 4]);
     float4 c0 = *reinterpret_cast<const float4 *>(&s_C[0][n0]), c1 = *reinterpret_cast<const float4 *>(&s_C[0][n0 + 4]);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
       }
       s_y[w][tl][lane] = y.x + y.y;
       if (tl == SUB - 1 && p.ckpt && dok)   // state entering the second half of the chunk
-        ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 1, NW, w, Dm, d), x);
+        ckpt_put<NW>(p.ckpt, b, nchunks, c, 1, w, Dm, d, x);
       __builtin_amdgcn_sched_barrier(0);
       b0 = nb0; b1 = nb1; c0 = nc0; c1 = nc1; dt = ndt; du = ndu;
     }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) 
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
           const f2 (&xs)[NS / 2] = *reinterpret_cast<const f2 (*)[NS / 2]>(&x[w * (NS / 2)]);
-          ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, half, NW, w, Dm, d), xs);
+          ckpt_put<NW>(p.ckpt, b, nchunks, c, half, w, Dm, d, xs);
         }
       }
       float dtv = cdt[k] + bias;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void scan_fwd_ws_kernel(const ScanPa
         ndt = s_dt[slot][k + 1][lane];
         ndu = s_du[slot][k + 1][lane];
       }
-      if ((k == 0 || k == SUB) && p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, k == 0 ? 0 : 1, NW, w, Dm, d), x);
+      if ((k == 0 || k == SUB) && p.ckpt && dok) ckpt_put<NW>(p.ckpt, b, nchunks, c, k == 0 ? 0 : 1, w, Dm, d, x);
       const f2 bv[NS / 2] = {f2{b0.x, b0.y}, f2{b0.z, b0.w}, f2{b1.x, b1.y}, f2{b1.z, b1.w}};
       const f2 cv[NS / 2] = {f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, f2{c1.z, c1.w}};
       f2 y = {0.f, 0.f};
@@ -783,7 +783,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_fwd_ws3_kernel(const ScanP
     __syncthreads();
     if (i >= nu) break;                           // (the drain interval belongs to the finisher)
     const int slot = i & 1;
-    if (p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, i >> 1, i & 1, NW, w, Dm, d), x);
+    if (p.ckpt && dok) ckpt_put<NW>(p.ckpt, b, nchunks, i >> 1, i & 1, w, Dm, d, x);
     float4 b0 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][n0]), b1 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][n0 + 4]);
     float4 c0 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][NP + n0]), c1 = *reinterpret_cast<const float4 *>(&s_bc[slot][0][NP + n0 + 4]);
     float2 op = s_op[slot][0][lane];
@@ -947,7 +947,9 @@ extern "C" int cum_scan_chunk(void) { return TB; }
 extern "C" int64_t cum_scan_ckpt_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len) {
   const int64_t nchunks = (len + TB - 1) / TB;
   const int64_t nw = (dstate + NS - 1) / NS;
-  return 2 * (int64_t)batch * nchunks * nw * dim * NS;   // the state entering each 8-step half of every chunk
+  // the state entering each 8-step half of every chunk; d_state > 16: whole 64-channel groups (scan_common.h, wide layout)
+  const int64_t chan = ckpt_is_wide((int)nw) ? (int64_t)((dim + 63) / 64) * 64 : dim;
+  return 2 * (int64_t)batch * nchunks * nw * chan * NS;
 }
 
 extern "C" int64_t cum_scan_fwd_workspace_elems(int32_t batch, int32_t dim, int32_t dstate, int32_t len) {

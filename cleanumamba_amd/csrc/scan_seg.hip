@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NW * 64) void scan_seg_kernel(const ScanParams p) {
       }
     }
     if (c + 1 < c_hi) load_rows(t0 + TB);
-    if (OUT && p.ckpt && dok) ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 0, NW, w, Dm, d), x);
+    if (OUT && p.ckpt && dok) ckpt_put<NW>(p.ckpt, b, nchunks, c, 0, w, Dm, d, x);
     __syncthreads();
     float4 b0 = *reinterpret_cast<const float4 *>(&s_B[0][n0]), b1 = *reinterpret_cast<const float4 *>(&s_B[0][n0 + 4]);
     float4 c0 = b0, c1 = b1;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void scan_seg_kernel(const ScanParams p) {
       if constexpr (OUT) {
         s_y[w][tl][lane] = y.x + y.y;
         if (tl == SUB - 1 && p.ckpt && dok)   // state entering the second half of the chunk
-          ckpt_store(p.ckpt, ckpt_slot(b, nchunks, c, 1, NW, w, Dm, d), x);
+          ckpt_put<NW>(p.ckpt, b, nchunks, c, 1, w, Dm, d, x);
       } else {
         dsum += dt;
       }

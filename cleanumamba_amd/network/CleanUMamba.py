@@ -669,7 +669,9 @@ class CleanUMamba(nn.Module):
         if plist is None or age >= 64:              # re-walk now and then: foreign code may swap Parameter objects
             plist, age = list(self.parameters()), 0
         self.__dict__["_plist"] = (plist, age + 1)
-        return sum(p._version for p in plist)
+        # ... and the one non-parameter input of the compiled hop plan: a plan made with normalize_input off has no
+        # running-std op, and was silently reused after the flag was switched on (found by the config-5-size test)
+        return (sum(p._version for p in plist), bool(self.normalize_input))
 
     def _hop(self, frame):
         """Eager first hop (it creates the state buffers), hipGraph replay afterwards."""

@@ -31,6 +31,7 @@ def test_size_queries_and_argument_errors():
     # two saved states (one per 8-step half) per 16-step chunk, states padded to whole 8-state wave slices
     assert lib.cum_scan_ckpt_elems(2, 8, 8, 33) == 2 * 2 * 3 * 8 * 8
     assert lib.cum_scan_ckpt_elems(1, 5, 13, 16) == 2 * 1 * 1 * 2 * 5 * 8
+    assert lib.cum_scan_ckpt_elems(1, 70, 64, 16) == 2 * 1 * 1 * 8 * 128 * 8      # d_state > 16: whole 64-channel groups
     assert lib.cum_scan_bwd_workspace_elems(2, 100, 13, 7) == 2 * 100 * 13 + 2 * 2 * 100 + 2 * 2 * 2 * 7 * 13
     assert lib.cum_conv_bwd_workspace_elems(2, 10, 33, 4) == 2 * 3 * 5 * 10
     # time-parallel forward scan: a workspace is asked for only where the sequential grid leaves the chip mostly idle

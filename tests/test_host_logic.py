@@ -323,3 +323,18 @@ def test_loss_terms_combination_matches_the_chain_of_scalar_ops():
     (3.0 * loss).backward()
     for a, b in zip(vals, ref_vals):
         assert torch.allclose(a.grad, b.grad, rtol=1e-6)
+
+
+def test_xor_scatter_lane_algebra_of_the_backward_scan():
+    """csrc/scan_bwd.hip keeps state k ^ h(lane) in register slot k so that one DPP add eliminates one register of the
+    per-step dB / dC reduce-scatter; tools/xor_scatter_model.py restates the exchanges (quad_perm, row_half_mirror,
+    row_ror:8, permlane32/16 swaps), the owner lane of every (array, state, step) total and the four staged B / C
+    variants in numpy and checks them against plain sums."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("xor_scatter_model", os.path.join(root, "tools", "xor_scatter_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for seed in range(3):
+        assert m.check(seed)

@@ -74,6 +74,13 @@ TN_TRAFFIC_BYTES = 409.6e6
 SCAN_ISSUE_ROOF = 8.6e12     # state updates / s: tools/clock_probe.hip on MI355X (profiles/r02_clock_probe.txt: 8.56-8.89 T/s
                              # at 6-8 waves per SIMD, clock 2.30-2.36 GHz = 3.6-3.7 updates per clock and SIMD)
 
+# the same for the BACKWARD: the bare arithmetic of one 8-step half of scan_bwd_kernel on registers only (7 recomputed
+# forward steps + 8 reverse steps + the 16 products and 16 DPP adds of the per-step dB / dC reduce + the row-level swaps; one
+# v_exp_f32 per update), two waves per SIMD (the kernel's 256-register occupancy) on every SIMD: tools/bwd_issue_probe.hip,
+# profiles/r06_bwd_issue_probe.txt: 3.33-3.34 T state updates/s at 2.38 GHz (one wave per SIMD: 1.69).  What lies between
+# this and the kernel: LDS operand traffic, phase A / C, barriers, loads.
+SCAN_BWD_ISSUE_ROOF = 3.34e12
+
 B16 = 16
 ENC_T = [160254, 80126, 40062, 20030, 10014, 5006, 2502, 1250, 624]
 ENC_C = [1, 64, 128, 256, 512, 768, 768, 768, 768]
@@ -242,7 +249,8 @@ def _scan_case(dev, bsz, dim, Ns, L, io, backward):
 def scan_rows(dev, dt):
     """The north_star kernel against both of its roofs.  Algorithmic bytes: SURVEY.md 8(d), B*T*(s*4*D + 4*2*N) forward
     (u, delta, z, out in the I/O type of s bytes; B, C in f32), B*T*(s*7*D + 4*4*N) backward.  State updates: B*T*D*N.
-    HBM roof 8 TB/s; issue roof = SCAN_ISSUE_ROOF, the measured rate of the bare update loop (one v_exp_f32 per update).
+    HBM roof 8 TB/s; issue roof = SCAN_ISSUE_ROOF, the measured rate of the bare update loop (one v_exp_f32 per update);
+    backward rows: SCAN_BWD_ISSUE_ROOF, the measured rate of the backward's bare arithmetic (tools/bwd_issue_probe.hip).
     At d_state 64 the issue roof binds; at d_state <= 16 the HBM roof does."""
     issue_roof = SCAN_ISSUE_ROOF
     cases = [("E8 bottleneck B=16 D=2048 N=64 L=624", 16, 2048, 64, 624, dt, True),
@@ -272,8 +280,9 @@ def scan_rows(dev, dt):
             rows.append({"kernel": f"selective scan {kind}, {name}, {_name(io)} I/O", "launch_ms": round(ms, 4),
                          "algorithmic_bytes": byt, "achieved_GBps": round(gbs, 1),
                          "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "state_updates_T_per_s": round(ups / 1e12, 3),
-                         "issue_roof_frac": round(ups / issue_roof, 4) if kind == "fwd" else None,
-                         "binding_roof": "hbm" if byt / (HBM_PEAK_GBS * 1e9) > upd / issue_roof else "v_exp_f32 issue"})
+                         "issue_roof_frac": round(ups / (issue_roof if kind == "fwd" else SCAN_BWD_ISSUE_ROOF), 4),
+                         "binding_roof": ("hbm" if byt / (HBM_PEAK_GBS * 1e9) > upd / (issue_roof if kind == "fwd" else SCAN_BWD_ISSUE_ROOF)
+                                          else ("v_exp_f32 issue" if kind == "fwd" else "VALU issue (recompute + reverse step + reduce)"))})
             if kind == "bwd" and _scan_case.sequential_bwd_ms is not None:
                 sb = _scan_case.sequential_bwd_ms
                 rows[-1].update(path="time-parallel (segments + carry, csrc/scan_bwd_small.hip PASS 1 / 0)",
@@ -503,18 +512,20 @@ def _free_port():
 
 def _visible_devices(env=None):
     """How the device masks re-number the GPUs: None = no mask (HIP order = bus order), a list of physical indices when ONE of
-    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES is set to plain integers, "unknown" otherwise (UUID
-    tokens, or a ROCr mask stacked under a HIP one)."""
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES are plain integers (a HIP mask on top of a ROCr mask
+    indexes what the ROCr mask left), "unknown" otherwise (UUID tokens, an index out of range)."""
     env = os.environ if env is None else env
     hipm = env.get("HIP_VISIBLE_DEVICES", env.get("CUDA_VISIBLE_DEVICES"))
     rocr = env.get("ROCR_VISIBLE_DEVICES")
     if hipm is None and rocr is None:
         return None
-    if hipm is not None and rocr is not None:
-        return "unknown"
     try:
-        return [int(t) for t in (hipm if hipm is not None else rocr).split(",") if t.strip() != ""]
-    except ValueError:
+        parse = lambda m: [int(t) for t in m.split(",") if t.strip() != ""]
+        if hipm is not None and rocr is not None:      # the HIP mask indexes what the ROCr mask left visible
+            r = parse(rocr)
+            return [r[i] for i in parse(hipm)]
+        return parse(hipm if hipm is not None else rocr)
+    except (ValueError, IndexError):
         return "unknown"
 
 
@@ -579,7 +590,10 @@ def launch_ranks(args):
     n = args.gpus
     env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))     # cores this process may use
+    # cores this process may use, shared by the ranks -- and no more than 32 OpenMP threads per rank: the host side of a
+    # step is thousands of tiny CPU ops, each a barrier over the whole team (a 128-thread team on a shared host took more
+    # than eight minutes to construct the model: the two-rank self-test of round 6)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(32, len(os.sched_getaffinity(0)) // n))))
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     outs, logs, procs = [], [], []
     for r in range(n):
@@ -638,7 +652,7 @@ def main():
         try:
             cpus = _cpus_of_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), info=pin_info)
             os.sched_setaffinity(0, cpus)
-            torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))      # no more threads than cores
+            torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus), 32)))  # no more threads than cores, <= 32
         except (OSError, ValueError):
             cpus = None
     assert torch.cuda.is_available(), "bench.py needs a GPU"

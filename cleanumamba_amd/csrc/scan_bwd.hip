@@ -154,13 +154,16 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   const int nvalid = FULL ? NS : ((N - n0) < NS ? (N - n0) : NS);
   const int nchunks = p.nchunks;
   const int hm = lane_hmask(lane);       // slot k of this lane holds state n0 + (k ^ hm)
+#ifdef CUM_BWD_PRIO   // experiment: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, item 4)
+  if (NW == 8 && w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
   f2 Ap[NP2], dAacc[NP2], dxc[NP2];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     const int j = k ^ hm;
     const int jj = j < nvalid ? j : nvalid - 1;
-    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    const float a = scan_A(p, (int64_t)dc * N + n0 + jj) * kLog2e;
     Ap[k / 2][k % 2] = (j < nvalid) ? a : 0.f;
     dAacc[k / 2][k % 2] = 0.f;
     dxc[k / 2][k % 2] = 0.f;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanParams p) {
   const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
   const int o_sl = (int)p.s.o_sl;
   const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
-  const int softplus = p.s.delta_softplus;
+  const int softplus = p.s.delta_softplus & kScanSoftplus;
 
   // dB / dC slab stores (see the header): this lane's array, state and step offset inside a group of four steps
   const int st_state = lane_hmask(lane & 7);
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256) void scan_bwd_finalize_rows_kernel(const ScanP
     float v = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0 && dst) *dst = v;
+    if (lane == 0 && dst) *dst = (o < nA && (p.s.delta_softplus & kScanAIsLog)) ? v * scan_A(p, o) : v;   // dA_log = dA * A
   }
 }
 
@@ -572,7 +575,7 @@ __global__ void scan_bwd_finalize_kernel(const ScanParams p, float *dA, float *d
     } else if (i < nA) {
       float s = 0.f;
       for (int64_t b = 0; b < Bs; ++b) s += p.ws_dA[b * nA + i];
-      dA[i] = s;
+      dA[i] = (p.s.delta_softplus & kScanAIsLog) ? s * scan_A(p, i) : s;      // A given as A_log: dA_log = dA * A
     } else if (i < nA + Dm) {
       const int64_t d = i - nA;
       float s = 0.f;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_bwd_ws_kernel(const ScanPa
     const int o_sl = (int)p.s.o_sl;
     const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
     const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
-    const int softplus = p.s.delta_softplus;
+    const int softplus = p.s.delta_softplus & kScanSoftplus;
 
     float ru[SUB], rdl[SUB], rz[SUB], rdo[SUB], rbc[BCE];
     auto load_rows = [&](int h) {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_bwd_ws_kernel(const ScanPa
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int jj = j < nvalid ? j : nvalid - 1;
-    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    const float a = scan_A(p, (int64_t)dc * N + n0 + jj) * kLog2e;
     Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
     dAacc[j / 2][j % 2] = 0.f;
     dxc[j / 2][j % 2] = 0.f;

@@ -99,6 +99,16 @@ __device__ __forceinline__ int64_t carry_slot(int b, int nseg, int seg, int NW, 
   return ((((int64_t)b * nseg + seg) * NW + w) * Dm + d) * NS;
 }
 
+// cum_scan_shape::delta_softplus is a flag word: bit 0 = softplus on delta + bias; bit 1 (CUM_SCAN_A_IS_LOG) = the `A`
+// argument holds A_log and the op uses A = -exp(A_log) (upstream Mamba.forward's `A = -torch.exp(self.A_log.float())`,
+// src/network/S4/MambaS4.py mirror); the backward then returns dA_log = dA * A.  One expf per (channel, state) at kernel
+// start instead of two elementwise launches per block and step (and a third in the backward).
+constexpr int kScanSoftplus = 1, kScanAIsLog = 2;
+__device__ __forceinline__ float scan_A(const ScanParams &p, int64_t idx) {
+  const float a = p.A[idx];
+  return (p.s.delta_softplus & kScanAIsLog) ? -expf(a) : a;
+}
+
 typedef const float __attribute__((address_space(4))) *cfp;
 
 // B_t or C_t slice of this wave (wave-uniform address -> s_load_dwordx8).

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int jj = j < nvalid ? j : nvalid - 1;
-    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    const float a = scan_A(p, (int64_t)dc * N + n0 + jj) * kLog2e;
     Ap[j] = (j < nvalid) ? a : 0.f;
     x[j] = 0.f;
   }
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanParams p) {
   const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
   const int o_sl = (int)p.s.o_sl;
   const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
-  const int softplus = p.s.delta_softplus;
+  const int softplus = p.s.delta_softplus & kScanSoftplus;
 
   float ru[K], rdt[K], rz[K];
   auto load_rows = [&](int t0) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int jj = j < nvalid ? j : nvalid - 1;
-    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    const float a = scan_A(p, (int64_t)dc * N + n0 + jj) * kLog2e;
     Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
     x[j / 2][j % 2] = 0.f;
   }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_lds_kernel(const ScanParams 
   const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
   const int o_sl = (int)p.s.o_sl;
   const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
-  const int softplus = p.s.delta_softplus;
+  const int softplus = p.s.delta_softplus & kScanSoftplus;
 
   float ru[K], rdt[K], rz[K], rb[BCK], rc[BCK];
   auto load_rows = [&](int t0) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) 
 #pragma unroll
   for (int j = 0; j < NPD; ++j) {
     const int jj = j < N ? j : N - 1;
-    const float a = p.A[(int64_t)dc * N + jj] * kLog2e;
+    const float a = scan_A(p, (int64_t)dc * N + jj) * kLog2e;
     Ap[j / 2][j % 2] = j < N ? a : 0.f;
     x[j / 2][j % 2] = 0.f;
   }
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) 
   const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
   const int o_sl = (int)p.s.o_sl;
   const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
-  const int softplus = p.s.delta_softplus;
+  const int softplus = p.s.delta_softplus & kScanSoftplus;
   const int nchunks = p.nchunks;
 
   float ru[PB], rdt[PB], rz[PB], rbc[BCE];
@@ -496,7 +496,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void scan_fwd_ws_kernel(const ScanPa
     const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
     const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
     const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
-    const int softplus = p.s.delta_softplus;
+    const int softplus = p.s.delta_softplus & kScanSoftplus;
     float ru[PB], rdt[PB], rz[PB], rbc[BCE];
     auto load_block = [&](int t0) {
       const bool FULL = t0 + PB <= L;      // wave-uniform: the clamps below are scalar selects
@@ -558,7 +558,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void scan_fwd_ws_kernel(const ScanPa
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int jj = j < nvalid ? j : nvalid - 1;
-    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    const float a = scan_A(p, (int64_t)dc * N + n0 + jj) * kLog2e;
     Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
     x[j / 2][j % 2] = 0.f;
   }
@@ -691,7 +691,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_fwd_ws3_kernel(const ScanP
     const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
     const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
     const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
-    const int softplus = p.s.delta_softplus;
+    const int softplus = p.s.delta_softplus & kScanSoftplus;
     float ru[SUB], rdt[SUB], rz[SUB], rbc[BCE];
     auto load_rows = [&](int h) {
       const int t0 = h * SUB;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void scan_fwd_ws3_kernel(const ScanP
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int jj = j < nvalid ? j : nvalid - 1;
-    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    const float a = scan_A(p, (int64_t)dc * N + n0 + jj) * kLog2e;
     Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
     x[j / 2][j % 2] = 0.f;
   }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NW * 64) void scan_seg_kernel(const ScanParams p) {
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     const int jj = j < nvalid ? j : nvalid - 1;
-    const float a = p.A[(int64_t)dc * N + n0 + jj] * kLog2e;
+    const float a = scan_A(p, (int64_t)dc * N + n0 + jj) * kLog2e;
     Ap[j / 2][j % 2] = (j < nvalid) ? a : 0.f;
     x[j / 2][j % 2] = 0.f;
   }
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NW * 64) void scan_seg_kernel(const ScanParams p) {
   const int u_sl = (int)p.s.u_sl, dt_sl = (int)p.s.dt_sl, z_sl = has_z ? (int)p.s.z_sl : (int)p.s.u_sl;
   const int o_sl = (int)p.s.o_sl;
   const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
-  const int softplus = p.s.delta_softplus;
+  const int softplus = p.s.delta_softplus & kScanSoftplus;
 
   float ru[K], rdt[K], rz[OUT ? K : 1], rb[BCK], rc[OUT ? BCK : 1];
   auto load_rows = [&](int t0) {

@@ -154,7 +154,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.cum_abi_version() != 14:
+        if L.cum_abi_version() != 15:
             raise RuntimeError("libcleanumamba_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -133,7 +133,9 @@ class _MambaInnerFn(torch.autograd.Function):
         dt = cs.proj_fwd(x_dbl[:, :R], dtw, cd)                                        # (M, D); the bias goes in the scan
         bc = x_dbl[:, R:].float().view(Bn, L, 2 * N)                                   # B | C in f32, as the scan reads them
         Bm, Cm = bc[..., :N].transpose(1, 2), bc[..., N:].transpose(1, 2)
-        A = -torch.exp(A_log.detach().float())
+        # A_log goes to the kernels as it is (flag CUM_SCAN_A_IS_LOG: they form -exp(A_log) themselves and the backward
+        # returns dA_log): no exp / neg launches here, no dA * A launch in the backward
+        A = A_log.detach().float().contiguous()
         Df, bias = Dp.detach().float().contiguous(), dt_bias.detach().float().contiguous()
         dtT = dt.view(Bn, L, Dn).transpose(1, 2)
         y = torch.empty(Bn, L, Dn, dtype=cd, device=dev)
@@ -142,6 +144,7 @@ class _MambaInnerFn(torch.autograd.Function):
         if save:
             ckpt = torch.empty(max(lib.cum_scan_ckpt_elems(Bn, Dn, N, L), 1), dtype=torch.float32, device=dev)
         ss = ssi._shape(xcT, dtT, zv, yT, Bm, Cm, True)
+        ss.delta_softplus |= ssi.A_IS_LOG
         # y before the gate, kept for the backward where the forward kernel can (the E6 / E8 bottleneck): the backward scan
         # then reads it instead of rebuilding it
         ypre = torch.empty_like(y) if (save and ssi.keeps_y(ss, ssi.TIME_PARALLEL)) else None
@@ -189,9 +192,9 @@ class _MambaInnerFn(torch.autograd.Function):
                 return flat.grad[offs[i]:offs[i] + like.numel()].view(like.shape)
             return torch.empty(like.shape, dtype=torch.float32, device=dev)
         dcw, dcb, dbias, dA_log, dD = slot(0, w2), slot(1, cb), slot(2, bias), slot(3, A), slot(4, Df)
-        dA = torch.empty_like(A)
         bwd, ws = ssi.scan_backward_entry(Bn, Dn, N, L, dev)
         su = ssi._shape(xcT, dtT, zv, dyT, Bm, Cm, True)                  # o_* strides := dout's
+        su.delta_softplus |= ssi.A_IS_LOG                                 # `A` is A_log: the kernel returns dA_log
         gs = hip.ScanGradStrides()
         gs.du_sb, gs.du_sd, gs.du_sl = duT.stride()
         gs.dd_sb, gs.dd_sd, gs.dd_sl = ddT.stride()
@@ -200,10 +203,9 @@ class _MambaInnerFn(torch.autograd.Function):
             hip.check(bwd(ctypes.byref(su), ctypes.byref(gs), hip.ptr(xcT), hip.ptr(dtT), hip.ptr(A),
                           hip.ptr(Bm), hip.ptr(Cm), hip.ptr(Df), hip.ptr(zv), hip.ptr(bias),
                           hip.ptr(dyT), hip.ptr(ypre.transpose(1, 2) if ypre is not None else None),
-                          hip.ptr(ckpt), hip.ptr(duT), hip.ptr(ddT), hip.ptr(dA),
+                          hip.ptr(ckpt), hip.ptr(duT), hip.ptr(ddT), hip.ptr(dA_log),
                           hip.ptr(dBC[0]), hip.ptr(dBC[1]), hip.ptr(dD), hip.ptr(dzT), hip.ptr(dbias),
                           hip.ptr(ws), hip.stream_ptr()))
-        torch.mul(dA, A, out=dA_log)                                       # A = -exp(A_log): dA / dA_log = A
         # d(x_dbl) = (d dt | dB | dC): one buffer, rows readable 64 columns past their end (zero weight columns there)
         pad = cs.rup(S, cs.bk_of(cd)) - S
         dxd_flat = torch.empty(M * S + pad, dtype=cd, device=dev)

@@ -38,6 +38,9 @@ def _empty_like_layout(t):
     return torch.empty(t.shape, dtype=t.dtype, device=t.device)
 
 
+A_IS_LOG = 2       # cum_scan_shape.delta_softplus, bit 1 (include/cleanumamba_hip.h): `A` holds A_log
+
+
 def _shape(u, delta, z, out, Bm, Cm, softplus):
     s = hip.ScanShape()
     s.batch, s.dim, s.len = u.shape
@@ -49,7 +52,8 @@ def _shape(u, delta, z, out, Bm, Cm, softplus):
     s.o_sb, s.o_sd, s.o_sl = out.stride()
     s.B_sb, s.B_sn, s.B_sl = Bm.stride()
     s.C_sb, s.C_sn, s.C_sl = Cm.stride()
-    s.delta_softplus = int(bool(softplus))
+    # flag word (include/cleanumamba_hip.h): a bool is bit 0; an int is taken as it is (softplus | A_IS_LOG)
+    s.delta_softplus = int(softplus) if type(softplus) is int else int(bool(softplus))
     s.io_dtype = hip.dtype_code(u.dtype)
     return s
 
@@ -123,7 +127,7 @@ class SelectiveScanFn(torch.autograd.Function):
         if need_grad and z is not None and keeps_y(s, TIME_PARALLEL):
             y_pre = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device)
         scan_forward(s, u, delta, A, Bm, Cm, D, z, delta_bias, out, last, ckpt, TIME_PARALLEL, y_pre=y_pre)
-        ctx.delta_softplus = bool(delta_softplus)
+        ctx.delta_softplus = delta_softplus if type(delta_softplus) is int else bool(delta_softplus)
         ctx.has_z = z is not None
         ctx.b4 = (B.dim() == 4, C.dim() == 4)
         ctx.save_for_backward(u, delta, A, Bm, Cm, D, z, delta_bias, ckpt, y_pre)

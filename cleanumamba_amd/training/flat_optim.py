@@ -83,7 +83,12 @@ class FlatParams:
         # fresh[i]: nothing has been accumulated into gradient i since zero_grad() -- a producer may then WRITE its
         # result into the view (GradSink below) instead of handing it to autograd's AccumulateGrad (read-read-write)
         self.fresh = [False] * len(self.params)
+        # Lazy zeroing (see zero_grad): indices whose gradient memory still holds the PREVIOUS cycle's values
+        self.stale = set()
+        self.sunk_now, self.sunk_last = set(), None
         ref = weakref.ref(self)
+        for i, p in enumerate(self.params):
+            p.register_hook(self._pre_accumulate(ref, i))
         ptrs = [p.data_ptr() for p in self.params]
         for ptr in ptrs:
             _SINKS[ptr] = ref
@@ -117,10 +122,56 @@ class FlatParams:
                     g.copy_(p.grad)
                 p.grad = g
 
+    @staticmethod
+    def _pre_accumulate(ref, i):
+        """Tensor hook of parameter i: autograd is about to ADD a gradient into its view.  If that view was left un-zeroed
+        by a lazy zero_grad() it is cleared first (sink-written gradients never come through here: their producers return
+        None to autograd)."""
+        def hook(grad):
+            flat = ref()
+            if flat is not None and i in flat.stale:
+                flat.stale.discard(i)
+                flat.grad_views[i].zero_()
+            return grad
+        return hook
+
+    # The whole-buffer memset (165 MB for the 41.4 M model, every step) is only needed by gradients that autograd
+    # ACCUMULATES into their views.  A gradient that a kernel WRITES through the sink below needs no zero underneath it, and
+    # in a TrainStep every gradient is such a write.  zero_grad() therefore clears only the views that were not sink-written
+    # in the previous cycle and marks the others stale; a stale view is cleared the moment something else than a sink
+    # write is about to touch it (the hook above) or, if nothing touches it at all, in settle() before anybody reads the
+    # buffer (optimizer, exchange).  The alignment padding between parameters is written by nobody and stays zero.
+    LAZY_ZERO = True
+    # set by GradBuckets when a gradient exchange reads whole bucket slices at the end of the backward (before settle()):
+    # untouched stale views would be exchanged as they are, so every view is zeroed up front there
+    exchange_reads_buffer = False
+
     def zero_grad(self):
-        self.grad.zero_()
+        last = self.sunk_last
+        self.sunk_last, self.sunk_now = None, set()
+        if self.LAZY_ZERO and last and not self.exchange_reads_buffer:
+            self.stale = set(last)
+            start = None
+            for i in range(len(self.params) + 1):          # contiguous runs of the views that do need zeros
+                need = i < len(self.params) and i not in last
+                if need and start is None:
+                    start = self.offsets[i]
+                if not need and start is not None:
+                    self.grad[start:(self.offsets[i] if i < len(self.params) else self.numel)].zero_()
+                    start = None
+        else:
+            self.stale = set()
+            self.grad.zero_()
         self.attach_grads()
         self.fresh = [True] * len(self.params)
+
+    def settle(self):
+        """End of an accumulation cycle, before the flat gradient is read: views still stale (no gradient reached them in
+        this cycle) become zeros; what was sink-written in this cycle may stay un-zeroed at the next zero_grad()."""
+        for i in sorted(self.stale):
+            self.grad_views[i].zero_()
+        self.stale = set()
+        self.sunk_last = set(self.sunk_now)
 
     # ---- gradient sink: kernels write parameter gradients straight into the flat buffer
     def slot(self, param):
@@ -139,6 +190,8 @@ class FlatParams:
         """The gradients of these parameters now sit in their views (they are no longer fresh); tell the exchange."""
         for i in indices:
             self.fresh[i] = False
+            self.stale.discard(i)
+            self.sunk_now.add(i)
         if self.on_write is not None:
             self.on_write([self.params[i] for i in indices])
 
@@ -215,6 +268,7 @@ class FlatAdam:
             self.write_lr()
         lib, f = hip.lib(), self.flat
         f.require_intact()
+        f.settle()
         st = hip.stream_ptr()
         with torch.cuda.device(f.data.device):
             hip.check(lib.cum_optim_sumsq(hip.ptr(f.grad), f.numel, hip.ptr(self.partials), st))

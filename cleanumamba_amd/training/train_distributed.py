@@ -80,6 +80,7 @@ class GradBuckets:
         # producers that can hand over part of their gradients before they are done with all of them do so when there is
         # an exchange to overlap with (network/convstack.py EncoderStack.backward)
         self.flat.early_announce = self.exchanging
+        self.flat.exchange_reads_buffer = self.exchanging        # (no lazy zero_grad under an exchange: flat_optim.py)
 
     def _written(self, params):
         """Gradients a kernel wrote straight into the flat buffer (FlatParams.wrote): same bookkeeping as the hook."""

@@ -41,7 +41,7 @@ extern "C" {
 #define CUM_ELAUNCH (-2)     /* hipLaunch failed */
 #define CUM_EWORKSPACE (-3)  /* workspace too small */
 
-#define CUM_ABI_VERSION 14
+#define CUM_ABI_VERSION 15
 
 int cum_abi_version(void);
 const char *cum_last_error(void);
@@ -59,6 +59,8 @@ int cum_scan_chunk(void);
  * receives the state entering every half of every chunk of cum_scan_chunk() steps
  * (opaque layout, 16-byte aligned); the backward consumes it.  last_state: NULL or (batch, dim, dstate) contiguous.
  */
+#define CUM_SCAN_SOFTPLUS 1
+#define CUM_SCAN_A_IS_LOG 2
 typedef struct {
   int32_t batch, dim, dstate, len;
   int64_t u_sb, u_sd, u_sl;          /* u strides: batch, dim, len */
@@ -67,7 +69,10 @@ typedef struct {
   int64_t o_sb, o_sd, o_sl;          /* out */
   int64_t B_sb, B_sn, B_sl;          /* Bm */
   int64_t C_sb, C_sn, C_sl;          /* Cm */
-  int32_t delta_softplus;            /* apply softplus (threshold 20) to delta + bias */
+  int32_t delta_softplus;            /* flag word.  bit 0: apply softplus (threshold 20) to delta + bias.
+                                        bit 1 (CUM_SCAN_A_IS_LOG = 2): `A` holds A_log -- the op uses A = -exp(A_log), as
+                                        upstream Mamba.forward forms it from its parameter, and the backward returns
+                                        dA_log = dA * A in `dA` (no elementwise launches around the op) */
   int32_t io_dtype;                  /* CUM_F32 / CUM_BF16 / CUM_F16: element type of u, delta, z, out and of dout, du,
                                         ddelta, dz (what autocast hands over); all arithmetic and every other
                                         tensor stay fp32 */

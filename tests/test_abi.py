@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
         assert s in hip.SIGNATURES, f"{s} has no ctypes signature"
     assert set(hip.SIGNATURES) <= set(syms)
-    assert lib.cum_abi_version() == 14
+    assert lib.cum_abi_version() == 15
     assert lib.cum_scan_chunk() == 16
 
 

@@ -201,14 +201,15 @@ def test_bench_pins_ranks_to_the_numa_node_of_their_gpu(tmp_path):
     got = [bench._cpus_of_rank(r, 2, str(sysr), allowed, visible=[3, 0], info=info) for r in range(2)]
     assert got[0] == list(range(8, 16)) + list(range(24, 32)) and got[1] == list(range(0, 8)) + list(range(16, 24))
     assert info["numa_node"] == 0 and info["bdf"] == "0000:10:00.0" and "mask" in info["how"]
-    # a mask that cannot be mapped (UUIDs, or two stacked masks): the even split, and the line says so
+    # a mask that cannot be mapped (UUIDs, an index beyond the lower mask): the even split, and the line says so
     got = [bench._cpus_of_rank(r, 4, str(sysr), allowed, visible="unknown", info=info) for r in range(4)]
     assert got == [list(range(8 * r, 8 * r + 8)) for r in range(4)] and info["how"].startswith("even split")
     assert bench._visible_devices({}) is None
     assert bench._visible_devices({"HIP_VISIBLE_DEVICES": "2,3"}) == [2, 3]
     assert bench._visible_devices({"ROCR_VISIBLE_DEVICES": "1"}) == [1]
     assert bench._visible_devices({"HIP_VISIBLE_DEVICES": "GPU-abcdef"}) == "unknown"
-    assert bench._visible_devices({"HIP_VISIBLE_DEVICES": "0", "ROCR_VISIBLE_DEVICES": "1,2"}) == "unknown"
+    assert bench._visible_devices({"HIP_VISIBLE_DEVICES": "1,0", "ROCR_VISIBLE_DEVICES": "4,6"}) == [6, 4]
+    assert bench._visible_devices({"HIP_VISIBLE_DEVICES": "2", "ROCR_VISIBLE_DEVICES": "4,6"}) == "unknown"
     # no sysfs: contiguous even split of what the process may use
     got = [bench._cpus_of_rank(r, 4, str(tmp_path / "nothing"), set(range(8))) for r in range(4)]
     assert got == [[0, 1], [2, 3], [4, 5], [6, 7]]
@@ -338,3 +339,47 @@ def test_xor_scatter_lane_algebra_of_the_backward_scan():
     spec.loader.exec_module(m)
     for seed in range(3):
         assert m.check(seed)
+
+
+def test_lazy_zero_grad_never_leaves_a_stale_gradient():
+    """FlatParams.zero_grad() skips the memset under gradients that kernels WRITE through the sink; whatever else happens
+    to such a view in the next cycle -- autograd accumulating into it, nothing touching it at all -- must see zeros."""
+    import torch.nn as nn
+    from cleanumamba_amd.training import flat_optim as fo
+    m = nn.Sequential(nn.Linear(4, 4), nn.Linear(4, 2))
+    f = fo.FlatParams(m)
+    params = list(m.parameters())
+    f.armed = True
+    f.zero_grad()                                    # first cycle: everything zeroed, everything written by "kernels"
+    for p in params:
+        i, o = f.slot(p)
+        f.grad[o:o + p.numel()] = 7.0
+        f.wrote([i])
+    f.settle()
+    assert float(f.grad.sum()) == 7.0 * sum(p.numel() for p in params)
+    f.zero_grad()                                    # lazy: nothing cleared yet, all four views stale
+    assert len(f.stale) == 4 and float(f.grad.abs().sum()) > 0
+    # parameter 0: sink-written again; parameter 1: autograd accumulates (the hook clears the view first);
+    # parameters 2, 3: nothing reaches them -> zero at settle()
+    i, o = f.slot(params[0])
+    f.grad[o:o + params[0].numel()] = 1.0
+    f.wrote([i])
+    f.armed = False
+    (params[1] * 2.0).sum().backward()
+    f.settle()
+    assert float(params[0].grad.sum()) == params[0].numel()
+    assert torch.equal(params[1].grad, torch.full_like(params[1], 2.0))
+    assert float(params[2].grad.abs().sum()) == 0 and float(params[3].grad.abs().sum()) == 0
+    # the next zero_grad() may skip only what was sink-written in THIS cycle (parameter 0)
+    f.zero_grad()
+    assert f.stale == {f.index[id(params[0])]}
+    assert float(params[1].grad.abs().sum()) == 0
+    # under a gradient exchange (whole bucket slices are read before settle) nothing is left stale
+    f.settle()
+    f.exchange_reads_buffer = True
+    f.armed = True
+    i, o = f.slot(params[0])
+    f.wrote([i])
+    f.settle()
+    f.zero_grad()
+    assert not f.stale and float(f.grad.abs().sum()) == 0

@@ -523,3 +523,31 @@ def test_mamba_inner_single_node_equals_separate_ops(cuda, monkeypatch, dtype, t
     assert rel_l2(res[True][1], res[False][1]) < 3 * tol
     for k in res[True][2]:
         assert rel_l2(res[True][2][k], res[False][2][k]) < 3 * tol, k
+
+
+@pytest.mark.parametrize("shape", [(2, 130, 64, 50), (2, 70, 20, 47), (3, 130, 16, 41), (2, 48, 8, 100), (1, 2048, 64, 624),
+                                   (1, 128, 16, 624)])
+def test_scan_with_a_log_flag_equals_minus_exp_outside(cuda, shape):
+    """cum_scan_shape.delta_softplus bit 1 (CUM_SCAN_A_IS_LOG): `A` holds A_log, the kernels form A = -exp(A_log) (upstream
+    Mamba.forward: `A = -torch.exp(self.A_log.float())`) and the backward returns dA_log = dA * A -- against the same op fed
+    -exp(A_log) with torch's chain rule around it; sequential kernels of every d_state class and the time-parallel forms
+    (the last two shapes)."""
+    from cleanumamba_amd.mamba_ssm.ops.selective_scan_interface import A_IS_LOG, selective_scan_fn
+    bsz, dim, N, L = shape
+    gen = torch.Generator().manual_seed(7 + sum(shape))
+    rn = lambda *s: torch.randn(*s, generator=gen)
+    base = dict(u=rn(bsz, L, dim).transpose(1, 2), delta=0.5 * rn(bsz, L, dim).transpose(1, 2), A_log=0.5 * rn(dim, N),
+                B=rn(bsz, L, N).transpose(1, 2), C=rn(bsz, L, N).transpose(1, 2), D=rn(dim),
+                z=rn(bsz, L, dim).transpose(1, 2), delta_bias=0.5 * rn(dim))
+    dout = rn(bsz, L, dim).transpose(1, 2).to(cuda)
+    res = {}
+    for flag in (False, True):
+        t = {k: v.to(cuda).requires_grad_(True) for k, v in base.items()}
+        A = t["A_log"] if flag else -torch.exp(t["A_log"])
+        y = selective_scan_fn(t["u"], t["delta"], A, t["B"], t["C"], t["D"], z=t["z"], delta_bias=t["delta_bias"],
+                              delta_softplus=(1 | A_IS_LOG) if flag else True)
+        (y * dout).sum().backward()
+        res[flag] = (y.detach(), {k: v.grad for k, v in t.items()})
+    assert rel_l2(res[True][0], res[False][0]) < 2e-6
+    for k in base:
+        assert rel_l2(res[True][1][k], res[False][1][k]) < 2e-5, k

@@ -683,3 +683,32 @@ def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path, mode):
         assert out["modes"] is None
         assert out["step_graph"] == ("captured" if mode == "graph" else "off"), out["step_graph"]
         assert ("per-bucket" in out["exchange"]) == (mode == "eager"), out["exchange"]
+
+
+def test_lazy_zero_grad_steps_equal_memset_steps(cuda):
+    """Three optimisation steps of the 442K model with the lazy zero_grad (no whole-buffer memset under sink-written
+    gradients, training/flat_optim.py) and with the memset: bit-identical parameters, and the lazy run leaves no view stale."""
+    from cleanumamba_amd.network import CleanUMamba
+    from cleanumamba_amd.training import flat_optim as fo
+    from cleanumamba_amd.training.train_step import TrainStep
+    sd, cfg = load_ckpt("442k")
+    clean, noisy = synth.waveform(2, 8000, seed=11)
+    clean, noisy = clean.to(cuda), noisy.to(cuda)
+    outs = {}
+    for lazy in (True, False):
+        fo.FlatParams.LAZY_ZERO = lazy
+        try:
+            net = CleanUMamba(**cfg)
+            net.load_state_dict(sd, strict=True)
+            net = net.to(cuda).train()
+            step = TrainStep(net, optimization={"n_iters": 100}, use_graph=False)
+            for _ in range(3):
+                step(clean, noisy)
+            flat = step.optimizer.flat
+            assert not flat.stale
+            if lazy:
+                assert flat.sunk_last and len(flat.sunk_last) == len(flat.params)     # every gradient is a sink write
+            outs[lazy] = flat.data.clone()
+        finally:
+            fo.FlatParams.LAZY_ZERO = True
+    assert torch.equal(outs[True], outs[False])

@@ -25,6 +25,7 @@ SKIP = ("view", "reshape", "empty", "as_strided", "slice", "select", "transpose"
         "_local_scalar_dense", "unfold", "lift_fresh", "chunk", "movedim", "diagonal", "resize_", "set_", "_to_copy_meta", "sym_")
 acc = collections.Counter()
 sizes = {}
+shapes = collections.defaultdict(set)      # for the ops without a Python frame: which tensors they touch
 
 
 class Mode(TorchDispatchMode):
@@ -43,6 +44,8 @@ class Mode(TorchDispatchMode):
                         break
                 acc[(name, fr)] += 1
                 sizes[(name, fr)] = max(sizes.get((name, fr), 0), max((t.numel() for t in ts), default=0))
+                if fr == "<autograd engine>":
+                    shapes[(name, fr)].add(" ".join(f"{tuple(t.shape)}:{str(t.dtype).replace('torch.', '')}" for t in ts))
         return out
 
 
@@ -51,4 +54,6 @@ with Mode():
 torch.cuda.synchronize()
 for (name, fr), n in sorted(acc.items(), key=lambda kv: (-kv[1], kv[0])):
     print(f"{n:4d}  {name:34s} max numel {sizes[(name, fr)]:>11d}  {fr}")
+    for sh in sorted(shapes.get((name, fr), ())):
+        print(f"          {sh}")
 print("total", sum(acc.values()))

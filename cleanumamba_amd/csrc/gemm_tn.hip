@@ -831,6 +831,76 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const ReduceJob j0, cons
   }
 }
 
+// The same reduction writing its result where the PARAMETER lives (cum_gemm_tn_scatter): workgroups walk the float4 of
+// the destination matrices (a parameter's gradient seen as rows x cols, row-major, contiguous) and gather their four
+// sources from the GEMM-layout result through two small tables -- source position rowoff[r] + coloff[c] in the virtual
+// [N][K] result, positions N K + n = the bias gradient -- so that the f32 result never makes the round trip through an
+// arena in GEMM layout and a second, un-packing launch.  A conv weight (H, C, 4) reads its four taps as four 256-byte
+// runs per wave and writes whole 1-KiB rows.  Fixed summation order (slab lanes through LDS, as above): deterministic.
+struct ScatterJob {
+  const float *in, *bin;     // weight slabs [S][rows_in][ld_in], bias slabs [S][ldb]
+  float *dst;
+  const int *ro, *co;
+  int64_t in_slab, bin_slab;
+  int ld_in, rows, cols4, K, NK, fold;
+};
+
+__global__ __launch_bounds__(256) void tn_reduce_scatter_kernel(const ScatterJob j0, const ScatterJob j1, int nb0, int S) {
+  __shared__ float4 red[4][64];
+  const bool first = (int)blockIdx.x < nb0;
+  const ScatterJob &j = first ? j0 : j1;
+  const int bx = first ? blockIdx.x : blockIdx.x - nb0;
+  const int v = bx * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;
+  const int64_t total = (int64_t)j.rows * j.cols4;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  int r = 0, c = 0;
+  if (v < total) {
+    r = v / j.cols4;
+    c = (v % j.cols4) * 4;
+    const int base = j.ro[r];
+    const float *src[4];
+    int64_t stride[4];
+    int fold[4];
+    bool any_fold = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = base + j.co[c + i];
+      fold[i] = 0;
+      if (q < j.NK) {
+        const int n = q / j.K;
+        src[i] = j.in + (int64_t)n * j.ld_in + (q - n * j.K);
+        stride[i] = j.in_slab;
+      } else {
+        src[i] = j.bin + (q - j.NK);
+        stride[i] = j.bin_slab;
+        fold[i] = j.fold;
+        any_fold = any_fold || j.fold > 0;
+      }
+    }
+    for (int s = sl; s < S; s += 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] += src[i][(int64_t)s * stride[i]];
+      if (any_fold) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (fold[i] > 0) a[i] += src[i][(int64_t)s * stride[i] + fold[i]];
+      }
+    }
+  }
+  red[sl][threadIdx.x & 63] = make_float4(a[0], a[1], a[2], a[3]);
+  __syncthreads();
+  if (sl == 0 && v < total) {
+    float4 rr = red[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      const float4 t = red[q][threadIdx.x];
+      rr.x += t.x; rr.y += t.y; rr.z += t.z; rr.w += t.w;
+    }
+    *reinterpret_cast<float4 *>(j.dst + ((int64_t)r * j.cols4 * 4 + c)) = rr;
+  }
+}
+
 }  // namespace cum
 
 using namespace cum;
@@ -894,17 +964,32 @@ extern "C" int cum_gemm_tn_tile(int32_t dtype, int64_t M, int32_t N, int32_t K) 
   return tn_use8(M, N, K, dtype) ? 256 : TN_T;
 }
 
-extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
-                           int64_t ldx, float *dW, int64_t ldw, float *db, float *workspace, void *stream) {
+static int gemm_tn_impl(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
+                        int64_t ldx, float *dW, int64_t ldw, float *db, const cum_tn_scatter *sj, int nsj, float *workspace,
+                        void *stream) {
   CUM_REQUIRE(dtype_ok(dtype), "gemm_tn: dtype must be CUM_F32, CUM_BF16 or CUM_F16");
-  CUM_REQUIRE(dZ && X && dW && workspace && M >= 0 && N > 0 && K > 0, "gemm_tn: bad argument");
+  CUM_REQUIRE(dZ && X && (dW || sj) && workspace && M >= 0 && N > 0 && K > 0, "gemm_tn: bad argument");
   const int epc = is16(dtype) ? 8 : 4;
   CUM_REQUIRE(N % epc == 0 && K % epc == 0 && ldz % epc == 0 && ldx % epc == 0 && ldw % 4 == 0,
               "gemm_tn: N, K and strides must keep 16-byte alignment");
   CUM_REQUIRE(((uintptr_t)dZ & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)dW & 15) == 0,
               "gemm_tn: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  bool want_bias = db != nullptr;
+  if (sj) {
+    CUM_REQUIRE(nsj >= 1 && nsj <= 2, "gemm_tn_scatter: one or two destinations");
+    for (int i = 0; i < nsj; ++i) {
+      CUM_REQUIRE(sj[i].dst && sj[i].rowoff && sj[i].coloff && sj[i].rows > 0 && sj[i].cols > 0 && sj[i].cols % 4 == 0 &&
+                      ((uintptr_t)sj[i].dst & 15) == 0,
+                  "gemm_tn_scatter: destinations are 16-byte aligned matrices with a multiple of 4 columns");
+      want_bias = want_bias || sj[i].reads_bias;
+    }
+  }
   if (M == 0) {
+    if (sj) {
+      for (int i = 0; i < nsj; ++i) (void)hipMemsetAsync(sj[i].dst, 0, sizeof(float) * (size_t)sj[i].rows * sj[i].cols, st);
+      return CUM_OK;
+    }
     (void)hipMemset2DAsync(dW, sizeof(float) * ldw, 0, sizeof(float) * K, N, st);
     if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * N, st);
     return CUM_OK;
@@ -916,7 +1001,7 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   p.rows_per_split = rps;
   p.nsplit = S;
   p.slab = workspace;
-  p.bslab = db ? workspace + (int64_t)S * Np * Kp : nullptr;
+  p.bslab = want_bias ? workspace + (int64_t)S * Np * Kp : nullptr;
 #ifdef CUM_AB
   p.skip_store = (int)cum_knob("CUM_TN_NOSTORE", 0);
 #endif
@@ -949,20 +1034,51 @@ extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const
   float *part = workspace + (int64_t)S * Np * Kp + (int64_t)S * Np;
   float *bpart = part + (int64_t)C * N * K;
   const int cols4 = K / 4, bc4 = N / 4;
-  const int gx = (int)(((int64_t)N * cols4 + 63) / 64), bx = db ? (bc4 + 63) / 64 : 0;
+  const int gx = (int)(((int64_t)N * cols4 + 63) / 64), bx = want_bias ? (bc4 + 63) / 64 : 0;
+  // the last pass in scatter form: destination matrices instead of dW / db (one launch, up to two destinations)
+  auto scatter_pass = [&](const float *win, int64_t wslab, int ldin, const float *bin, int64_t bslab, int Sx) {
+    ScatterJob js[2];
+    int nb[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) {
+      const cum_tn_scatter &q = sj[i < nsj ? i : 0];
+      js[i] = ScatterJob{win, bin, q.dst, q.rowoff, q.coloff, wslab, bslab, ldin, q.rows, q.cols / 4, K, N * K, q.bias_fold};
+      nb[i] = i < nsj ? (int)(((int64_t)q.rows * (q.cols / 4) + 63) / 64) : 0;
+    }
+    hipLaunchKernelGGL(tn_reduce_scatter_kernel, dim3(nb[0] + nb[1], 1), dim3(256), 0, st, js[0], js[1], nb[0], Sx);
+  };
   // job 0: dW slabs [S][Np][Kp]; job 1: bias slabs [S][Np] seen as one row of Np / 4 float4
   if (C == 1) {
-    const ReduceJob w{p.slab, dW, (int64_t)Np * Kp, 0, ldw, Kp, N, cols4};
-    const ReduceJob bj{p.bslab, db, (int64_t)Np, 0, N, Np, 1, bc4};
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx + bx, 1), dim3(256), 0, st, w, bj, gx, S);
+    if (sj) {
+      scatter_pass(p.slab, (int64_t)Np * Kp, Kp, p.bslab, (int64_t)Np, S);
+    } else {
+      const ReduceJob w{p.slab, dW, (int64_t)Np * Kp, 0, ldw, Kp, N, cols4};
+      const ReduceJob bj{p.bslab, db, (int64_t)Np, 0, N, Np, 1, bc4};
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx + bx, 1), dim3(256), 0, st, w, bj, gx, S);
+    }
   } else {
     const ReduceJob w1{p.slab, part, (int64_t)Np * Kp, (int64_t)N * K, (int64_t)K, Kp, N, cols4};
     const ReduceJob b1{p.bslab, bpart, (int64_t)Np, (int64_t)Np, (int64_t)Np, Np, 1, bc4};
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx + bx, C), dim3(256), 0, st, w1, b1, gx, S);
-    const ReduceJob w2{part, dW, (int64_t)N * K, 0, ldw, K, N, cols4};
-    const ReduceJob b2{bpart, db, (int64_t)Np, 0, N, Np, 1, bc4};
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx + bx, 1), dim3(256), 0, st, w2, b2, gx, C);
+    if (sj) {
+      scatter_pass(part, (int64_t)N * K, K, bpart, (int64_t)Np, C);
+    } else {
+      const ReduceJob w2{part, dW, (int64_t)N * K, 0, ldw, K, N, cols4};
+      const ReduceJob b2{bpart, db, (int64_t)Np, 0, N, Np, 1, bc4};
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3(gx + bx, 1), dim3(256), 0, st, w2, b2, gx, C);
+    }
   }
   CUM_CHECK_LAUNCH();
   return CUM_OK;
+}
+
+extern "C" int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
+                           int64_t ldx, float *dW, int64_t ldw, float *db, float *workspace, void *stream) {
+  CUM_REQUIRE(dW, "gemm_tn: bad argument");
+  return gemm_tn_impl(dtype, M, N, K, dZ, ldz, X, ldx, dW, ldw, db, nullptr, 0, workspace, stream);
+}
+
+extern "C" int cum_gemm_tn_scatter(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
+                                   int64_t ldx, const cum_tn_scatter *jobs, int32_t njobs, float *workspace, void *stream) {
+  CUM_REQUIRE(jobs, "gemm_tn_scatter: bad argument");
+  return gemm_tn_impl(dtype, M, N, K, dZ, ldz, X, ldx, nullptr, 0, nullptr, jobs, njobs, workspace, stream);
 }

@@ -33,6 +33,12 @@ class ScanGradStrides(ctypes.Structure):
                 ("dz_sb", c_i64), ("dz_sd", c_i64), ("dz_sl", c_i64)]
 
 
+class TnScatter(ctypes.Structure):
+    """cum_tn_scatter (include/cleanumamba_hip.h): one destination of cum_gemm_tn_scatter."""
+    _fields_ = [("dst", ctypes.c_void_p), ("rowoff", ctypes.c_void_p), ("coloff", ctypes.c_void_p),
+                ("rows", c_i32), ("cols", c_i32), ("reads_bias", c_i32), ("bias_fold", c_i32)]
+
+
 class ConvShape(ctypes.Structure):
     _fields_ = [("batch", c_i32), ("dim", c_i32), ("len", c_i32), ("width", c_i32),
                 ("x_sb", c_i64), ("x_sd", c_i64), ("x_sl", c_i64),
@@ -83,6 +89,7 @@ SIGNATURES = {
     "cum_colsum": (c_i32, [c_i32, c_i64, c_i32, _P, c_i64, _P, _P, _P]),
     "cum_gemm_tn_workspace_elems": (c_i64, [c_i32, c_i64, c_i32, c_i32]),
     "cum_gemm_tn": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P, _P, _P]),
+    "cum_gemm_tn_scatter": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, c_i32, _P, _P]),
     "cum_stft_frames": (c_i32, [_P, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, _P, _P, c_i64, _P]),
     "cum_stft_loss_workspace_elems": (c_i64, [c_i64, c_i64]),
     "cum_stft_loss_fwd": (c_i32, [_P, _P, c_i64, c_i64, c_i32, c_i64, _P, _P, _P]),

@@ -106,14 +106,23 @@ class small_m_gemms:
         _SPLIT_K_OK = self.prev
 
 
-def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True, out=None, out_w=None, out_b=None):
+def wgrad(dZ, z_off, ldz, N, X, x_off, ldx, K, M, want_bias=True, out=None, out_w=None, out_b=None, scatter=None):
     """dW [N, K] f32 = dZ^T X (X rows may overlap), db [N] f32 = column sums of dZ.  csrc/gemm_tn.hip.
     ``out = (flat f32 buffer, offset)`` places dW then db at that offset (N*K + N elements) instead of allocating;
     ``out_w`` / ``out_b``: contiguous f32 tensors of N*K / N elements that receive dW / db (gradient views of the
-    flat buffer, see grad_sink)."""
+    flat buffer, see grad_sink); ``scatter``: a ctypes array of hip.TnScatter -- the result goes straight to the
+    parameters' own layouts (cum_gemm_tn_scatter; _ScatterPlan below) and nothing is returned."""
     lib = hip.lib()
     dc = hip.dtype_code(dZ.dtype)
     dev = dZ.device
+    if scatter is not None:
+        ws = torch.empty(max(lib.cum_gemm_tn_workspace_elems(dc, M, N, K), 1), dtype=torch.float32, device=dev)
+        esz = dZ.element_size()
+        with torch.cuda.device(dev):
+            hip.check(lib.cum_gemm_tn_scatter(dc, M, N, K, ctypes.c_void_p(dZ.data_ptr() + z_off * esz), ldz,
+                                              ctypes.c_void_p(X.data_ptr() + x_off * esz), ldx, scatter, len(scatter),
+                                              hip.ptr(ws), hip.stream_ptr()))
+        return None, None
     if out_w is not None:
         dW = out_w.view(N, K)
         db = (out_b if out_b is not None else torch.empty(N, dtype=torch.float32, device=dev)) if want_bias else None
@@ -561,6 +570,72 @@ class _WgradArena:
             outs.append(flat[off:off + n].view(sh))
             off += n
         return outs
+
+
+# "1": weight gradients straight from the slab reduce into the parameters' layouts (cum_gemm_tn_scatter), no arena and no
+# un-pack launch.  Built in round 6 and measured SLOWER on the E8 step (same box, A B A B: 19.12 / 19.14 ms against 18.89 /
+# 18.89 with the arena): the reduce then gathers its four sources per destination float4 with 4-byte loads through every
+# slab (2.1 GB per step) -- 256-byte runs per wave for a conv weight's taps, rows K apart for a transposed conv's -- where
+# the arena path reads the slabs as whole float4 rows and pays the permutation once, on 165 MB.  Off; kept for A/B.
+_SCATTER = os.environ.get("CUM_WGRAD_SCATTER", "0") == "1"
+_SCATTER_PLANS = {}
+
+
+class _ScatterPlan:
+    """Weight gradients straight into the parameters' layouts: per arena slot (= per weight-gradient GEMM) the row / column
+    tables of cum_gemm_tn_scatter for the parameters that slot feeds, derived once per stack signature from the same
+    index layouts the arena un-pack uses (``parts``: per parameter the arena position of every element).
+
+    slots[s] = [(q, rowoff, coloff, rows, cols, reads_bias, bias_fold)] with q the parameter's position in the stack's
+    parameter list, or None where a parameter of the slot does not separate (the arena path then serves that slot)."""
+
+    def __init__(self, arena, parts, shapes, slot_of, folds, dev):
+        per = {}
+        for q, (part, sh, sl) in enumerate(zip(parts, shapes, slot_of)):
+            if sl is None:
+                continue
+            rows, cols = (sh[0], _numel(sh) // sh[0]) if len(sh) > 1 else (1, _numel(sh))
+            rel = part.reshape(rows, cols).to(torch.int64) - arena.offs[sl]
+            N, K = arena.sizes[sl]
+            fold = folds.get(q, 0)
+            ok = cols % 4 == 0 and bool((part.reshape(-1) >= 0).all()) and int(rel.min()) >= 0 and \
+                int(rel.max()) < N * K + N
+            sep = _separable(rel) if ok else None
+            if sep is None:
+                per[sl] = None
+                continue
+            if per.get(sl, []) is None:
+                continue
+            ro, co, _ = sep
+            per.setdefault(sl, []).append((q, ro.to(dev), co.to(dev), rows, cols, int(bool((rel >= N * K).any())), int(fold)))
+        self.slots = {sl: (v if v is not None and len(v) <= 2 else None) for sl, v in per.items()}
+
+    def jobs(self, slot, grad, offs):
+        """ctypes array for one GEMM: destinations = the parameters' views of the flat gradient buffer."""
+        ent = self.slots.get(slot)
+        if not ent:
+            return None
+        arr = (hip.TnScatter * len(ent))()
+        for k, (q, ro, co, rows, cols, rb, fold) in enumerate(ent):
+            if offs[q] % 4:
+                return None
+            arr[k].dst = grad.data_ptr() + 4 * offs[q]
+            arr[k].rowoff, arr[k].coloff = ro.data_ptr(), co.data_ptr()
+            arr[k].rows, arr[k].cols, arr[k].reads_bias, arr[k].bias_fold = rows, cols, rb, fold
+        return arr
+
+    def params_of(self, slot):
+        return [e[0] for e in (self.slots.get(slot) or ())]
+
+
+def _scatter_plan(key, arena, parts_fn, shapes, slot_of, folds, dev):
+    if not _SCATTER:
+        return None
+    ck = (key, dev)
+    plan = _SCATTER_PLANS.get(ck)
+    if plan is None:
+        plan = _SCATTER_PLANS[ck] = _ScatterPlan(arena, parts_fn(), shapes, slot_of, folds, dev)
+    return plan
 
 
 def _contiguous_run(offs, shapes):
@@ -1161,14 +1236,16 @@ def _glu_bwd(z, ybuf, dy, go):
     return dz
 
 
-def _glu_wgrad(dz, xbuf, w, gi, M, out=None):
+def _glu_wgrad(dz, xbuf, w, gi, M, out=None, scatter=None):
     """Weight / bias gradient of a 1x1+GLU layer from dZ [M, G*32] and its input row buffer.  With ``out`` (an arena
-    slot) the GEMM-layout results stay there for the stack's batched un-pack and nothing is returned."""
+    slot) the GEMM-layout results stay there for the stack's batched un-pack and nothing is returned; with ``scatter``
+    they go straight to the parameters' gradient views."""
     G32 = dz.shape[1]
     H2 = w.shape[0]
     sh = tuple(w.shape)
-    dwp, dbp = wgrad(dz, 0, G32, G32, xbuf, gi.Cp, gi.Cp, gi.Cp, M, out=out)
-    if out is not None:
+    dwp, dbp = wgrad(dz, 0, G32, G32, xbuf, gi.Cp, gi.Cp, gi.Cp, M, out=None if scatter is not None else out,
+                     scatter=scatter)
+    if out is not None or scatter is not None:
         return None, None
     db = take(dbp, ("glu_vec_unpack", H2), lambda: _invert(lay_glu_vec(H2), (H2,)))
     dw = take(dwp, ("glu_unpack", sh, G32, gi.Cp), lambda: _invert(lay_glu_fwd(sh, G32, gi.Cp), sh))
@@ -1409,6 +1486,26 @@ class EncoderStack(torch.autograd.Function):
             flat, idx, offs = sink
             arena.unpack_into((key, lo, hi), lambda: parts(lo, hi), shapes[4 * lo:4 * hi], flat.grad, offs[4 * lo:4 * hi])
             flat.wrote(idx[4 * lo:4 * hi])
+        # Scatter form (cum_gemm_tn_scatter): every generic layer's two weight-gradient GEMMs write w, b of that layer
+        # straight into the flat gradient buffer and the layer is announced at once; the arena + un-pack launch remain
+        # for the fused first layer only (its own reduce kernels write arena slots).  All generic layers or none.
+        fused0 = y1s[0] is None and arena is not None and not ctx.needs_input_grad[0]
+        first = 1 if fused0 else 0
+        plan = None
+        if sink is not None:
+            plan = _scatter_plan(key, arena, lambda: parts(0, E), shapes, [2 * (q // 4) + (q % 4 >= 2) for q in range(4 * E)],
+                                 {}, dev)
+            if plan is not None and not all(len(plan.params_of(sl)) == 2 for i in range(first, E) for sl in (2 * i, 2 * i + 1)):
+                plan = None
+            if plan is not None and first and not _contiguous_run(sink[2][:4], shapes[:4]):
+                plan = None
+
+        def sc(slot):
+            if plan is None:
+                return None
+            jobs = plan.jobs(slot, sink[0].grad, sink[2])
+            assert jobs is not None
+            return jobs
         for i in reversed(range(E)):
             gi, gm, go = geos[i]
             w1, b1, w2, b2 = params[4 * i:4 * i + 4]
@@ -1424,7 +1521,7 @@ class EncoderStack(torch.autograd.Function):
                     break
                 y1 = _conv_relu_fwd(bufs[0], w1, b1, gi, gm)      # generic route (input gradient wanted): rebuild it
             grads[4 * i + 2], grads[4 * i + 3] = _glu_wgrad(dz, y1, w2, gm, go.M,
-                                                            out=arena.out(2 * i + 1) if arena else None)
+                                                            out=arena.out(2 * i + 1) if arena else None, scatter=sc(2 * i + 1))
             # 1x1 data gradient, gated by the ReLU below it in the epilogue
             wt = _glu_dgrad_weights(w2, gm, G32, dt)
             dzc = gm.new(dt, dev)
@@ -1437,13 +1534,15 @@ class EncoderStack(torch.autograd.Function):
             # conv weight gradient: X row m = the 4*Cp contiguous inputs of output row m
             sh = tuple(w1.shape)
             dwp, dbp = wgrad(dzc, gm.Cp, gm.Cp, gm.Cp, bufs[i], gi.Cp, 2 * gi.Cp, 4 * gi.Cp, gm.M,
-                             out=arena.out(2 * i) if arena else None)
+                             out=arena.out(2 * i) if (arena and plan is None) else None, scatter=sc(2 * i))
             if arena is None:
                 grads[4 * i] = take(dwp, ("conv_unpack", sh, gi.Cp, gm.Cp),
                                     lambda: _invert(lay_conv_fwd(sh, gi.Cp, gm.Cp, 4 * gi.Cp), sh)).to(w1.dtype)
                 grads[4 * i + 1] = dbp[:sh[0]].to(w1.dtype)
             dz = None
-            if early and i == cut:
+            if plan is not None:
+                sink[0].wrote(sink[1][4 * i:4 * i + 4])          # this layer's four gradients are in place
+            elif early and i == cut:
                 flush(cut, E)
             if i == 0 and not ctx.needs_input_grad[0]:
                 break
@@ -1465,7 +1564,11 @@ class EncoderStack(torch.autograd.Function):
             else:
                 dz = _glu_bwd(zs[i - 1], bufs[i], dx if ext is None else dx + ext, gi)
         if arena is not None:
-            if sink is not None:           # straight into the flat gradient buffer: no AccumulateGrad adds
+            if plan is not None:           # every generic layer is in place already: the fused first layer's arena slots
+                if first:
+                    flush(0, 1)
+                grads = [None] * len(params)
+            elif sink is not None:         # straight into the flat gradient buffer: no AccumulateGrad adds
                 flush(0, cut if early else E)
                 grads = [None] * len(params)
             else:
@@ -1555,6 +1658,48 @@ class DecoderStack(torch.autograd.Function):
         if _ARENA_BATCH:
             arena = _WgradArena([nk for j in range(E) for nk in ((g32s[j], geos[j][0].Cp),
                                                                  (2 * geos[j][2].Cp, 2 * geos[j][1].Cp))], dev)
+        shapes3 = [tuple(params[4 * j + k].shape) for j in range(E) for k in range(3)]
+
+        def parts():
+            out = []
+            for j in range(E):
+                gi, gg, go = geos[j]
+                sh1, sht = shapes3[3 * j], shapes3[3 * j + 2]
+                G32 = g32s[j]
+                out.append(arena.dw_index(2 * j, _invert(lay_glu_fwd(sh1, G32, gi.Cp), sh1)))
+                out.append(arena.db_index(2 * j, _invert(lay_glu_vec(sh1[0]), (sh1[0],))))
+                out.append(arena.dw_index(2 * j + 1, _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)))
+            return out
+        key = ("dec", tuple(shapes3), tuple((g[0].Cp, g[1].Cp, g[2].Cp) for g in geos), tuple(g32s))
+        # Scatter form (cum_gemm_tn_scatter; see EncoderStack.backward): w1, b1 from the 1x1's GEMM, wt and bt from the
+        # transposed conv's -- bt as the fold of the two halves of the paired-row bias gradient, which cost an ATen add
+        # per layer on the arena path.  The fused last layer keeps the arena (its own reduce kernels write the slots).
+        last_generic = E - 1 if ctx.fused_last else E
+        plan, sink4 = None, None
+        if arena is not None:
+            sink4 = grad_sink(list(params))
+            if sink4 is not None and all(p.is_leaf and p.dtype == torch.float32 for p in params):
+                shapes4 = [tuple(p.shape) for p in params]
+
+                def parts4():                      # parts() + the transposed conv's bias: channel c <- db[c] (+ db[Cp + c])
+                    three, out = parts(), []
+                    for j in range(E):
+                        out += three[3 * j:3 * j + 3]
+                        out.append(arena.db_index(2 * j + 1, torch.arange(1, shapes4[4 * j + 3][0] + 1, dtype=torch.int64)))
+                    return out
+                plan = _scatter_plan(key + ("bt",), arena, parts4, shapes4,
+                                     [2 * (q // 4) + (q % 4 >= 2) for q in range(4 * E)],
+                                     {4 * j + 3: geos[j][2].Cp for j in range(E)}, dev)
+                if plan is not None and not all(len(plan.params_of(sl)) == 2 for j in range(last_generic)
+                                                for sl in (2 * j, 2 * j + 1)):
+                    plan = None
+
+        def sc(slot):
+            if plan is None:
+                return None
+            jobs = plan.jobs(slot, sink4[0].grad, sink4[2])
+            assert jobs is not None
+            return jobs
         for j in reversed(range(E)):
             gi, gg, go = geos[j]
             w1, b1, wt, bt = params[4 * j:4 * j + 4]
@@ -1568,8 +1713,9 @@ class DecoderStack(torch.autograd.Function):
                 continue
             # transposed-conv weight gradient: pair rows of dpre against the 2*Cp contiguous inputs (rows m-1, m)
             dwp, dbp = wgrad(dpre, go.Cp, 2 * go.Cp, 2 * go.Cp, gs[j], 0, gg.Cp, 2 * gg.Cp, gg.M,
-                             out=arena.out(2 * j + 1) if arena else None)
-            grads[4 * j + 3] = _convt_bias_grad(bt, dbp, go.Cp, sht[1], wt.dtype)
+                             out=arena.out(2 * j + 1) if (arena and plan is None) else None, scatter=sc(2 * j + 1))
+            if plan is None:
+                grads[4 * j + 3] = _convt_bias_grad(bt, dbp, go.Cp, sht[1], wt.dtype)
             if arena is None:
                 grads[4 * j + 2] = take(dwp, ("convt_unpack", sht, gg.Cp, go.Cp),
                                         lambda: _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)).to(wt.dtype)
@@ -1586,7 +1732,10 @@ class DecoderStack(torch.autograd.Function):
                 dg = gg.new(dt, dev)
                 gemm(dpre, go.Cp, 2 * go.Cp, wc, None, dg, gg.Cp, gg.Cp, gg.M, gg.P, gg.T, hip.EPI_BIAS, gg.Cp, geo=gg)
                 dz = _glu_bwd(z, gs[j], dg, gg)
-            grads[4 * j], grads[4 * j + 1] = _glu_wgrad(dz, us[j], w1, gi, gg.M, out=arena.out(2 * j) if arena else None)
+            grads[4 * j], grads[4 * j + 1] = _glu_wgrad(dz, us[j], w1, gi, gg.M, out=arena.out(2 * j) if arena else None,
+                                                        scatter=sc(2 * j))
+            if plan is not None:
+                sink4[0].wrote(sink4[1][4 * j:4 * j + 4])        # this layer's four gradients are in place
             # 1x1 data gradient: ungated it is the gradient of u_j (and of the skip added into it); gated by the ReLU
             # of layer j-1 it is that layer's dpre -- both written by one epilogue
             w1t = _glu_dgrad_weights(w1, gi, G32, dt)
@@ -1603,27 +1752,20 @@ class DecoderStack(torch.autograd.Function):
             if j > 0 and j - 1 < ctx.n_skips:
                 dskips[j - 1] = du
         if arena is not None:
-            # w1, b1, wt per layer from one gather (bt is the sum of two halves of its slab: set above)
-            shapes = [tuple(params[4 * j + k].shape) for j in range(E) for k in range(3)]
-
-            def parts():
-                out = []
-                for j in range(E):
-                    gi, gg, go = geos[j]
-                    sh1, sht = shapes[3 * j], shapes[3 * j + 2]
-                    G32 = g32s[j]
-                    out.append(arena.dw_index(2 * j, _invert(lay_glu_fwd(sh1, G32, gi.Cp), sh1)))
-                    out.append(arena.db_index(2 * j, _invert(lay_glu_vec(sh1[0]), (sh1[0],))))
-                    out.append(arena.dw_index(2 * j + 1, _invert(lay_convt_fwd(sht, gg.Cp, go.Cp, 2 * go.Cp, 2 * gg.Cp), sht)))
-                return out
-            key = ("dec", tuple(shapes), tuple((g[0].Cp, g[1].Cp, g[2].Cp) for g in geos), tuple(g32s))
+            # w1, b1, wt per layer from one gather (bt is the sum of two halves of its slab: set above); in scatter form
+            # only the fused last layer's three are left to it
+            shapes = shapes3
+            lo3 = 3 * last_generic if plan is not None else 0
             three = [params[4 * j + k] for j in range(E) for k in range(3)]
-            sink = grad_sink(three)
-            if sink is not None:           # w1, b1, wt straight into the flat gradient buffer (bt keeps the autograd path)
+            sink = grad_sink(three[lo3:]) if lo3 < len(three) else None
+            if plan is not None and lo3 == len(three):
+                pass                       # nothing left for the arena
+            elif sink is not None:         # w1, b1, wt straight into the flat gradient buffer (bt keeps the autograd path)
                 flat, idx, offs = sink
+                offs = [None] * lo3 + list(offs)
                 # the transposed-conv biases sit between the gathered parameters: they must not be overwritten with
                 # zeros by the gap fill, so the gather runs per contiguous run of gathered parameters
-                order = sorted(range(len(three)), key=lambda q: offs[q])
+                order = sorted(range(lo3, len(three)), key=lambda q: offs[q])
                 runs, cur = [], [order[0]]
                 for q_prev, q in zip(order, order[1:]):
                     end_prev = offs[q_prev] + (_numel(shapes[q_prev]) + 3) // 4 * 4
@@ -1640,7 +1782,7 @@ class DecoderStack(torch.autograd.Function):
                         if all_parts is None:
                             all_parts = parts()
                         return [all_parts[q] for q in run]
-                    arena.unpack_into((key, r), run_parts, [shapes[q] for q in run], flat.grad, [offs[q] for q in run])
+                    arena.unpack_into((key, r, lo3), run_parts, [shapes[q] for q in run], flat.grad, [offs[q] for q in run])
                 flat.wrote(idx)
             else:
                 un = arena.unpack(key, parts, shapes)

@@ -275,6 +275,25 @@ int64_t cum_gemm_tn_workspace_elems(int32_t dtype, int64_t M, int32_t N, int32_t
 int cum_gemm_tn(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz,
                 const void *X, int64_t ldx, float *dW, int64_t ldw, float *db, float *workspace,
                 void *stream);
+/* cum_gemm_tn_scatter: the same product, its result written where the PARAMETERS live instead of as dW / db in GEMM
+ * layout (the reference's autograd leaves every weight gradient in its parameter's own layout,
+ * src/training/train.py:282-285; the GEMM layout is this library's, so un-doing it is the library's job too: one launch
+ * less and no f32 round trip per weight gradient).  A destination is a contiguous row-major f32 matrix rows x cols (cols a
+ * multiple of 4, 16-byte aligned) -- a parameter's gradient seen as a matrix -- whose element (r, c) is the element
+ * rowoff[r] + coloff[c] of the virtual result: positions n K + k of dW [N][K], positions N K + n the bias gradient
+ * (reads_bias != 0 if any position of the job is one; bias_fold: below).  rowoff / coloff: int32 device arrays.  One or
+ * two destinations (a layer's weight and bias).  workspace as cum_gemm_tn.  Deterministic. */
+typedef struct {
+  float *dst;
+  const int32_t *rowoff, *coloff;
+  int32_t rows, cols;
+  int32_t reads_bias;
+  int32_t bias_fold;         /* > 0: a bias position N K + n delivers db[n] + db[n + bias_fold] (the transposed conv's bias
+                                gradient: the GEMM sees output rows in pairs, N = 2 Cp, and each channel twice) */
+} cum_tn_scatter;
+int cum_gemm_tn_scatter(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
+                        int64_t ldx, const cum_tn_scatter *jobs, int32_t njobs, float *workspace, void *stream);
+
 /* Output tile edge of the kernel cum_gemm_tn runs for this problem: 256 (ping-pong kernel) or 128. */
 int cum_gemm_tn_tile(int32_t dtype, int64_t M, int32_t N, int32_t K);
 

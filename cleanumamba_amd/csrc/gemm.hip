@@ -59,11 +59,6 @@ struct GemmParams {
   int n_store;             // number of output columns to store (<= N, or N/2 for GLU); multiple of 4
   int64_t zero_head, zero_tail;
   int rows_epilogue;       // gemm_nt8_kernel: GLU_BWD epilogue through LDS (CUM_NT8_ROWS=0 turns it off for A/B runs)
-  // in-kernel split-K of the 128 x 128 kernel (cum_gemm_nt_ws): partial tiles [tile][split][128 x 128] f32, then one
-  // arrival counter per tile (zero between launches: the last arriver resets it)
-  float *ws;
-  int *ctr;
-  int ksplit;
 };
 
 template <typename T>
@@ -737,7 +732,7 @@ __device__ __forceinline__ void nt_epilogue_any(const GemmParams &p, const f32x4
 //   MFMAs of step k, one barrier per step.
 // The kernel is bound by L2 -> LDS bandwidth (a 128x128x64 tile moves 32 KB per 2.1 MFLOP = 64 flop/B; 256x128:
 // 85 flop/B; 256x256: 128 flop/B), so the largest tile that still fills the chip wins.
-template <typename T, int EPI, int BM, int BN, bool SPLIT = false>
+template <typename T, int EPI, int BM, int BN>
 // 16-bit element types: four waves per SIMD (128 VGPRs).  f32 (the parity path) carries 16-byte operand registers
 // through the epilogues and needs up to ~170: it is allowed down to two waves per SIMD instead of spilling.  So is the
 // GLU-backward epilogue (three operand streams): held to 128 it parked 84 values in AGPRs (v_accvgpr moves in the loop,
@@ -770,10 +765,7 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu((s
   // ONE XCD and the activation panel (128 x K) is fetched from HBM once instead of once per n-tile; the small
   // weight matrix is served from the Infinity Cache.  Placement affects speed only.
   const int NB = (p.N + BN - 1) / BN;
-  // SPLIT: the ksplit workgroups of one tile get ids 8 apart too (same XCD, back to back): their partial tiles meet in
-  // that XCD's L2
-  const int xcd = blockIdx.x & 7, local_s = blockIdx.x >> 3;
-  const int local = SPLIT ? local_s / p.ksplit : local_s, split = SPLIT ? local_s % p.ksplit : 0;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int m_tile = (local / NB) * 8 + xcd;
   const int n0 = (local % NB) * BN;
   const int m0 = m_tile * BM;
@@ -838,11 +830,9 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu((s
 
   float bv[4][4];
   nt_load_bias(p, n0, wn, g, bv);
-  const int nk_all = p.K / BK;
-  const int kt_lo = SPLIT ? (int)((int64_t)nk_all * split / p.ksplit) : 0;
-  const int nk = SPLIT ? (int)((int64_t)nk_all * (split + 1) / p.ksplit) : nk_all;
+  const int nk = p.K / BK;
   if constexpr (DB) CUM_GLDS(0, 0);
-  for (int kt = kt_lo; kt < nk; ++kt) {
+  for (int kt = 0; kt < nk; ++kt) {
     if constexpr (!DB) CUM_GLDS(kt * BK, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // DB: stage kt has landed for every wave, and every wave is done reading stage kt-1
@@ -855,56 +845,6 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu((s
   }
 #undef CUM_GLDS
 
-  if constexpr (SPLIT) {
-    // ---- in-kernel split-K (launches whose tiles fill less than half of the chip's 1024 workgroup slots: the M ~ 10 000
-    // GEMMs around the bottleneck).  Every workgroup of a tile leaves its partial accumulators in the tile's slab row
-    // (fragment order: whole 1-KiB wave rows), publishes them (MI355X_MICROARCH.md, "Valid forms": every storing wave's
-    // vmcnt(0), workgroup barrier, one agent-scope release, the arrival counter), and the LAST arriver of the tile sums
-    // all ksplit partials in split order -- its own from the slab too, so the sum does not depend on who came last:
-    // bit-reproducible -- and runs the epilogue.  The counter goes back to zero for the next launch.
-    const int tile_id = m_tile * NB + (local % NB);
-    float *slab = p.ws + ((int64_t)tile_id * p.ksplit) * (BM * BN);
-    {
-      float4 *mine = reinterpret_cast<float4 *>(slab + (int64_t)split * (BM * BN));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          mine[(i * 4 + jj) * NT + tid] = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int *flag = reinterpret_cast<int *>(lds_all);
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int old = __hip_atomic_fetch_add(p.ctr + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == p.ksplit - 1) {
-        __hip_atomic_store(p.ctr + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      *flag = old;
-    }
-    __syncthreads();
-    const int old = *flag;
-    __syncthreads();                      // (the LDS word is the epilogue's again)
-    if (old != p.ksplit - 1) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < p.ksplit; ++sp) {
-      const float4 *part = reinterpret_cast<const float4 *>(slab + (int64_t)sp * (BM * BN));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const float4 v = part[(i * 4 + jj) * NT + tid];
-          acc[i][jj][0] += v.x; acc[i][jj][1] += v.y; acc[i][jj][2] += v.z; acc[i][jj][3] += v.w;
-        }
-    }
-  }
   if constexpr (ROWS)   // (the single-buffered loop ends with a barrier: the LDS is free; 128 VGPRs: no slab of loads ahead)
     nt_epilogue_any<T, EPI, 1, (EPI == EPI_GLU_BWD && sizeof(T) == 2) ? 1 : 0>(p, &acc, bv, m0, n0, wm, wn, lane,
                                   reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
@@ -1578,44 +1518,10 @@ static int launch_gemm_nt9(const GemmParams &p, int epi, hipStream_t st) {
   return CUM_OK;
 }
 
-// in-kernel split-K of the 128 x 128 kernel (16-bit types, workspace given): how many workgroups share a tile.  Launches
-// whose tiles fill less than half of the chip's 1024 slots (256 CUs x 4 workgroups) run single-buffered workgroups one or two
-// to a CU, with nothing to hide the loads behind; splitting K over 2-4 workgroups per tile brings the slots back to one
-// resident round.  At least 8 K-steps per split.
-static int nt_ksplit(const GemmParams &p, int esz) {
-  if (esz != 2 || !p.ws) return 1;
-  const int64_t tiles = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (tiles > 512 || tiles < 1) return 1;
-  int64_t s = 1024 / tiles;
-  const int64_t nk = p.K / 64;
-  if (s > 4) s = 4;
-  if (s > nk / 8) s = nk / 8;
-  return s < 2 ? 1 : (int)s;
-}
-static int64_t nt_ws_tiles(const GemmParams &p) { return (int64_t)(8 * (((p.M + 127) / 128 + 7) / 8)) * ((p.N + 127) / 128); }
-
 template <typename T, int BM, int BN>
-static int launch_gemm_tile(const GemmParams &p0, int epi, hipStream_t st) {
-  GemmParams p = p0;
+static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   const int NB = (p.N + BN - 1) / BN, MB = (p.M + BM - 1) / BM;
   dim3 grid(8 * NB * ((MB + 7) / 8)), block(BM * BN / 64);
-  if constexpr (BM == 128 && BN == 128 && sizeof(T) == 2) {
-    const int S = nt_ksplit(p, (int)sizeof(T));
-    if (S > 1) {
-      p.ksplit = S;
-      p.ctr = reinterpret_cast<int *>(p.ws + nt_ws_tiles(p) * 4 * (BM * BN));     // behind the slabs (4 = largest split)
-      grid.x *= S;
-      switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, BM, BN, true>), grid, block, 0, st, p); break;
-        case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU, BM, BN, true>), grid, block, 0, st, p); break;
-        case EPI_MASK: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_MASK, BM, BN, true>), grid, block, 0, st, p); break;
-        case EPI_GLU_BWD: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU_BWD, BM, BN, true>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU, BM, BN, true>), grid, block, 0, st, p); break;
-      }
-      CUM_CHECK_LAUNCH();
-      return CUM_OK;
-    }
-  }
   switch (epi) {
     case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, BM, BN>), grid, block, 0, st, p); break;
     case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU, BM, BN>), grid, block, 0, st, p); break;
@@ -1689,8 +1595,8 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
 
 using namespace cum;
 
-static int gemm_nt_impl(const cum_gemm_desc *d, const void *A, const void *W, const float *bias, const void *res,
-                        void *out, void *aux, const void *aux2, float *workspace, int64_t workspace_elems, void *stream) {
+extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias, const void *res,
+                           void *out, void *aux, const void *aux2, void *stream) {
   CUM_REQUIRE(d && A && W && out, "gemm: null argument");
   CUM_REQUIRE(dtype_ok(d->dtype), "gemm: dtype must be CUM_F32, CUM_BF16 or CUM_F16");
   CUM_REQUIRE(d->epilogue >= 0 && d->epilogue <= 4, "gemm: bad epilogue");
@@ -1720,39 +1626,9 @@ static int gemm_nt_impl(const cum_gemm_desc *d, const void *A, const void *W, co
   p.M = d->M; p.N = d->N; p.K = d->K; p.pitch = d->pitch; p.valid = d->valid; p.n_store = d->n_store;
   p.zero_head = d->zero_head; p.zero_tail = d->zero_tail;
   p.rows_epilogue = (int)cum_knob("CUM_NT8_ROWS", 1);      // AB build: 0 = the generic GLU-backward epilogue
-  if (workspace) {
-    GemmParams q = p;
-    q.ws = workspace;
-    if (choose_tile(q, is16(d->dtype) ? 2 : 4) == 128 && nt_ksplit(q, is16(d->dtype) ? 2 : 4) > 1) {
-      CUM_REQUIRE(((uintptr_t)workspace & 15) == 0 && workspace_elems >= nt_ws_tiles(q) * (4 * 128 * 128 + 1),
-                  "gemm: workspace smaller than cum_gemm_nt_workspace_elems() or misaligned");
-      p.ws = workspace;
-    }
-  }
   if (d->dtype == CUM_BF16) return launch_gemm<__bf16>(p, d->epilogue, (hipStream_t)stream);
   if (d->dtype == CUM_F16) return launch_gemm<f16>(p, d->epilogue, (hipStream_t)stream);
   return launch_gemm<float>(p, d->epilogue, (hipStream_t)stream);
-}
-
-extern "C" int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias, const void *res,
-                           void *out, void *aux, const void *aux2, void *stream) {
-  return gemm_nt_impl(d, A, W, bias, res, out, aux, aux2, nullptr, 0, stream);
-}
-
-extern "C" int64_t cum_gemm_nt_workspace_elems(const cum_gemm_desc *d) {
-  if (!d || !dtype_ok(d->dtype) || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
-  GemmParams p{};
-  p.M = d->M; p.N = d->N; p.K = d->K; p.allow_split_k = d->allow_split_k;
-  p.ws = reinterpret_cast<float *>(16);      // (any non-null value: "a workspace would be given")
-  const int esz = is16(d->dtype) ? 2 : 4;
-  if (choose_tile(p, esz) != 128 || nt_ksplit(p, esz) <= 1) return 0;
-  return nt_ws_tiles(p) * (4 * 128 * 128 + 1);
-}
-
-extern "C" int cum_gemm_nt_ws(const cum_gemm_desc *d, const void *A, const void *W, const float *bias, const void *res,
-                              void *out, void *aux, const void *aux2, float *workspace, int64_t workspace_elems,
-                              void *stream) {
-  return gemm_nt_impl(d, A, W, bias, res, out, aux, aux2, workspace, workspace_elems, stream);
 }
 
 extern "C" int cum_gemm_nt_tile(const cum_gemm_desc *d) {
@@ -1760,15 +1636,6 @@ extern "C" int cum_gemm_nt_tile(const cum_gemm_desc *d) {
   GemmParams p{};
   p.M = d->M; p.N = d->N; p.K = d->K; p.allow_split_k = d->allow_split_k;
   return choose_tile(p, is16(d->dtype) ? 2 : 4);
-}
-
-extern "C" int cum_gemm_nt_ksplit(const cum_gemm_desc *d) {
-  if (!d || !dtype_ok(d->dtype) || d->M <= 0) return 1;
-  GemmParams p{};
-  p.M = d->M; p.N = d->N; p.K = d->K; p.allow_split_k = d->allow_split_k;
-  p.ws = reinterpret_cast<float *>(16);
-  const int esz = is16(d->dtype) ? 2 : 4;
-  return choose_tile(p, esz) == 128 ? nt_ksplit(p, esz) : 1;
 }
 
 extern "C" int cum_glu_bwd_gate(int32_t dtype, int64_t M, int32_t n_groups, int32_t n_out, const void *Bg, int64_t ldb,

@@ -81,9 +81,6 @@ SIGNATURES = {
     "cum_causal_conv1d_update": (c_i32, [c_i32, c_i32, c_i32, _P, _P, _P, _P, c_i32, _P, _P]),
     "cum_gemm_nt": (c_i32, [ctypes.POINTER(GemmDesc)] + [_P] * 8),
     "cum_gemm_nt_tile": (c_i32, [ctypes.POINTER(GemmDesc)]),
-    "cum_gemm_nt_ws": (c_i32, [ctypes.POINTER(GemmDesc)] + [_P] * 7 + [_P, c_i64, _P]),
-    "cum_gemm_nt_workspace_elems": (c_i64, [ctypes.POINTER(GemmDesc)]),
-    "cum_gemm_nt_ksplit": (c_i32, [ctypes.POINTER(GemmDesc)]),
     "cum_gemm_tn_tile": (c_i32, [c_i32, c_i64, c_i32, c_i32]),
     "cum_glu_bwd_gate": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P, c_i64, _P]),
     "cum_glu_bwd": (c_i32, [c_i32, c_i64, c_i32, c_i32, _P, c_i64, _P, c_i64, _P, _P]),

@@ -84,26 +84,9 @@ def gemm(A, a_off, lda, Wp, bias, out, o_off, ldc, M, pitch, valid, epilogue, n_
         d.zero_head, d.zero_tail = geo.head, geo.tail
     # offsets are in elements of the GEMM dtype; bit arrays (mask_bits) are passed as views that start at the right word
     P = lambda t, off: None if t is None else ctypes.c_void_p(t.data_ptr() + off * (esz if t.dtype == dt else 0))
-    lib = hip.lib()
     with torch.cuda.device(A.device):
-        need = lib.cum_gemm_nt_workspace_elems(ctypes.byref(d)) if _NT_SPLIT else 0
-        if need:
-            # in-kernel split-K (csrc/gemm.hip SPLIT): partial tiles + arrival counters.  ONE zero-initialised buffer per
-            # device and stream, reused by every such launch (the last arriver of a tile leaves its counter at zero)
-            key = (A.device, torch.cuda.current_stream(A.device).cuda_stream)
-            ws = _NT_WS.get(key)
-            if ws is None or ws.numel() < need:
-                ws = _NT_WS[key] = torch.zeros(need, dtype=torch.float32, device=A.device)
-            hip.check(lib.cum_gemm_nt_ws(ctypes.byref(d), P(A, a_off), P(Wp, 0), hip.ptr(bias), P(res, r_off),
-                                         P(out, o_off), P(aux, x_off), P(aux2, y_off), hip.ptr(ws), ws.numel(),
-                                         hip.stream_ptr()))
-            return
-        hip.check(lib.cum_gemm_nt(ctypes.byref(d), P(A, a_off), P(Wp, 0), hip.ptr(bias), P(res, r_off),
-                                  P(out, o_off), P(aux, x_off), P(aux2, y_off), hip.stream_ptr()))
-
-
-_NT_SPLIT = os.environ.get("CUM_NT_SPLIT", "1") != "0"      # "0": never the in-kernel split-K of the 128 x 128 GEMM (A/B)
-_NT_WS = {}
+        hip.check(hip.lib().cum_gemm_nt(ctypes.byref(d), P(A, a_off), P(Wp, 0), hip.ptr(bias), P(res, r_off),
+                                        P(out, o_off), P(aux, x_off), P(aux2, y_off), hip.stream_ptr()))
 
 
 _SPLIT_K_OK = False

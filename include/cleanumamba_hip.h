@@ -239,19 +239,6 @@ typedef struct {
 
 int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const float *bias,
                 const void *res, void *out, void *aux, const void *aux2, void *stream);
-/* cum_gemm_nt_ws: cum_gemm_nt with a workspace, which lets the library split K INSIDE the launch where the 128 x 128
- * kernel's tiles fill less than half of the chip's workgroup slots (16-bit types; the M ~ 10 000 GEMMs around the
- * bottleneck: upstream Mamba.forward's projections called at src/network/CleanUMamba.py:288-290, the deepest encoder /
- * decoder layers :108-113, 121-130, the 1x1 convs :139, :194): 2-4 workgroups per tile, f32 partial tiles in the
- * workspace, fixed-order combine by the tile's last arriver (bit-reproducible), every epilogue unchanged.
- * workspace: cum_gemm_nt_workspace_elems(d) f32 elements (0: this problem is not split, NULL may be passed), 16-byte
- * aligned, ZERO-INITIALISED by the caller once -- the library leaves it zero where it needs zeros (the arrival counters), so
- * one buffer serves every launch of a stream.  cum_gemm_nt_ksplit: workgroups per tile such a call would use (1: no split). */
-int64_t cum_gemm_nt_workspace_elems(const cum_gemm_desc *d);
-int cum_gemm_nt_ws(const cum_gemm_desc *d, const void *A, const void *W, const float *bias, const void *res,
-                   void *out, void *aux, const void *aux2, float *workspace, int64_t workspace_elems, void *stream);
-int cum_gemm_nt_ksplit(const cum_gemm_desc *d);
-
 /* Which kernel cum_gemm_nt runs for this problem (only dtype, M, N, K, allow_split_k are read): 64 = 64 x 64 tiles with
  * K split over the waves, 128 = 128 x 128, 256 = 256 x 128 (f32), 512 = 256 x 256 with two wave groups in ping-pong
  * (16-bit).  Lets a parity test state which kernel a shape was verified on. */

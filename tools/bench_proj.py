@@ -1,5 +1,4 @@
 """Mamba projection GEMM shapes (E8, B=16): torch (hipBLASLt) against cum_gemm_nt on the same operands.  GPU box."""
-import ctypes
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -26,13 +25,7 @@ for name, N, K in (("in_proj fwd", 4096, 512), ("in_proj dgrad", 512, 4096), ("o
     Wp = torch.zeros(cs.rup(N, 32), K, device=dev, dtype=dt); Wp[:N] = W
     bias = torch.zeros(Wp.shape[0], device=dev)
     t_own = timeit(lambda: cs.gemm(A, 0, K, Wp, bias, out, 0, N, M, 1 << 30, 1 << 30, hip.EPI_BIAS, N))
-    d = hip.GemmDesc()
-    d.dtype, d.M, d.N, d.K = hip.dtype_code(dt), M, Wp.shape[0], K
-    ks = hip.lib().cum_gemm_nt_ksplit(ctypes.byref(d))
-    cs._NT_SPLIT = False                      # the same kernel without the in-kernel split-K (round 5's path)
-    t_plain = timeit(lambda: cs.gemm(A, 0, K, Wp, bias, out, 0, N, M, 1 << 30, 1 << 30, hip.EPI_BIAS, N))
-    cs._NT_SPLIT = True
     t_sk = timeit(lambda: cs.gemm(A, 0, K, Wp, bias, out, 0, N, M, 1 << 30, 1 << 30, hip.EPI_BIAS, N, split_k=True)) if K >= 256 else float("nan")
     ref = A.float() @ W.float().t()
     err = float((out.float() - ref).abs().max())
-    print(f"{name:16s} M={M} N={N:5d} K={K:5d}  hipBLASLt {t_lib:6.1f} us   cum_gemm_nt {t_own:6.1f} us ({2e-6 * M * N * K / t_own:5.0f} TF/s; {ks} workgroups per tile; unsplit {t_plain:6.1f} us)   64x64 split-K {t_sk:6.1f} us   max err {err:.3f}")
+    print(f"{name:16s} M={M} N={N:5d} K={K:5d}  hipBLASLt {t_lib:6.1f} us   cum_gemm_nt {t_own:6.1f} us ({2e-6 * M * N * K / t_own:5.0f} TF/s)   64x64 split-K {t_sk:6.1f} us   max err {err:.3f}")

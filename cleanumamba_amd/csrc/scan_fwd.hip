@@ -8,6 +8,7 @@
 // At d_state = 64 the kernel is bound by v_exp_f32 issue (one per state update), not
 // by HBM -- see DESIGN.md "scan roofline".
 #include <stdlib.h>
+#include <type_traits>
 #include "scan_common.h"
 
 namespace cum {
@@ -456,6 +457,157 @@ __global__ __launch_bounds__(64) void scan_fwd_small_kernel(const ScanParams p) 
   }
 }
 
+// The same kernel as straight-line code for the shapes north_star prices against HBM (z given, softplus on, whole
+// 64-channel groups): what scan_fwd_small_kernel spends beside its arithmetic was half of its instruction stream -- per
+// step a divergent branch around softplus (x <= 20 is all but always true: computed unconditionally here, selected),
+// an exec-masked store, a branch on `z`, the tile address moved out of a scalar, per block 24 register copies from the
+// prefetched rows into the current ones.  Here: one 32-bit element offset per lane and tensor on wave-uniform row
+// pointers, two register sets and two LDS tiles used alternately by a loop unrolled over TWO blocks (no copies,
+// compile-time tile addresses), rows kept as loaded, steps of a full block without any predicate -- the compiler then
+// overlaps the LDS reads, the transcendentals and the stores of neighbouring steps; only a clip's ragged last block runs
+// the predicated form.  (Raw buffer loads -- resource + vector offset + scalar row offset, no vector address arithmetic at
+// all -- were tried: the compiler wraps them in waterfall loops wherever it cannot prove the row offset uniform, 183
+// registers.)
+template <int NW, typename TIO, int PB>
+__global__ __launch_bounds__(64) void scan_fwd_small_fast_kernel(const ScanParams p) {
+  constexpr int NPD = NW * NS;
+  constexpr int NP2 = NPD / 2;
+  constexpr int BCE = PB * 2 * NPD / 64;
+  constexpr int NBLK = TB / PB;
+  static_assert(PB == TB || PB == SUB, "a block is a chunk or one of its halves");
+  __shared__ __attribute__((aligned(16))) float s_bc[2][PB][2 * NPD];
+
+  const int lane = threadIdx.x;
+  const int b = blockIdx.y;
+  const int d = blockIdx.x * 64 + lane;        // (whole groups: every lane owns a channel)
+  const int N = p.s.dstate, L = p.s.len, Dm = p.s.dim;
+
+  f2 Ap[NP2], x[NP2];
+#pragma unroll
+  for (int j = 0; j < NPD; ++j) {
+    const int jj = j < N ? j : N - 1;
+    const float a = scan_A(p, (int64_t)d * N + jj) * kLog2e;
+    Ap[j / 2][j % 2] = j < N ? a : 0.f;
+    x[j / 2][j % 2] = 0.f;
+  }
+  const float Dd = p.D ? p.D[d] : 0.f;
+  const float bias = p.bias ? p.bias[d] : 0.f;
+  const TIO *up = static_cast<const TIO *>(p.u) + b * p.s.u_sb;
+  const TIO *dtp = static_cast<const TIO *>(p.delta) + b * p.s.dt_sb;
+  const TIO *zp = static_cast<const TIO *>(p.z) + b * p.s.z_sb;
+  TIO *op = static_cast<TIO *>(p.out) + b * p.s.o_sb;
+  const int u_o = d * (int)p.s.u_sd, dt_o = d * (int)p.s.dt_sd, z_o = d * (int)p.s.z_sd, o_o = d * (int)p.s.o_sd;
+  const float *Bb = p.Bm + b * p.s.B_sb, *Cb = p.Cm + b * p.s.C_sb;
+  const int64_t u_sl = p.s.u_sl, dt_sl = p.s.dt_sl, z_sl = p.s.z_sl, o_sl = p.s.o_sl;
+  const int B_sl = (int)p.s.B_sl, C_sl = (int)p.s.C_sl, B_sn = (int)p.s.B_sn, C_sn = (int)p.s.C_sn;
+  const int nchunks = p.nchunks;
+  // this lane's elements of a block's [PB][B | C] tile: (step, column) fixed per lane and k
+  int bc_off[BCE];
+  bool bc_ok[BCE];
+#pragma unroll
+  for (int k = 0; k < BCE; ++k) {
+    const int e = lane + 64 * k, j = e % (2 * NPD);
+    const bool isC = j >= NPD;
+    const int n = isC ? j - NPD : j, nc = n < N ? n : N - 1;
+    bc_ok[k] = n < N;
+    bc_off[k] = isC ? nc * C_sn : nc * B_sn;
+  }
+
+  struct Rows { TIO u[PB], dt[PB], z[PB]; float bc[BCE]; };     // rows as loaded: converted where a step uses them
+  auto load_block = [&](int t0, Rows &r) {
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      int t = t0 + k;
+      t = t < L ? t : L - 1;               // (wave-uniform clamp: the prefetch of the block behind the last one)
+      r.u[k] = (up + t * u_sl)[u_o];
+      r.dt[k] = (dtp + t * dt_sl)[dt_o];
+      r.z[k] = (zp + t * z_sl)[z_o];
+    }
+#pragma unroll
+    for (int k = 0; k < BCE; ++k) {
+      const int e = lane + 64 * k;
+      const int tl = e / (2 * NPD), j = e % (2 * NPD);
+      int t = t0 + tl;
+      t = t < L ? t : L - 1;
+      const float v = j >= NPD ? Cb[t * C_sl + bc_off[k]] : Bb[t * B_sl + bc_off[k]];
+      r.bc[k] = bc_ok[k] ? v : 0.f;
+    }
+  };
+  // one block: TAIL = the clip ends inside it (steps past the end neither touch the state nor store)
+  auto run_block = [&](int blk, const Rows &r, float (*tile)[2 * NPD], auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int t0 = blk * PB;
+#pragma unroll
+    for (int k = 0; k < BCE; ++k) (&tile[0][0])[lane + 64 * k] = r.bc[k];
+    // (same wave wrote the tile: LDS operations of one wave complete in order, the reads below see the writes)
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      if ((k == 0 || (PB == TB && k == SUB)) && p.ckpt) {
+        const int c = blk / NBLK, half = PB == TB ? (k == 0 ? 0 : 1) : (blk % NBLK);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const f2 (&xs)[NS / 2] = *reinterpret_cast<const f2 (*)[NS / 2]>(&x[w * (NS / 2)]);
+          ckpt_put<NW>(p.ckpt, b, nchunks, c, half, w, Dm, d, xs);
+        }
+      }
+      // softplus(delta + bias), upstream's threshold: computed on min(x, 20) for every lane, the identity selected
+      // above 20 (a divergent branch around three transcendentals costs more than they do)
+      const float pre = (float)r.dt[k] + bias;
+      const float sp = fast_log1p(fast_exp(fminf(pre, 20.f)));
+      float dtv = pre <= 20.f ? sp : pre;
+      if constexpr (TAIL) dtv = (t0 + k < L) ? dtv : 0.f;
+      const float uv = (float)r.u[k];
+      const float du = dtv * uv;
+      f2 y = {0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NPD / 4; ++q) {            // four states (two pairs) per 16-byte broadcast read
+        const float4 bq = *reinterpret_cast<const float4 *>(&tile[k][4 * q]);
+        const float4 cq = *reinterpret_cast<const float4 *>(&tile[k][NPD + 4 * q]);
+        const f2 bv[2] = {f2{bq.x, bq.y}, f2{bq.z, bq.w}}, cv[2] = {f2{cq.x, cq.y}, f2{cq.z, cq.w}};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * q + h;
+          const f2 e = dtv * Ap[j];
+          f2 a;
+          a.x = __builtin_amdgcn_exp2f(e.x);
+          a.y = __builtin_amdgcn_exp2f(e.y);
+          x[j] = a * x[j] + du * bv[h];
+          y = cv[h] * x[j] + y;
+        }
+      }
+      const float zv = (float)r.z[k];
+      const float yv = (y.x + y.y + Dd * uv) * (zv * sigmoidf_(zv));
+      if (!TAIL || t0 + k < L) (op + (t0 + k) * o_sl)[o_o] = (TIO)yv;
+    }
+  };
+
+  const int nblocks = nchunks * NBLK;
+  const int nfull = L / PB;                      // blocks that lie wholly inside the clip
+  Rows ra, rb;
+  load_block(0, ra);
+  int blk = 0;
+  for (; blk + 1 < nfull; blk += 2) {            // two full blocks per turn: register sets and tiles alternate
+    load_block((blk + 1) * PB, rb);
+    run_block(blk, ra, s_bc[0], std::false_type{});
+    load_block((blk + 2) * PB, ra);
+    run_block(blk + 1, rb, s_bc[1], std::false_type{});
+  }
+  for (; blk < nblocks; ++blk) {                 // what is left: at most one full block and the ragged one
+    if (blk + 1 < nblocks) load_block((blk + 1) * PB, rb);
+    if (blk < nfull)
+      run_block(blk, ra, s_bc[blk & 1], std::false_type{});
+    else
+      run_block(blk, ra, s_bc[blk & 1], std::true_type{});
+    ra = rb;
+  }
+  if (p.last_state) {
+    float *ls = p.last_state + ((int64_t)b * Dm + d) * N;
+#pragma unroll
+    for (int j = 0; j < NPD; ++j)
+      if (j < N) ls[j] = x[j / 2][j % 2];
+  }
+}
+
 // Wave-specialised form of the same small-d_state scan.  With all states of a channel in one wave, the work that
 // depends on (t, d) only -- softplus (exp, log, rcp), the SiLU gate (exp, rcp), delta*u, D*u, the loads and their
 // address arithmetic: ~155 issue cycles per step -- costs MORE than the eight state updates it feeds (~140), and the grid
@@ -871,10 +1023,21 @@ static int launch_fwd_io(const ScanParams &p, hipStream_t st) {
       // more waves per SIMD (1024 SIMDs) than the whole-chunk form fits (3 at d_state <= 8, 2 at <= 16): the half-chunk
       // form, which fits one more
       const int64_t half_min = cum_knob("CUM_SCAN_SMALL_HALF_MIN", NW == 1 ? 3072 : 2048);
-      if ((int64_t)grid.x * grid.y > half_min)
-        hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO, SUB>), grid, dim3(64), 0, st, p);
-      else
-        hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO, TB>), grid, dim3(64), 0, st, p);
+      // the straight-line form (scan_fwd_small_fast_kernel): z given, softplus on, whole 64-channel groups, channel offsets
+      // that fit its 32-bit lane offsets.  Its whole-chunk form needs 176 registers at d_state <= 8 (two waves per SIMD
+      // where the branchy one fits three): taken only while the grid brings no more than two.
+      const int64_t ext = p.s.dim - 1, waves = (int64_t)grid.x * grid.y;
+      const bool fast = p.z && (p.s.delta_softplus & kScanSoftplus) && p.s.dim % 64 == 0 && p.s.len >= 1 &&
+                        p.s.u_sd >= 0 && p.s.dt_sd >= 0 && p.s.z_sd >= 0 && p.s.o_sd >= 0 && ext * p.s.u_sd < (1 << 30) &&
+                        ext * p.s.dt_sd < (1 << 30) && ext * p.s.z_sd < (1 << 30) && ext * p.s.o_sd < (1 << 30) &&
+                        cum_knob("CUM_SCAN_SMALL_FAST", 1) != 0;
+      if (waves > half_min) {
+        if (fast) hipLaunchKernelGGL((scan_fwd_small_fast_kernel<NW, TIO, SUB>), grid, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO, SUB>), grid, dim3(64), 0, st, p);
+      } else {
+        if (fast && (NW == 2 || waves <= 2048)) hipLaunchKernelGGL((scan_fwd_small_fast_kernel<NW, TIO, TB>), grid, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((scan_fwd_small_kernel<NW, TIO, TB>), grid, dim3(64), 0, st, p);
+      }
       CUM_CHECK_LAUNCH();
       return CUM_OK;
     }

@@ -720,6 +720,9 @@ def main():
             loss, _ = step(clean, noisy)
         skipped_before = float(step.optimizer.state_vec[9]) if step.flat else 0.0
         barrier()
+        buckets = getattr(step, "buckets", None)
+        if exchange and buckets is not None and step.graph_status != "captured":
+            buckets.timeline = []                        # per-bucket launch / completion stamps of the eager exchange
         host0 = step.host_seconds
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -727,6 +730,10 @@ def main():
         host_ms = 1e3 * (step.host_seconds - host0) / max(args.steps, 1)  # enqueue time only: nothing inside synchronises
         barrier()
         elapsed = time.perf_counter() - t0
+        bucket_times = None
+        if buckets is not None and buckets.timeline is not None:
+            bucket_times = buckets.timeline_summary()
+            buckets.timeline = None
         host_ms_ranks = [host_ms]
         if world > 1:
             import torch.distributed as dist
@@ -741,7 +748,7 @@ def main():
             info.update(loss_scale=float(sv[3]) if ac == torch.float16 else None, settle_steps=settle,
                         skipped_steps_in_timed_region=float(sv[9]) - skipped_before, adam_steps_total=float(sv[5]))
         return {"ms": 1e3 * elapsed / args.steps, "elapsed": elapsed, "host": host_ms_ranks, "loss": float(loss),
-                "graph": step.graph_status, "optim": info, "net": net}
+                "graph": step.graph_status, "optim": info, "net": net, "buckets": bucket_times}
 
     exchanging = world > 1 or alone
     modes = {}
@@ -758,7 +765,7 @@ def main():
         torch.cuda.empty_cache()
         graph = run_mode(True, True)
         modes = {"eager_overlapped": round(eager["ms"], 3), "three_graphs": round(graph["ms"], 3),
-                 "three_graphs_status": graph["graph"]}
+                 "three_graphs_status": graph["graph"], "eager_bucket_timeline_rank0": eager.get("buckets")}
         best = graph if graph["ms"] < eager["ms"] and graph["graph"] == "captured" else dict(eager, net=graph["net"])
         if best is not graph:
             graph.pop("net", None)
@@ -792,6 +799,9 @@ def main():
                "final_loss": round(final_loss, 5), "step_graph": graph_status, "optimizer": optim_info,
                "host_ms_per_step_by_rank": [round(h, 3) for h in host_ms_ranks],
                "modes": modes or None, "collective_ranks_observed": rccl_ranks,
+               # eager exchange, rank 0, per bucket: how long before the end of the backward it was launched and how long
+               # after it the compute stream was past its wait (GradBuckets.timeline_summary)
+               "bucket_timeline_rank0": best.get("buckets") or (modes or {}).get("eager_bucket_timeline_rank0"),
                "backend": (os.environ.get("CUM_DIST_BACKEND", "nccl") if exchanging else None),
                "cpu_affinity_rank0": (dict(pin_info, cores=f"{len(cpus)}: {cpus[0]}-{cpus[-1]}") if cpus else None),
                "exchange": ("none" if world == 1 and not alone else

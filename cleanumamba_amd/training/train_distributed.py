@@ -161,11 +161,27 @@ class GradBuckets:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(int(flag.item()))
 
+    # ``timeline``: None, or a list that receives one record per backward of the eager overlapped exchange (bench.py
+    # --gpus N): GPU events on the compute stream at the point every bucket's all-reduce is LAUNCHED (its last gradient
+    # is enqueued), at the END of the backward, and behind the wait for every bucket -- so the first multi-GPU run shows
+    # whether a step is lost to the exchange (buckets complete long after the backward has ended) or to the host (the
+    # launch points themselves are late).  The collective's own stream is the process group's and cannot be stamped.
+    timeline = None
+
+    def _stamp(self):
+        if self.timeline is None or not self.flat.grad.is_cuda:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
     def _launch(self, flat):
+        ev = self._stamp()
         if self.use_avg:
-            self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+            self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None, ev,
+                                 flat.numel()))
         else:
-            self.handles.append((dist.all_reduce(flat, group=self.group, async_op=True), flat))
+            self.handles.append((dist.all_reduce(flat, group=self.group, async_op=True), flat, ev, flat.numel()))
 
     def _finish(self):
         # buckets whose parameters did not all receive a gradient this pass are still reduced,
@@ -174,12 +190,32 @@ class GradBuckets:
             if b[2] != 0:
                 self._launch(b[0])
                 b[2] = 0
-        for h, flat in self.handles:
+        end_bwd, rec = self._stamp(), []
+        for h, flat, ev, n in self.handles:
             h.wait()
             if flat is not None:
                 flat /= self.world
+            rec.append((n, ev, self._stamp()))
+        if self.timeline is not None and end_bwd is not None:
+            self.timeline.append((end_bwd, rec))
         self.handles = []
         self._armed = False
+
+    def timeline_summary(self):
+        """Per bucket, averaged over the recorded backwards: bytes, ms from its launch point to the end of the backward
+        (how early it could start), ms from the end of the backward until the compute stream was past its wait (what of it
+        the step could not hide).  Call after a device synchronisation."""
+        if not self.timeline:
+            return None
+        nb = len(self.timeline[0][1])
+        out = []
+        for k in range(nb):
+            head = [end.elapsed_time(rec[k][1]) for end, rec in self.timeline if len(rec) == nb]      # negative: before the end
+            tail = [end.elapsed_time(rec[k][2]) for end, rec in self.timeline if len(rec) == nb]
+            if head:
+                out.append({"bytes": 4 * self.timeline[0][1][k][0], "launched_before_backward_end_ms": round(-sum(head) / len(head), 3),
+                            "complete_after_backward_end_ms": round(sum(tail) / len(tail), 3)})
+        return out
 
 
 def apply_gradient_allreduce(module, bucket_bytes=32 << 20):

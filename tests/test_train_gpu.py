@@ -676,6 +676,10 @@ def test_bench_two_ranks_from_a_plain_invocation(cuda, tmp_path, mode):
         m = out["modes"]
         assert m["eager_overlapped"] > 0 and m["three_graphs"] > 0 and m["no_exchange"] > 0
         assert m["three_graphs_status"] == "captured"
+        tl = m["eager_bucket_timeline_rank0"]              # per-bucket launch / completion stamps of the eager exchange
+        assert tl and len(tl) >= 2 and sum(b["bytes"] for b in tl) >= 4 * 41_000_000
+        assert all(b["launched_before_backward_end_ms"] >= -1e-3 and b["complete_after_backward_end_ms"] >= -1e-3 for b in tl)
+        assert tl[0]["launched_before_backward_end_ms"] > tl[-1]["launched_before_backward_end_ms"]      # decoder first
         assert abs(m["exchange_exposed_ms"] - (min(m["eager_overlapped"], m["three_graphs"]) - m["no_exchange"])) < 2e-3
         assert abs(out["ms_per_step"] - min(m["eager_overlapped"], m["three_graphs"])) < 2e-3
         assert out["step_graph"] == ("captured" if m["three_graphs"] < m["eager_overlapped"] else "off")

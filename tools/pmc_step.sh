@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of EVERY kernel of the E8 B = 16 f16 train step (GPU box): two SEPARATE rocprofv3 --pmc passes (FETCH_SIZE,
 # WRITE_SIZE; counters with --kernel-trace only, MI355X_MICROARCH.md) over three eager steps of bench.py, then the
-# time-parallel scan kernels (tools/bench_scan_tp.py).  Summary -> gpurun_out/r05_step_pmc.txt
+# time-parallel scan kernels (tools/bench_scan_tp.py).  Summary -> gpurun_out/${1:-r06}_step_pmc.txt
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   (cd $GRAFT_REPO_ROOT && rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcs_$c -- python3 bench.py --steps 3 --warmup 1 --no-graph --no-roofline --no-cpu-baseline) > $OUT/pmc_step_$c.log 2>&1
   (cd $GRAFT_REPO_ROOT && rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmct_$c -- python3 tools/bench_scan_tp.py) > $OUT/pmc_scantp_$c.log 2>&1
 done
-python3 - <<'PY' > $OUT/r05_step_pmc.txt
+python3 - <<'PY' > $OUT/${1:-r06}_step_pmc.txt
 import csv, glob, collections, re
 def load(prefix):
     acc = {c: collections.defaultdict(list) for c in ("FETCH_SIZE", "WRITE_SIZE")}
@@ -36,4 +36,4 @@ for title, prefix, per in (("train step (E8, B = 16, f16 autocast, eager; settle
     for _, k, n, fm, wm in sorted(rows, reverse=True)[:45]:
         print(f"{k} | {n} | {fm:.1f} | {wm:.1f}")
 PY
-cat $OUT/r05_step_pmc.txt | head -70
+cat $OUT/${1:-r06}_step_pmc.txt | head -70

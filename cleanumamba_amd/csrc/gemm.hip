@@ -59,7 +59,6 @@ struct GemmParams {
   int n_store;             // number of output columns to store (<= N, or N/2 for GLU); multiple of 4
   int64_t zero_head, zero_tail;
   int rows_epilogue;       // gemm_nt8_kernel: GLU_BWD epilogue through LDS (CUM_NT8_ROWS=0 turns it off for A/B runs)
-  int ksplit;              // gemm_nt_kernel<.., PERSIST>: block ids of the plain grid, walked by one resident round
 };
 
 template <typename T>
@@ -733,7 +732,7 @@ __device__ __forceinline__ void nt_epilogue_any(const GemmParams &p, const f32x4
 //   MFMAs of step k, one barrier per step.
 // The kernel is bound by L2 -> LDS bandwidth (a 128x128x64 tile moves 32 KB per 2.1 MFLOP = 64 flop/B; 256x128:
 // 85 flop/B; 256x256: 128 flop/B), so the largest tile that still fills the chip wins.
-template <typename T, int EPI, int BM, int BN, bool PERSIST = false>
+template <typename T, int EPI, int BM, int BN>
 // 16-bit element types: four waves per SIMD (128 VGPRs).  f32 (the parity path) carries 16-byte operand registers
 // through the epilogues and needs up to ~170: it is allowed down to two waves per SIMD instead of spilling.  So is the
 // GLU-backward epilogue (three operand streams): held to 128 it parked 84 values in AGPRs (v_accvgpr moves in the loop,
@@ -758,31 +757,22 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu((s
   constexpr int EPI_CHUNKS = ROWS ? (NT / 64) * nt_rows_lds(EPI) / 16 : 0;
   __shared__ uint4 lds_all[TILE_CHUNKS > EPI_CHUNKS ? TILE_CHUNKS : EPI_CHUNKS];
 
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = lane >> 4, r = lane & 15;
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
   // ids b and b+8 share an L2.  All n-tiles of one m-tile get ids that are 8 apart: they run back to back on
   // ONE XCD and the activation panel (128 x K) is fetched from HBM once instead of once per n-tile; the small
   // weight matrix is served from the Infinity Cache.  Placement affects speed only.
   const int NB = (p.N + BN - 1) / BN;
-  // PERSIST (launches of thousands of few-K-step tiles: the outer, HBM-bound layers): the grid is one resident round and a
-  // workgroup walks tiles bid, bid + gridDim.x, ... (gridDim.x a multiple of 8: it stays on its XCD) -- no dispatch,
-  // pointer set-up and drain per 128 rows.  p.ksplit carries the number of block ids of the un-persistent grid.
-  const int nbid = PERSIST ? p.ksplit : (int)gridDim.x;
-  int bid = blockIdx.x;
-  do {                                   // (one pass, and no loop in the code, unless PERSIST)
-  int tid = threadIdx.x;
-  if constexpr (PERSIST) asm volatile("" : "+v"(tid));      // (per-tile address arithmetic stays inside its tile: hoisted out
-                                                            //  of the loop it would live in ~50 more registers than there are)
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int g = lane >> 4, r = lane & 15;
-  const int xcd = bid & 7, local = bid >> 3;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int m_tile = (local / NB) * 8 + xcd;
   const int n0 = (local % NB) * BN;
   const int m0 = m_tile * BM;
-  if (m0 >= p.M) continue;
+  if (m0 >= p.M) return;
   // The first workgroup also clears the rows that frame the output buffer (leading zero row, slack rows), so the
   // host never issues fill kernels for them.
-  if (bid == 0) {
+  if (blockIdx.x == 0) {
     T *o = static_cast<T *>(p.out);
     T *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD && !(EPI == EPI_RELU && p.mask_bits)) ? static_cast<T *>(p.aux) : nullptr;
     for (int64_t i = threadIdx.x; i < p.zero_head; i += NT) {
@@ -860,8 +850,6 @@ __global__ __launch_bounds__(BM * BN / 64) __attribute__((amdgpu_waves_per_eu((s
                                   reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
   else
     nt_epilogue<T, EPI>(p, &acc, bv, m0, n0, wm, wn, g, r);
-  if constexpr (PERSIST) __syncthreads();      // the next tile's loads land where this epilogue's rows went through
-  } while (PERSIST && (bid += (int)gridDim.x) < nbid);
 }
 
 #ifdef CUM_AB   // gemm_nt8_kernel: the predecessor of gemm_nt9_kernel, kept for same-box A/B runs (CUM_NT9=0)
@@ -1531,27 +1519,9 @@ static int launch_gemm_nt9(const GemmParams &p, int epi, hipStream_t st) {
 }
 
 template <typename T, int BM, int BN>
-static int launch_gemm_tile(const GemmParams &p0, int epi, hipStream_t st) {
-  GemmParams p = p0;
+static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   const int NB = (p.N + BN - 1) / BN, MB = (p.M + BM - 1) / BM;
   dim3 grid(8 * NB * ((MB + 7) / 8)), block(BM * BN / 64);
-  if constexpr (BM == 128 && BN == 128 && sizeof(T) == 2) {
-    // experiment (AB build, CUM_NT_PERSIST=1): one resident round walking the tiles
-    const int slots = epi == EPI_GLU_BWD ? 768 : 1024;
-    if ((int)grid.x > 2 * slots && cum_knob("CUM_NT_PERSIST", 0) != 0) {
-      p.ksplit = (int)grid.x;
-      grid.x = slots;
-      switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, BM, BN, true>), grid, block, 0, st, p); break;
-        case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU, BM, BN, true>), grid, block, 0, st, p); break;
-        case EPI_MASK: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_MASK, BM, BN, true>), grid, block, 0, st, p); break;
-        case EPI_GLU_BWD: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU_BWD, BM, BN, true>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GLU, BM, BN, true>), grid, block, 0, st, p); break;
-      }
-      CUM_CHECK_LAUNCH();
-      return CUM_OK;
-    }
-  }
   switch (epi) {
     case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, BM, BN>), grid, block, 0, st, p); break;
     case EPI_RELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RELU, BM, BN>), grid, block, 0, st, p); break;

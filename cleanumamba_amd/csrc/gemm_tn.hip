@@ -239,6 +239,231 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
   }
 }
 
+// ---------------------------------------------------------------- whole 128 x 256 / 256 x 128 result, streamed (16-bit)
+// The two widest layers' weight gradients (enc1 / dec6 at E8: N x K = 128 x 256 and 256 x 128 over M = 641 024 rows) are pure
+// streaming reductions: 0.33 - 0.49 GB of operands, 42 GFLOP, a result of 32 K floats.  gemm_tn_kernel runs them as two
+// 128 x 128 tiles per row split on single-buffered LDS (issue 32 KB, wait for all of it, compute, barrier): three
+// workgroups per CU each spend most of a step waiting for their one stage -- 2.7 - 3.5 TB/s.  Here ONE workgroup of eight
+// waves owns the whole result for its row split (every operand byte crosses L2 -> LDS once), and the 64-row steps go
+// through a ring of three 48 KB LDS stages filled by LDS-DMA two steps ahead: 96 KB per CU in flight behind one counted
+// vmcnt and ONE barrier per step (the stage refilled at step s is the one every wave finished reading before it arrived at
+// step s's barrier).  Same fragment reads, swizzle, MFMA order inside a tile and slab layout as gemm_tn_kernel.
+template <typename T, int NT, int KT>
+__global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const TnParams p) {
+  static_assert(sizeof(T) == 2 && NT * KT == 128 * 256, "16-bit operands, a 32 K-element result");
+  constexpr int EPC = 8, BMK = 64, NST = 3;
+  constexpr int CZ = NT / EPC, CX = KT / EPC;          // 16-byte chunks per stage row: 16 / 32
+  constexpr int ZCH = BMK * CZ, XCH = BMK * CX;        // chunks per stage and operand
+  constexpr int NZ = ZCH / 512, NX = XCH / 512;        // LDS-DMA instructions per thread and step: 2 + 4 or 4 + 2
+  constexpr int STG = ZCH + XCH;                       // 3 072 chunks = 48 KB
+  constexpr int WN = NT / 64;
+  __shared__ uint4 lds[NST * STG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wn = wave % WN, wk = wave / WN;
+  const int g = lane >> 4, r = lane & 15;
+  const int sp = blockIdx.x;
+  const int64_t m_begin = (int64_t)sp * p.rows_per_split;
+  int64_t m_end = m_begin + p.rows_per_split;
+  m_end = m_end < p.M ? m_end : p.M;
+  const int rows = (int)(m_end - m_begin);
+  const T *dZ = static_cast<const T *>(p.dZ) + m_begin * p.ldz;
+  const T *X = static_cast<const T *>(p.X) + m_begin * p.ldx;
+  const int ldz = (int)p.ldz, ldx = (int)p.ldx;        // a split's extent fits 32 bits (checked by the launcher)
+
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+  int zrow[NZ], zoff[NZ], xrow[NX], xoff[NX];
+#pragma unroll
+  for (int i = 0; i < NZ; ++i) {
+    const int pos = i * 512 + tid;
+    zrow[i] = pos / CZ;
+    const int c = ((pos % CZ) ^ TnCfg<T>::swz(zrow[i])) * EPC;
+    zoff[i] = c < p.N ? c : 0;                         // columns past the edge: valid memory, products never read
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int pos = i * 512 + tid;
+    xrow[i] = pos / CX;
+    const int c = ((pos % CX) ^ TnCfg<T>::swz(xrow[i])) * EPC;
+    xoff[i] = c < p.K ? c : 0;
+  }
+  auto issue = [&](int s, int buf) {
+    uint4 *st = lds + buf * STG;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      int m = s * BMK + zrow[i];
+      m = m < rows ? m : rows - 1;
+      __builtin_amdgcn_global_load_lds((glb_ptr)(dZ + (m * ldz + zoff[i])), (lds_ptr)(&st[i * 512 + wave * 64]), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      int m = s * BMK + xrow[i];
+      m = m < rows ? m : rows - 1;
+      __builtin_amdgcn_global_load_lds((glb_ptr)(X + (m * ldx + xoff[i])), (lds_ptr)(&st[ZCH + i * 512 + wave * 64]), 16, 0, 0);
+    }
+  };
+
+  constexpr int BROWS = 512 / CZ;                      // rows of a stage one pass of the workgroup's bias sums covers
+  const int bc = tid % CZ;
+  float bsum[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) bsum[e] = 0.f;
+  const bool do_bias = p.bslab != nullptr;
+
+  f32x4 acc[4][4];                                     // [ki][ni]: D[i = k][j = n]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Fragment reads (ds_read_b64_tr_b16, as in gemm_tn_kernel): the 16 lanes of group g fetch a [4 rows][16 cols] block, lane
+  // (q, pp) = (r >> 2, r & 3) addresses row 8 g + q (+ 4: second half, + 32: second MFMA), columns 4 pp .. 4 pp + 3.  Rows
+  // r0 and r0 + 4 share a swizzle, so one address per 16-column block and immediates for the rest.  Every LDS read of the
+  // loop is inline asm: a compiler-visible read behind an LDS-DMA gets an s_waitcnt vmcnt(0) in front of it (and
+  // __syncthreads() one in front of the barrier), which would drain the two steps in flight at every step.
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)lds;
+  const int q = r >> 2, pp = r & 3;
+  const int r0 = 8 * g + q, s0 = TnCfg<T>::swz(r0);
+  unsigned ax[4], az[4], ab[BMK / BROWS];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ax[i] = (unsigned)((ZCH + r0 * CX + ((wk * 8 + 2 * i) ^ s0)) * 16 + pp * 8);
+    az[i] = (unsigned)((r0 * CZ + ((wn * 8 + 2 * i) ^ s0)) * 16 + pp * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < BMK / BROWS; ++i) {
+    const int row = tid / CZ + BROWS * i;
+    ab[i] = (unsigned)((row * CZ + (bc ^ TnCfg<T>::swz(row))) * 16);
+  }
+#define CUM_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+
+  const int nsteps = (rows + BMK - 1) / BMK;
+  issue(0, 0);
+  if (nsteps > 1) issue(1, 1);
+  int buf = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NZ + NX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((s + 1) * BMK > rows) {                        // ragged last step: rows past the end contribute nothing
+      uint4 *st = lds + buf * STG;
+#pragma unroll
+      for (int i = 0; i < NZ; ++i)
+        if (s * BMK + zrow[i] >= rows) st[i * 512 + tid] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (s * BMK + xrow[i] >= rows) st[ZCH + i * 512 + tid] = make_uint4(0, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");            // step s is visible; every wave is done with step s - 1
+    if (s + 2 < nsteps) issue(s + 2, buf == 0 ? 2 : buf - 1);
+    const unsigned sb = lds0 + (unsigned)(buf * STG * 16);
+    u32x2 xl[2][4], xh[2][4], zl[2][4], zh[2][4];
+    u32x4 bv[BMK / BROWS];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      CUM_TR(xl[0][i], sb + ax[i], 0);
+      CUM_TR(xh[0][i], sb + ax[i], 4 * CX * 16);
+      CUM_TR(zl[0][i], sb + az[i], 0);
+      CUM_TR(zh[0][i], sb + az[i], 4 * CZ * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < BMK / BROWS; ++i)            // (unconditional: a branch here would put copies in front of the waits)
+      asm volatile("ds_read_b128 %0, %1" : "=v"(bv[i]) : "v"(sb + ab[i]) : "memory");
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      // the wait takes the read results themselves as operands: nothing the compiler emits may touch them before it
+#define CUM_TR_WAIT(n)                                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(%16)"                                                                            \
+               : "+v"(xl[kk][0]), "+v"(xl[kk][1]), "+v"(xl[kk][2]), "+v"(xl[kk][3]), "+v"(xh[kk][0]), "+v"(xh[kk][1]), \
+                 "+v"(xh[kk][2]), "+v"(xh[kk][3]), "+v"(zl[kk][0]), "+v"(zl[kk][1]), "+v"(zl[kk][2]), "+v"(zl[kk][3]), \
+                 "+v"(zh[kk][0]), "+v"(zh[kk][1]), "+v"(zh[kk][2]), "+v"(zh[kk][3])                                    \
+               : "n"(n) : "memory")
+      __builtin_amdgcn_sched_barrier(0);               // (the first batch of MFMAs stays in front of the second wait)
+      if (kk == 0) CUM_TR_WAIT(BMK / BROWS);           // (lgkmcnt counts to 15: the second batch is issued behind this wait)
+      else CUM_TR_WAIT(0);
+#undef CUM_TR_WAIT
+      if (kk == 0) {                                   // the second batch's reads fly under the first batch's MFMAs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          CUM_TR(xl[1][i], sb + ax[i], 32 * CX * 16);
+          CUM_TR(xh[1][i], sb + ax[i], 36 * CX * 16);
+          CUM_TR(zl[1][i], sb + az[i], 32 * CZ * 16);
+          CUM_TR(zh[1][i], sb + az[i], 36 * CZ * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      u32x4 xf[4], zf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xf[i] = __builtin_shufflevector(xl[kk][i], xh[kk][i], 0, 1, 2, 3);
+        zf[i] = __builtin_shufflevector(zl[kk][i], zh[kk][i], 0, 1, 2, 3);
+      }
+#pragma unroll
+      for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          if constexpr (__is_same(T, f16))
+            acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf[ki]),
+                                                                 __builtin_bit_cast(f16x8, zf[ni]), acc[ki][ni], 0, 0, 0);
+          else
+            acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[ki]),
+                                                                  __builtin_bit_cast(bf16x8, zf[ni]), acc[ki][ni], 0, 0, 0);
+        }
+      if (kk == 0) {                                   // the dZ rows' column sums ride in the first MFMA batch's shadow
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BMK / BROWS == 2)
+          asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(bv[0]), "+v"(bv[1]) : : "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[BMK / BROWS - 1]) : : "memory");
+#pragma unroll
+        for (int i = 0; i < BMK / BROWS; ++i) {
+          if constexpr (__is_same(T, f16)) {
+            const f16x8 h = __builtin_bit_cast(f16x8, bv[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += (float)h[e];
+          } else {
+            const bf16x8 h = __builtin_bit_cast(bf16x8, bv[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += (float)h[e];
+          }
+        }
+      }
+    }
+    buf = buf == NST - 1 ? 0 : buf + 1;
+  }
+#undef CUM_TR
+
+  // ---- slab store: lane holds D[k = kb + 4g + j][n = nb + r]
+  float *slab = p.slab + (int64_t)sp * p.Np * p.Kp;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = wn * 64 + ni * 16 + r;
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki) {
+      const int k = wk * 64 + ki * 16 + 4 * g;
+      *reinterpret_cast<float4 *>(slab + (int64_t)n * p.Kp + k) =
+          make_float4(acc[ki][ni][0], acc[ki][ni][1], acc[ki][ni][2], acc[ki][ni][3]);
+    }
+  }
+  if (do_bias) {                                       // threads with the same column chunk hold partial sums
+    __syncthreads();                                   // the last step's reads are done: the stages are free
+    float *red = reinterpret_cast<float *>(lds);       // [512 / CZ][NT]
+    const int tr = tid / CZ;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[tr * NT + bc * EPC + e] = bsum[e];
+    __syncthreads();
+    if (tid < NT) {
+      float sum = 0.f;
+      for (int j = 0; j < 512 / CZ; ++j) sum += red[j * NT + tid];
+      p.bslab[(int64_t)sp * p.Np + tid] = sum;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- 256 x 256 output tile, 8 waves (16-bit types)
 // Same pipeline as gemm_nt8_kernel (gemm.hip): a reduction step of 64 rows is four 16 KB UNITS -- X columns 0-127 /
 // 128-255 of the tile (X0, X1) and dZ columns 0-127 / 128-255 (Z0, Z1), each [64 rows][16 chunks] in the swizzled
@@ -913,8 +1138,26 @@ static bool tn_use8(int64_t M, int32_t N, int32_t K, int32_t dtype) {
   return is16(dtype) && N % 256 == 0 && K % 256 == 0 && M >= 256 && tn8_enabled();
 }
 
+// The streaming kernel (gemm_tn_stream_kernel): 16-bit types, a padded result of exactly 128 x 256 or 256 x 128, and enough
+// rows that 256 splits (one workgroup per CU, one resident round) still run >= 8 steps each.
+static bool tn_use_stream(int64_t M, int32_t N, int32_t K, int32_t dtype) {
+  if (!is16(dtype) || tn_use8(M, N, K, dtype) || cum_knob("CUM_TN_STREAM", 1) == 0) return false;
+  const int np = (N + TN_T - 1) / TN_T, kp = (K + TN_T - 1) / TN_T;
+  return np * kp == 2 && M >= 256 * 64 * 8;
+}
+
 static void tn_plan(int64_t M, int32_t N, int32_t K, int32_t dtype, int *Np, int *Kp, int *S, int *rps) {
   const int force = (int)cum_knob("CUM_TN_SPLITS", 0);             // AB build: pins the split count
+  if (tn_use_stream(M, N, K, dtype)) {
+    *Np = (N + TN_T - 1) / TN_T * TN_T;
+    *Kp = (K + TN_T - 1) / TN_T * TN_T;
+    int64_t rows = (M + 255) / 256;
+    if (force > 0) rows = (M + force - 1) / force;
+    rows = (rows + 63) / 64 * 64;
+    *rps = (int)rows;
+    *S = (int)((M + rows - 1) / rows);
+    return;
+  }
   if (tn_use8(M, N, K, dtype)) {
     *Np = N;
     *Kp = K;
@@ -961,7 +1204,7 @@ extern "C" int64_t cum_gemm_tn_workspace_elems(int32_t dtype, int64_t M, int32_t
 }
 
 extern "C" int cum_gemm_tn_tile(int32_t dtype, int64_t M, int32_t N, int32_t K) {
-  return tn_use8(M, N, K, dtype) ? 256 : TN_T;
+  return tn_use8(M, N, K, dtype) ? 256 : tn_use_stream(M, N, K, dtype) ? 384 : TN_T;
 }
 
 static int gemm_tn_impl(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
@@ -1019,6 +1262,16 @@ static int gemm_tn_impl(int32_t dtype, int64_t M, int32_t N, int32_t K, const vo
       hipLaunchKernelGGL(gemm_tn9_kernel<__bf16>, grid8, block8, 0, st, p);
     else
       hipLaunchKernelGGL(gemm_tn9_kernel<f16>, grid8, block8, 0, st, p);
+  } else if (tn_use_stream(M, N, K, dtype)) {
+    CUM_REQUIRE((int64_t)rps * (ldz > ldx ? ldz : ldx) + 512 < (int64_t)1 << 31, "gemm_tn: a row split exceeds 2^31 elements");
+    const dim3 gs(S), bs(512);
+    if (Np == 128) {
+      if (dtype == CUM_BF16) hipLaunchKernelGGL((gemm_tn_stream_kernel<__bf16, 128, 256>), gs, bs, 0, st, p);
+      else hipLaunchKernelGGL((gemm_tn_stream_kernel<f16, 128, 256>), gs, bs, 0, st, p);
+    } else {
+      if (dtype == CUM_BF16) hipLaunchKernelGGL((gemm_tn_stream_kernel<__bf16, 256, 128>), gs, bs, 0, st, p);
+      else hipLaunchKernelGGL((gemm_tn_stream_kernel<f16, 256, 128>), gs, bs, 0, st, p);
+    }
   } else if (dtype == CUM_BF16)
     hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, block, 0, st, p);
   else if (dtype == CUM_F16)

@@ -294,7 +294,8 @@ typedef struct {
 int cum_gemm_tn_scatter(int32_t dtype, int64_t M, int32_t N, int32_t K, const void *dZ, int64_t ldz, const void *X,
                         int64_t ldx, const cum_tn_scatter *jobs, int32_t njobs, float *workspace, void *stream);
 
-/* Output tile edge of the kernel cum_gemm_tn runs for this problem: 256 (ping-pong kernel) or 128. */
+/* Kernel cum_gemm_tn runs for this problem: 256 (ping-pong kernel, 256 x 256 tiles), 384 (streaming kernel: the whole
+ * 128 x 256 / 256 x 128 result per workgroup) or 128 (128 x 128 tiles). */
 int cum_gemm_tn_tile(int32_t dtype, int64_t M, int32_t N, int32_t K);
 
 /* ---- multi-resolution STFT loss around rocFFT (src/util/stft_loss.py:16-184) -------------------------------------

@@ -254,6 +254,7 @@ def test_every_gemm_of_the_b16_step_against_f64(cuda, dtype):
     tn_tiles = {k: lib.cum_gemm_tn_tile(dc, k[0], k[1], k[2]) for k in tn}
     for M in rows:
         assert any(t == 256 for k, t in tn_tiles.items() if k[0] == M), M
+    assert sum(t == 384 for t in tn_tiles.values()) >= 2, tn_tiles          # enc1 / dec6: the streaming kernel
     assert any(t == 128 for t in tiles.values()) and any(t == 64 for t in tiles.values())
     # ---- every distinct call against f64
     for i, key in enumerate(nt):
@@ -262,6 +263,20 @@ def test_every_gemm_of_the_b16_step_against_f64(cuda, dtype):
     for i, key in enumerate(tn):
         _check_tn(cuda, dtype, key, f"b16.tn[{i}:{key[0]}x{key[1]}x{key[2]}:tile{tn_tiles[key]}]")
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(641024, 128, 256, 128, 128, True), (641024, 256, 128, 256, 128, True),
+                                   (131072 + 64 * 3 + 17, 96, 200, 96, 200, True), (200003, 256, 72, 256, 72, False),
+                                   (150001, 128, 256, 136, 264, False)])
+def test_streaming_weight_gradient_kernel(cuda, dtype, shape):
+    """gemm_tn_stream_kernel (the 128 x 256 / 256 x 128 results of the two widest layers): the E8 B = 16 shapes (the conv's
+    overlapping rows: ldx = K / 2), ragged row counts (the last split ends inside a 64-row step), column counts that end
+    inside the padded result, with and without the bias gradient -- against f64."""
+    from cleanumamba_amd import hip
+    M, N, K = shape[:3]
+    assert hip.lib().cum_gemm_tn_tile(hip.dtype_code(dtype), M, N, K) == 384
+    _check_tn(cuda, dtype, shape, f"tn_stream[{dtype}:{M}x{N}x{K}:ldx{shape[4]}]")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

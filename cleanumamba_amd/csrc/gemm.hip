@@ -28,6 +28,7 @@
 // share a CU, and their interleaving hides the load latency (CDNA guide: the 128x128 "step-3"
 // structure).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace cum {
@@ -59,6 +60,7 @@ struct GemmParams {
   int n_store;             // number of output columns to store (<= N, or N/2 for GLU); multiple of 4
   int64_t zero_head, zero_tail;
   int rows_epilogue;       // gemm_nt8_kernel: GLU_BWD epilogue through LDS (CUM_NT8_ROWS=0 turns it off for A/B runs)
+  int group_m;             // gemm_nt9_kernel: m-tiles an XCD walks side by side (launch_gemm_nt9)
 };
 
 template <typename T>
@@ -1098,10 +1100,17 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
   const int wave = uniform(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int g = lane >> 4, r = lane & 15;
+  // Tile order: workgroup ids b, b + 8, ... run on one XCD (one L2).  An XCD walks `group_m` of its m-tiles side by side,
+  // n-tile after n-tile: its 32 resident workgroups then cover group_m x (32 / group_m) tiles and pull group_m A panels +
+  // 32 / group_m W panels per K-tile through its L2 instead of 1 + 32 (group_m = 1: one m-tile after the other, which is what
+  // the layers' N <= 1 536 = 6 n-tiles want; a square GEMM with 32 n-tiles streams all of W per m-tile that way).
   const int NB = (p.N + 255) / 256;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int m_tile = (local / NB) * 8 + xcd;
-  const int n0 = (local % NB) * 256;
+  const int per = p.group_m * NB, grp = local / per, within = local - grp * per;
+  const int left = (int)gridDim.x / (8 * NB) - grp * p.group_m;
+  const int gm = left < p.group_m ? left : p.group_m;
+  const int m_tile = (grp * p.group_m + within % gm) * 8 + xcd;
+  const int n0 = (within / gm) * 256;
   const int m0 = m_tile * 256;
   if (m0 >= p.M) return;
   if (blockIdx.x == 0) {                              // framing rows of the output buffer (see gemm_nt_kernel)
@@ -1172,6 +1181,11 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
     aW[ks] = lds0 + (unsigned)(((2 + (wc >> 1)) * UNIT + ((wc & 1) * 64 + r) * 8 + (cl ^ (r & 7))) * 16);
   }
 #define CUM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+#ifdef CUM_NT9_TIMING_NO_W_READS   // timing-only build (wrong results): the W fragment reads = the third of the fragment
+#define CUM_DSRW(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))   // bytes four waves of 128 x 128 would not read
+#else
+#define CUM_DSRW(dst, addr, off) CUM_DSR(dst, addr, off)
+#endif
 #define CUM_BAR()                               \
   do {                                          \
     __builtin_amdgcn_sched_barrier(0);          \
@@ -1211,9 +1225,9 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
     const unsigned a0 = aA[0] + pb, a1 = aA[1] + pb, w0 = aW[0] + pb, w1 = aW[1] + pb;
     const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
     // ---- L1: W channels 0-31 and A rows 0-63; group 0 stages the W units of K-tile kt + 1 (freed one slot ago)
-    CUM_DSR(wf[0][0], w0, 0);     CUM_DSR(wf[0][1], w0, 2048);
+    CUM_DSRW(wf[0][0], w0, 0);    CUM_DSRW(wf[0][1], w0, 2048);
     CUM_DSR(af[0][0], a0, 0);     CUM_DSR(af[0][1], a0, 2048);  CUM_DSR(af[0][2], a0, 4096);  CUM_DSR(af[0][3], a0, 6144);
-    CUM_DSR(wf[1][0], w1, 0);     CUM_DSR(wf[1][1], w1, 2048);
+    CUM_DSRW(wf[1][0], w1, 0);    CUM_DSRW(wf[1][1], w1, 2048);
     CUM_DSR(af[1][0], a1, 0);     CUM_DSR(af[1][1], a1, 2048);  CUM_DSR(af[1][2], a1, 4096);  CUM_DSR(af[1][3], a1, 6144);
     if (wr == 0 && kt >= 1 && more1) {
       CUM_STAGE(2, kt + 1, par ^ 1);
@@ -1235,7 +1249,7 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
     CUM_QUAD(1, 0);                                                       // C2
     CUM_BAR();
     // ---- L3: W channels 32-63; the A units of this parity are free: K-tile kt + 2
-    CUM_DSR(wf[0][0], w0, 4096);  CUM_DSR(wf[0][1], w0, 6144);  CUM_DSR(wf[1][0], w1, 4096);  CUM_DSR(wf[1][1], w1, 6144);
+    CUM_DSRW(wf[0][0], w0, 4096); CUM_DSRW(wf[0][1], w0, 6144); CUM_DSRW(wf[1][0], w1, 4096); CUM_DSRW(wf[1][1], w1, 6144);
     if (more2) {
       CUM_STAGE(0, kt + 2, par);
       if (wr != 0) CUM_STAGE(1, kt + 2, par);
@@ -1267,6 +1281,7 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
   }
   if (wr == 0) CUM_BAR();                                                // group 1's last slot
 #undef CUM_HALFQ
+#undef CUM_DSRW
 #undef CUM_DSR
 #undef CUM_QUAD
 #undef CUM_STAGE
@@ -1275,6 +1290,232 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
   nt_epilogue_any<T, EPI, 2, 1>(p, acc, bv, m0, n0, 2 * wr, wc, lane,
                                 reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
 }
+
+#ifdef CUM_AB
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---------------------------------------------------------------- 256 x 256 tile, FOUR waves of 128 x 128 (experiment)
+// Same tile, LDS units and LDS-DMA as gemm_nt9_kernel; one wave per SIMD, its 64 accumulator blocks in AGPRs.  What it is
+// for: a wave of 128 x 128 reads (128 + 128) x 64 x 2 B = 32 KB of fragments per K-tile, 128 KB per CU, where eight waves of
+// 128 x 64 read 192 KB -- with the 64 KB the DMA writes, gemm_nt9_kernel keeps the LDS as busy as the matrix pipe (256 KB =
+// 2 048 clk at 128 B/clk against 2 048 MFMA cycles per SIMD), and a timing-only build of it without the W fragment reads
+// runs the plain 8192^3 GEMM at 1.67 PFLOP/s against 1.30 (profiles/r06_nt_asm_ab.txt).  Every instruction of the K loop
+// is a volatile asm statement, so the order written here is the order issued:
+//   phase A (64 MFMAs on K-half 0): the 32 fragment reads of K-half 1 under MFMAs 0-31; after MFMA 39 lgkmcnt(0) + barrier
+//     (every wave is done reading this parity's units), then the 16 LDS-DMAs of K-tile kt + 2 under MFMAs 40-55;
+//   phase B (64 MFMAs on K-half 1): after MFMA 23 vmcnt(16) + barrier (K-tile kt + 1 has landed for every wave), then the
+//     32 fragment reads of its K-half 0 under MFMAs 24-55, lgkmcnt(0) behind MFMA 63.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt4_kernel(const GemmParams p) {
+  static_assert(sizeof(T) == 2, "16-bit element types only");
+  constexpr int EPC = 8, BK = 64;
+  constexpr int UNIT = 128 * 8;
+  __shared__ uint4 lds_all[2 * 4 * UNIT];             // [K-tile parity][A0, A1, W0, W1]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, r = lane & 15;
+  const int NB = (p.N + 255) / 256;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int per = p.group_m * NB, grp = local / per, within = local - grp * per;
+  const int left = (int)gridDim.x / (8 * NB) - grp * p.group_m;
+  const int gm = left < p.group_m ? left : p.group_m;
+  const int m_tile = (grp * p.group_m + within % gm) * 8 + xcd;
+  const int n0 = (within / gm) * 256;
+  const int m0 = m_tile * 256;
+  if (m0 >= p.M) return;
+  if (blockIdx.x == 0) {                              // framing rows of the output buffer (see gemm_nt_kernel)
+    T *o = static_cast<T *>(p.out);
+    T *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD && !(EPI == EPI_RELU && p.mask_bits)) ? static_cast<T *>(p.aux) : nullptr;
+    for (int64_t i = threadIdx.x; i < p.zero_head; i += 256) {
+      o[-1 - i] = Elem<T>::from_f(0.f);
+      if (x) x[-1 - i] = Elem<T>::from_f(0.f);
+    }
+    const int64_t tail0 = (int64_t)p.M * p.ldc, tailx = (int64_t)p.M * p.ldz;
+    for (int64_t i = threadIdx.x; i < p.zero_tail; i += 256) {
+      o[tail0 + i] = Elem<T>::from_f(0.f);
+      if (x) x[tailx + i] = Elem<T>::from_f(0.f);
+    }
+  }
+  const T *A = static_cast<const T *>(p.A);
+  const T *W = static_cast<const T *>(p.W);
+  const T *src[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pos = it * 256 + tid;
+      const int row = pos >> 3, cphys = pos & 7;
+      const int clog = cphys ^ (row & 7);
+      if (u < 2) {
+        int am = m0 + 128 * u + row;
+        am = am < p.M ? am : p.M - 1;
+        src[u][it] = A + (int64_t)am * p.lda + clog * EPC;
+      } else {
+        int wn_ = n0 + 128 * (u - 2) + row;
+        wn_ = wn_ < p.N ? wn_ : p.N - 1;
+        src[u][it] = W + (int64_t)wn_ * p.ldw + clog * EPC;
+      }
+    }
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+#define CUM_DMA(u, it, kt, par)                                                                       \
+  __builtin_amdgcn_global_load_lds((glb_ptr)(src[u][it] + (kt) * BK),                                 \
+                                   (lds_ptr)(&lds_all[((par) * 4 + (u)) * UNIT + (it) * 256 + wave * 64]), 16, 0, 0)
+
+  f32x4 acc[8][8];                                    // [ni][mi] in AGPRs: channels 128 wc + 16 ni, rows 128 wr + 16 mi
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) CUM_DMA(u, it, 0, 0);
+  {
+    const int k1 = nk > 1 ? 1 : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) CUM_DMA(u, it, k1, 1);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)lds_all;
+  unsigned aA[2], aW[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int cl = ks * 4 + g;
+    aA[ks] = lds0 + (unsigned)((wr * UNIT + r * 8 + (cl ^ (r & 7))) * 16);
+    aW[ks] = lds0 + (unsigned)(((2 + wc) * UNIT + r * 8 + (cl ^ (r & 7))) * 16);
+  }
+#define CUM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define CUM_WAIT_FRAGS(ks)                                                                                               \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                    \
+               : "+v"(af[ks][0]), "+v"(af[ks][1]), "+v"(af[ks][2]), "+v"(af[ks][3]), "+v"(af[ks][4]), "+v"(af[ks][5]),   \
+                 "+v"(af[ks][6]), "+v"(af[ks][7]), "+v"(wf[ks][0]), "+v"(wf[ks][1]), "+v"(wf[ks][2]), "+v"(wf[ks][3]),   \
+                 "+v"(wf[ks][4]), "+v"(wf[ks][5]), "+v"(wf[ks][6]), "+v"(wf[ks][7]) : : "memory")
+#define CUM_MFMA(ks, ni, mi)                                                                                             \
+  do {                                                                                                                   \
+    if constexpr (__is_same(T, f16))                                                                                     \
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[ni][mi]) : "v"(wf[ks][ni]), "v"(af[ks][mi]));     \
+    else                                                                                                                 \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ni][mi]) : "v"(wf[ks][ni]), "v"(af[ks][mi]));    \
+  } while (0)
+  // fragment read number J (0-15) of K-half KS at parity offset pb: A block J / 2 (even J) or W block J / 2 (odd J)
+#define CUM_FRAG(KS, J, pb)                                                             \
+  do {                                                                                  \
+    if constexpr (((J) & 1) != 0) CUM_DSR(wf[KS][(J) >> 1], aW[KS] + (pb), ((J) >> 1) * 2048); \
+    else CUM_DSR(af[KS][(J) >> 1], aA[KS] + (pb), ((J) >> 1) * 2048);                   \
+  } while (0)
+
+  u32x4 af[2][8], wf[2][8];
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                     // K-tile 0 landed; K-tile 1 stays in flight
+  asm volatile("s_barrier" ::: "memory");
+  static_for<0, 16>([&](auto ic) {
+    constexpr int j = decltype(ic)::value;
+    CUM_FRAG(0, j, 0u);
+  });
+  CUM_WAIT_FRAGS(0);
+  // The loop body is branch-free (with accumulators in asm operands every branch costs the allocator its grip on them): the
+  // last two K-tiles re-fetch K-tile nk - 1 into the free parity and read fragments nobody uses.
+#ifndef CUM_NT4_PA
+#define CUM_NT4_PA 40      // MFMAs of phase A in front of the "units free" barrier (16 ... 48)
+#endif
+#ifndef CUM_NT4_PB
+#define CUM_NT4_PB 24      // MFMAs of phase B in front of the "next K-tile landed" barrier (0 ... 48)
+#endif
+#ifdef CUM_NT4_NOBAR       // timing-only: no barriers (races)
+#define CUM_NT4_BAR() asm volatile("" ::: "memory")
+#else
+#define CUM_NT4_BAR() asm volatile("s_barrier" ::: "memory")
+#endif
+#ifdef CUM_NT4_NODMA        // timing-only: no LDS-DMA in the loop
+#define CUM_DMA_L(u, it, kt, par) asm volatile("" ::: "memory")
+#else
+#define CUM_DMA_L(u, it, kt, par) CUM_DMA(u, it, kt, par)
+#endif
+#ifdef CUM_NT4_NOREAD       // timing-only: no fragment reads in the loop
+#define CUM_FRAG_L(KS, J, pb) asm volatile("" ::: "memory")
+#else
+#define CUM_FRAG_L(KS, J, pb) CUM_FRAG(KS, J, pb)
+#endif
+  constexpr int PA = CUM_NT4_PA, PB = CUM_NT4_PB;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int par = kt & 1;
+    const unsigned pb = (unsigned)par * (4 * UNIT * 16), pn = pb ^ (4 * UNIT * 16);
+    const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
+    // ---- phase A: K-half 0
+    static_for<0, PA>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      CUM_MFMA(0, i >> 3, i & 7);
+      if constexpr (i < 16) CUM_FRAG_L(1, i, pb);
+    });
+    CUM_WAIT_FRAGS(1);
+    CUM_NT4_BAR();                                                       // this parity's units are free
+    static_for<PA, PA + 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      CUM_MFMA(0, i >> 3, i & 7);
+      CUM_DMA_L((i - PA) >> 2, (i - PA) & 3, kt2, par);
+    });
+    static_for<PA + 16, 64>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      CUM_MFMA(0, i >> 3, i & 7);
+    });
+    // ---- phase B: K-half 1
+    static_for<0, PB>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      CUM_MFMA(1, i >> 3, i & 7);
+    });
+    #ifndef CUM_NT4_NODMA
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#endif
+    CUM_NT4_BAR();                                                       // K-tile kt + 1 is visible to every wave
+    static_for<PB, PB + 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      CUM_MFMA(1, i >> 3, i & 7);
+      CUM_FRAG_L(0, i - PB, pn);
+    });
+    static_for<PB + 16, 64>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      CUM_MFMA(1, i >> 3, i & 7);
+    });
+    CUM_WAIT_FRAGS(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef CUM_DSR
+#undef CUM_WAIT_FRAGS
+#undef CUM_MFMA
+#undef CUM_FRAG
+#undef CUM_DMA
+  // the last MFMAs' results must be in the AGPRs before anything the compiler emits reads them (it sees asm outputs as
+  // ready at once): the blocks of the last eight MFMAs go through the nops
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_barrier"
+               : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
+                 "+a"(acc[7][6]), "+a"(acc[7][7]) : : "memory");
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float bv[4][4];
+    nt_load_bias(p, n0, 2 * wc + h, g, bv);
+    f32x4 part[2][4][4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) part[hh][ni][mi] = acc[4 * h + ni][4 * hh + mi];
+    nt_epilogue_any<T, EPI, 2, 1>(p, part, bv, m0, n0, 2 * wr, 2 * wc + h, lane,
+                                  reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
+  }
+}
+#endif  // CUM_AB
 
 // ---------------------------------------------------------------- small-M variant (streaming hops)
 // Launches with only a few dozen 128x128 tiles (M = streams x a handful of rows) leave most of the chip idle while
@@ -1502,10 +1743,35 @@ static int launch_gemm_nt8(const GemmParams &p, int epi, hipStream_t st) {
 #endif  // CUM_AB
 
 template <typename T>
-static int launch_gemm_nt9(const GemmParams &p, int epi, hipStream_t st) {
+static int launch_gemm_nt9(const GemmParams &p0, int epi, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
+    GemmParams p = p0;
     const int NB = (p.N + 255) / 256, MB = (p.M + 255) / 256;
     dim3 grid(8 * NB * ((MB + 7) / 8)), block(512);
+    p.group_m = (int)cum_knob("CUM_NT_GROUPM", NB >= 24 ? 4 : 1);
+    if (p.group_m < 1) p.group_m = 1;
+#ifdef CUM_AB
+#ifdef CUM_NT4_ONLY_BIAS                              // (tuning builds: one instantiation, a fifth of the compile time)
+    if (cum_knob("CUM_NT4", 0) != 0 && epi == EPI_BIAS) {
+      hipLaunchKernelGGL((gemm_nt4_kernel<T, EPI_BIAS>), grid, dim3(256), 0, st, p);
+      CUM_CHECK_LAUNCH();
+      return CUM_OK;
+    }
+#else
+    if (cum_knob("CUM_NT4", 0) != 0) {                 // the four-wave experiment (gemm_nt4_kernel)
+      const dim3 b4(256);
+      switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt4_kernel<T, EPI_BIAS>), grid, b4, 0, st, p); break;
+        case EPI_RELU: hipLaunchKernelGGL((gemm_nt4_kernel<T, EPI_RELU>), grid, b4, 0, st, p); break;
+        case EPI_MASK: hipLaunchKernelGGL((gemm_nt4_kernel<T, EPI_MASK>), grid, b4, 0, st, p); break;
+        case EPI_GLU_BWD: hipLaunchKernelGGL((gemm_nt4_kernel<T, EPI_GLU_BWD>), grid, b4, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_nt4_kernel<T, EPI_GLU>), grid, b4, 0, st, p); break;
+      }
+      CUM_CHECK_LAUNCH();
+      return CUM_OK;
+    }
+#endif
+#endif
     switch (epi) {
       case EPI_BIAS: hipLaunchKernelGGL((gemm_nt9_kernel<T, EPI_BIAS>), grid, block, 0, st, p); break;
       case EPI_RELU: hipLaunchKernelGGL((gemm_nt9_kernel<T, EPI_RELU>), grid, block, 0, st, p); break;

@@ -13,3 +13,13 @@ bias = torch.zeros(n, device=dev)
 for _ in range(6):
     cs.gemm(A, 0, n, W, bias, out, 0, n, n, 1 << 30, 1 << 30, hip.EPI_BIAS, n)
 torch.cuda.synchronize()
+if "time" in sys.argv:
+    import os
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(20):
+        cs.gemm(A, 0, n, W, bias, out, 0, n, n, 1 << 30, 1 << 30, hip.EPI_BIAS, n)
+    ev[1].record()
+    torch.cuda.synchronize()
+    us = ev[0].elapsed_time(ev[1]) / 20 * 1e3
+    print({"n": n, "us": round(us, 1), "PFLOPs": round(2 * n ** 3 / us * 1e-9, 3), "group_m": os.environ.get("CUM_NT_GROUPM", "default")})

@@ -1291,6 +1291,139 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
                                 reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
 }
 
+// ---------------------------------------------------------------- 128 x 256 tile, 8 waves, three-stage LDS-DMA ring
+// For launches with FEW tiles and a long K axis (M ~ 10 000: the bottleneck's projections with N = 512, the innermost conv
+// layers with N = 768): 312 tiles of 128 x 128 leave a CU one or two single-buffered workgroups, each paying a whole L2
+// round trip per K-step (in_proj's data gradient 76 us where the vendor's stream-K kernel takes 45), and 256 x 256 tiles
+// fill half the chip.  Here a workgroup owns 128 x 256 (<= 256 workgroups: one resident round, one per CU) and walks K
+// through a ring of three 48 KB stages filled by LDS-DMA TWO K-steps ahead: 96 KB per CU in flight behind one counted
+// vmcnt and one barrier per K-step (the stage refilled at step kt is the one every wave finished reading before it arrived
+// at kt's barrier).  Wave tile, fragment layout, MFMA order and epilogues are those of gemm_nt_kernel<T, EPI, 128, 128>
+// (results are bit-identical to it); every LDS read of the loop is inline asm (a compiler-visible read behind an LDS-DMA is
+// given an s_waitcnt vmcnt(0), which would drain the ring at every step).
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmParams p) {
+  static_assert(sizeof(T) == 2, "16-bit element types only");
+  constexpr int EPC = 8, BK = 64, BM = 128, BN = 256, NST = 3;
+  constexpr int STAGE = (BM + BN) * 8;                // 16-byte chunks per stage: A rows, then W rows; 48 KB
+  __shared__ uint4 lds_all[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g = lane >> 4, r = lane & 15;
+  const int NB = (p.N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int m_tile = (local / NB) * 8 + xcd;
+  const int n0 = (local % NB) * BN;
+  const int m0 = m_tile * BM;
+  if (m0 >= p.M) return;
+  if (blockIdx.x == 0) {                              // framing rows of the output buffer (see gemm_nt_kernel)
+    T *o = static_cast<T *>(p.out);
+    T *x = (EPI != EPI_GLU && EPI != EPI_GLU_BWD && !(EPI == EPI_RELU && p.mask_bits)) ? static_cast<T *>(p.aux) : nullptr;
+    for (int64_t i = threadIdx.x; i < p.zero_head; i += 512) {
+      o[-1 - i] = Elem<T>::from_f(0.f);
+      if (x) x[-1 - i] = Elem<T>::from_f(0.f);
+    }
+    const int64_t tail0 = (int64_t)p.M * p.ldc, tailx = (int64_t)p.M * p.ldz;
+    for (int64_t i = threadIdx.x; i < p.zero_tail; i += 512) {
+      o[tail0 + i] = Elem<T>::from_f(0.f);
+      if (x) x[tailx + i] = Elem<T>::from_f(0.f);
+    }
+  }
+  const T *A = static_cast<const T *>(p.A);
+  const T *W = static_cast<const T *>(p.W);
+  const T *ga[2], *gw[4];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int pos = it * 512 + tid, row = pos >> 3, clog = (pos & 7) ^ (row & 7);
+    int am = m0 + row;
+    am = am < p.M ? am : p.M - 1;
+    ga[it] = A + (int64_t)am * p.lda + clog * EPC;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int pos = it * 512 + tid, row = pos >> 3, clog = (pos & 7) ^ (row & 7);
+    int wr = n0 + row;
+    wr = wr < p.N ? wr : p.N - 1;
+    gw[it] = W + (int64_t)wr * p.ldw + clog * EPC;
+  }
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  typedef const __attribute__((address_space(1))) void *glb_ptr;
+  auto issue = [&](int kt, int buf) {
+    uint4 *st = lds_all + buf * STAGE;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(ga[it] + kt * BK), (lds_ptr)(&st[it * 512 + wave * 64]), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(gw[it] + kt * BK), (lds_ptr)(&st[BM * 8 + it * 512 + wave * 64]), 16, 0, 0);
+  };
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bv[4][4];
+  nt_load_bias(p, n0, wn, g, bv);
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)lds_all;
+  unsigned aA[2], aW[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int cl = (ks * 4 + g) ^ (r & 7);
+    aA[ks] = (unsigned)(((wm * 64 + r) * 8 + cl) * 16);
+    aW[ks] = (unsigned)(((BM + wn * 64 + r) * 8 + cl) * 16);
+  }
+#define CUM_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define CUM_FWAIT(n, KS)                                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(%8)"                                                                               \
+               : "+v"(wf[KS][0]), "+v"(wf[KS][1]), "+v"(wf[KS][2]), "+v"(wf[KS][3]), "+v"(af[KS][0]), "+v"(af[KS][1]), \
+                 "+v"(af[KS][2]), "+v"(af[KS][3]) : "n"(n) : "memory")
+  const int nk = p.K / BK;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-step kt landed; kt + 1 stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");            // step kt is visible; every wave is done with step kt - 1
+    if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
+    const unsigned sb = lds0 + (unsigned)(buf * STAGE * 16);
+    u32x4 af[2][4], wf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned a = sb + aA[ks], w = sb + aW[ks];
+      CUM_DSR(wf[ks][0], w, 0); CUM_DSR(wf[ks][1], w, 2048); CUM_DSR(wf[ks][2], w, 4096); CUM_DSR(wf[ks][3], w, 6144);
+      CUM_DSR(af[ks][0], a, 0); CUM_DSR(af[ks][1], a, 2048); CUM_DSR(af[ks][2], a, 4096); CUM_DSR(af[ks][3], a, 6144);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 0) CUM_FWAIT(8, 0);
+      else CUM_FWAIT(0, 1);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          if constexpr (__is_same(T, f16))
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[ks][ni]),
+                                                                 __builtin_bit_cast(f16x8, af[ks][mi]), acc[ni][mi], 0, 0, 0);
+          else
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][ni]),
+                                                                  __builtin_bit_cast(bf16x8, af[ks][mi]), acc[ni][mi], 0, 0, 0);
+        }
+    }
+    buf = buf == NST - 1 ? 0 : buf + 1;
+  }
+#undef CUM_DSR
+#undef CUM_FWAIT
+  asm volatile("s_barrier" ::: "memory");              // every wave is done reading the ring: it is the epilogues' space now
+  nt_epilogue_any<T, EPI, 1, (EPI == EPI_GLU_BWD) ? 1 : 0>(p, &acc, bv, m0, n0, wm, wn, lane,
+                                reinterpret_cast<unsigned char *>(lds_all) + wave * nt_rows_lds(EPI));
+}
+
 #ifdef CUM_AB
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -1784,6 +1917,23 @@ static int launch_gemm_nt9(const GemmParams &p0, int epi, hipStream_t st) {
   return CUM_OK;
 }
 
+template <typename T>
+static int launch_gemm_ring(const GemmParams &p, int epi, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    const int NB = (p.N + 255) / 256, MB = (p.M + 127) / 128;
+    dim3 grid(8 * NB * ((MB + 7) / 8)), block(512);
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_ring_kernel<T, EPI_BIAS>), grid, block, 0, st, p); break;
+      case EPI_RELU: hipLaunchKernelGGL((gemm_nt_ring_kernel<T, EPI_RELU>), grid, block, 0, st, p); break;
+      case EPI_MASK: hipLaunchKernelGGL((gemm_nt_ring_kernel<T, EPI_MASK>), grid, block, 0, st, p); break;
+      case EPI_GLU_BWD: hipLaunchKernelGGL((gemm_nt_ring_kernel<T, EPI_GLU_BWD>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm_nt_ring_kernel<T, EPI_GLU>), grid, block, 0, st, p); break;
+    }
+    CUM_CHECK_LAUNCH();
+  }
+  return CUM_OK;
+}
+
 template <typename T, int BM, int BN>
 static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
   const int NB = (p.N + BN - 1) / BN, MB = (p.M + BM - 1) / BM;
@@ -1800,7 +1950,8 @@ static int launch_gemm_tile(const GemmParams &p, int epi, hipStream_t st) {
 }
 
 // Tile choice of cum_gemm_nt for one problem (esz: element size).  64 = the small-M kernel (64 x 64 tiles, K split over
-// the four waves), 128 = 128 x 128, 256 = 256 x 128 (f32), 512 = 256 x 256 with the two wave groups in ping-pong (16-bit).
+// the four waves), 128 = 128 x 128, 256 = 256 x 128 (f32), 384 = 128 x 256 through the three-stage ring (16-bit, few tiles),
+// 512 = 256 x 256 with the two wave groups in ping-pong (16-bit).
 // cum_gemm_nt_tile() reports it, so tests can tell which kernel a shape is verified on.
 static int choose_tile(const GemmParams &p, int esz) {
   const int64_t mb256 = (p.M + 255) / 256;
@@ -1825,6 +1976,9 @@ static int choose_tile(const GemmParams &p, int esz) {
     // never take this tile: the 128 x 128 kernel routes its epilogue through LDS, which the outer, HBM-bound layers gain
     // more from than from the taller tile.
     else if (esz == 4 && p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
+    // few tiles, long K (M ~ 10 000 with N = 512 / 768): 128 x 256 tiles through the three-stage ring, one resident round
+    else if (esz == 2 && p.N % 256 == 0 && p.K >= 512 && ((p.M + 127) / 128) * (int64_t)(p.N / 256) <= cum_knob("CUM_NT_RING", 256))
+      tile = 384;
     else tile = 128;
   }
   if (esz == 2) {
@@ -1847,6 +2001,7 @@ static int launch_gemm(const GemmParams &p, int epi, hipStream_t st) {
 #endif
       return launch_gemm_nt9<T>(p, epi, st);
     }
+    if (tile == 384) return launch_gemm_ring<T>(p, epi, st);
 #ifdef CUM_AB
     if (tile == 256) return launch_gemm_tile<T, 256, 128>(p, epi, st);
 #endif

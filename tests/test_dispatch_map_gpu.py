@@ -256,6 +256,9 @@ def test_every_gemm_of_the_b16_step_against_f64(cuda, dtype):
         assert any(t == 256 for k, t in tn_tiles.items() if k[0] == M), M
     assert sum(t == 384 for t in tn_tiles.values()) >= 2, tn_tiles          # enc1 / dec6: the streaming kernel
     assert any(t == 128 for t in tiles.values()) and any(t == 64 for t in tiles.values())
+    # the M ~ 10 000 launches with N = 512 / 768 and a long K axis: the 128 x 256 ring kernel (tile id 384), all epilogues they use
+    ring = sorted({(k[0], k[2], k[3]) for k, t in tiles.items() if t == 384})
+    assert {e for e, _, _ in ring} >= {hip.EPI_BIAS, hip.EPI_RELU, hip.EPI_GLU_BWD} and (0, 512, 4096) in ring, ring
     # ---- every distinct call against f64
     for i, key in enumerate(nt):
         _check_nt(cuda, dtype, key, f"b16.nt[{i}:epi{key[0]}:{key[1]}x{key[2]}x{key[3]}:tile{tiles[key]}]")

@@ -1304,7 +1304,11 @@ __global__ __launch_bounds__(512) void gemm_nt9_kernel(const GemmParams p) {
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit element types only");
-  constexpr int EPC = 8, BK = 64, BM = 128, BN = 256, NST = 3;
+#ifndef CUM_RING_NST
+#define CUM_RING_NST 3      // (2: one K-step in flight -- the timing experiment of profiles/r06_nt_ring_ab.txt)
+#endif
+  constexpr int EPC = 8, BK = 64, BM = 128, BN = 256, NST = CUM_RING_NST;
+  static_assert(NST == 2 || NST == 3, "two or three stages");
   constexpr int STAGE = (BM + BN) * 8;                // 16-byte chunks per stage: A rows, then W rows; 48 KB
   __shared__ uint4 lds_all[NST * STAGE];
 
@@ -1383,13 +1387,13 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmParams p) {
                  "+v"(af[KS][2]), "+v"(af[KS][3]) : "n"(n) : "memory")
   const int nk = p.K / BK;
   issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  if (NST == 3 && nk > 1) issue(1, 1);
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-step kt landed; kt + 1 stays in flight
+    if (NST == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-step kt landed; kt + 1 stays in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");            // step kt is visible; every wave is done with step kt - 1
-    if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
+    if (kt + NST - 1 < nk) issue(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
     const unsigned sb = lds0 + (unsigned)(buf * STAGE * 16);
     u32x4 af[2][4], wf[2][4];
 #pragma unroll

@@ -284,14 +284,16 @@ def test_streaming_weight_gradient_kernel(cuda, dtype, shape):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
-def test_ping_pong_kernel_ragged_rows_every_epilogue(cuda, dtype, epi):
-    """gemm_nt9_kernel on a row count that ends inside a 256-row tile (and inside a 64-row wave slab), every epilogue
-    with its optional operands: residual, pre-activation copies, sign nibbles both ways, gate-only GLU forms."""
+@pytest.mark.parametrize("kernel", ["nt9", "ring"])
+def test_ping_pong_kernel_ragged_rows_every_epilogue(cuda, dtype, epi, kernel):
+    """gemm_nt9_kernel (256 x 256 ping-pong; tile id 512) and gemm_nt_ring_kernel (128 x 256 through the three-stage ring; tile
+    id 384) on a row count that ends inside a tile (and inside a 64-row wave slab), every epilogue with its optional operands:
+    residual, pre-activation copies, sign nibbles both ways, gate-only GLU forms."""
     from cleanumamba_amd import hip
-    M, N, K = 60000 + 77, 768, 1536
+    M, N, K = (60000 + 77, 768, 1536) if kernel == "nt9" else (10000 + 77, 768, 1536)
     d = hip.GemmDesc()
     d.dtype, d.M, d.N, d.K = hip.dtype_code(dtype), M, N, K
-    assert hip.lib().cum_gemm_nt_tile(ctypes.byref(d)) == 512
+    assert hip.lib().cum_gemm_nt_tile(ctypes.byref(d)) == (512 if kernel == "nt9" else 384)
     n_store = N // 2 if epi == hip.EPI_GLU else N
     cases = {
         0: [(True, N, False, 0, False, 0, False, False)],
@@ -304,7 +306,7 @@ def test_ping_pong_kernel_ragged_rows_every_epilogue(cuda, dtype, epi):
         ldc = 2 * N if epi == hip.EPI_GLU_BWD else n_store
         key = (epi, M, N, K, K, ldc, 5003, 5001, n_store, has_res, ldr, has_aux, ldz, has_aux2, ldy, gate_only, mask_bits,
                False, epi != hip.EPI_GLU_BWD, None, 0, 0)
-        _check_nt(cuda, dtype, key, f"nt9.ragged[{dtype}:epi{epi}:{ci}]")
+        _check_nt(cuda, dtype, key, f"{kernel}.ragged[{dtype}:epi{epi}:{ci}]")
 
 
 def _e6_net(cuda):

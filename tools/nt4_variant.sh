@@ -1,5 +1,6 @@
 #!/bin/bash
-# tools/_ab/nt4_variant.sh NAME "-DCUM_NT4_PA=.. ..."  -> tools/_ab/lib_nt4_NAME.so (gemm.hip rebuilt with the flags, other objects reused)
+# tools/nt4_variant.sh NAME "-DCUM_NT4_PA=.. ..."  -> tools/_ab/lib_nt4_NAME.so: gemm.hip rebuilt with -DCUM_AB -DCUM_NT4_ONLY_BIAS and
+# the flags given, the other objects taken from an AB build in tools/_ab/build/ (make AB=1 objects copied there); CPU container.
 set -e
 cd /root/repo/cleanumamba_amd/csrc
 d=/tmp/nt4v_$1; mkdir -p $d; cp ../../tools/_ab/build/*.o $d/

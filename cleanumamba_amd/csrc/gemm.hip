@@ -1981,7 +1981,9 @@ static int choose_tile(const GemmParams &p, int esz) {
     // more from than from the taller tile.
     else if (esz == 4 && p.K >= 256 && tiles_256x128 >= 1024) tile = 256;
     // few tiles, long K (M ~ 10 000 with N = 512 / 768): 128 x 256 tiles through the three-stage ring, one resident round
-    else if (esz == 2 && p.N % 256 == 0 && p.K >= 512 && ((p.M + 127) / 128) * (int64_t)(p.N / 256) <= cum_knob("CUM_NT_RING", 256))
+    // (from 40 tiles up: below that -- batch-1 inference, M ~ 600 -- twice as many 128 x 128 workgroups measured 1-2 % ahead)
+    else if (esz == 2 && p.N % 256 == 0 && p.K >= 512 && ((p.M + 127) / 128) * (int64_t)(p.N / 256) <= cum_knob("CUM_NT_RING", 256) &&
+             ((p.M + 127) / 128) * (int64_t)(p.N / 256) >= 40)
       tile = 384;
     else tile = 128;
   }

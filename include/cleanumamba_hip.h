@@ -241,7 +241,7 @@ int cum_gemm_nt(const cum_gemm_desc *d, const void *A, const void *W, const floa
                 const void *res, void *out, void *aux, const void *aux2, void *stream);
 /* Which kernel cum_gemm_nt runs for this problem (only dtype, M, N, K, allow_split_k are read): 64 = 64 x 64 tiles with
  * K split over the waves, 128 = 128 x 128, 256 = 256 x 128 (f32), 384 = 128 x 256 through a three-stage LDS ring (16-bit,
- * launches with <= 256 such tiles and K >= 512), 512 = 256 x 256 with two wave groups in ping-pong (16-bit).  Lets a
+ * launches with 40 ... 256 such tiles and K >= 512), 512 = 256 x 256 with two wave groups in ping-pong (16-bit).  Lets a
  * parity test state which kernel a shape was verified on. */
 int cum_gemm_nt_tile(const cum_gemm_desc *d);
 
